@@ -1,0 +1,457 @@
+/*
+ * csgn_oracle.c -- CPU restatement of the certFHE/CSGN ciphertext-arithmetic hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see csgn_oracle.h).  Plain C99, single-threaded, no
+ * dependencies.  Parity: PINNED against oracle/_ref (the real reference, compiled by
+ * oracle/Makefile) and against tests/golden/.
+ *
+ * Citations are /root/reference/-relative.  The reference's 32-bit `int` loop counters
+ * and its out-of-bounds writes are NOT reproduced: this file restates the
+ * results the reference produces where it works, with 64-bit indexing throughout.
+ */
+#include "csgn_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define WORD_BITS 64u
+#define GOLDEN 0x9E3779B97F4A7C15ull
+
+/* ------------------------------------------------------------------ helpers ---- */
+
+static uint64_t splitmix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* bit `pos` (0 = most significant) of word w -- the reference's MSB-first convention,
+ * src/SecretKey.cpp:181 / src/SecretKey.cpp:92-93. */
+static unsigned msb_bit(uint64_t w, unsigned pos)
+{
+    return (unsigned)((w >> (WORD_BITS - 1u - pos)) & 1u);
+}
+
+static int key_contains(const uint64_t *key, uint64_t d, uint64_t value)
+{
+    /* src/Helpers.cpp:18-26 */
+    for (uint64_t i = 0; i < d; ++i)
+        if (key[i] == value)
+            return 1;
+    return 0;
+}
+
+/* Unpack a (v, bitlen) stream into one byte per bit (src/SecretKey.cpp:110-124,
+ * src/Ciphertext.cpp:16-31).  Returns the number of bits; *bits_out is malloc'ed. */
+static uint64_t unpack_stream(uint64_t n_bits, const uint64_t *v, uint64_t len,
+                              const uint64_t *bitlen, uint8_t **bits_out)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint64_t rem = n_bits % WORD_BITS;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < len; ++i) {
+        uint64_t b = bitlen ? bitlen[i]
+                            : ((rem != 0 && dl != 0 && (i % dl) == dl - 1) ? rem : WORD_BITS);
+        total += b;
+    }
+    uint8_t *bits = (uint8_t *)malloc(total ? total : 1);
+    uint64_t q = 0;
+    for (uint64_t i = 0; i < len; ++i) {
+        uint64_t b = bitlen ? bitlen[i]
+                            : ((rem != 0 && dl != 0 && (i % dl) == dl - 1) ? rem : WORD_BITS);
+        for (uint64_t k = 0; k < b; ++k)
+            bits[q++] = (uint8_t)msb_bit(v[i], (unsigned)k);
+    }
+    *bits_out = bits;
+    return total;
+}
+
+/* ------------------------------------------------------------------ Context ---- */
+
+uint64_t csgn_oracle_default_len(uint64_t n_bits)
+{
+    /* src/Context.cpp:24-28 */
+    return n_bits / WORD_BITS + ((n_bits % WORD_BITS) ? 1u : 0u);
+}
+
+uint64_t csgn_oracle_context_s(uint64_t n_bits, uint64_t d)
+{
+    /* src/Context.cpp:22 */
+    return n_bits / (2 * d);
+}
+
+void csgn_oracle_bitlen(uint64_t n_bits, uint64_t terms, uint64_t *bitlen)
+{
+    /* src/SecretKey.cpp:171-173 (pattern per term; no overflow when N%64==0) */
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint64_t rem = n_bits % WORD_BITS;
+    for (uint64_t t = 0; t < terms; ++t)
+        for (uint64_t k = 0; k < dl; ++k)
+            bitlen[t * dl + k] = (rem != 0 && k == dl - 1) ? rem : WORD_BITS;
+}
+
+/* ----------------------------------------------------------------- multiply ---- */
+
+uint64_t csgn_oracle_mul_len(uint64_t dl, uint64_t len1, uint64_t len2)
+{
+    if (dl == 0)
+        return 0;
+    if (len1 == dl && len1 == len2)          /* src/Ciphertext.cpp:137-138 */
+        return len1;
+    return ((len1 / dl) * len2) / dl * dl;   /* src/Ciphertext.cpp:146, as parsed by C */
+}
+
+uint64_t csgn_oracle_mul(uint64_t dl,
+                         const uint64_t *c1, uint64_t len1, const uint64_t *bitlen_in1,
+                         const uint64_t *c2, uint64_t len2,
+                         uint64_t *out, uint64_t *bitlen_out)
+{
+    uint64_t newlen = csgn_oracle_mul_len(dl, len1, len2);
+    if (dl == 0)
+        return 0;
+
+    if (len1 == dl && len1 == len2) {
+        /* fast path: src/Ciphertext.cpp:124-131, 137-144 */
+        for (uint64_t k = 0; k < dl; ++k)
+            out[k] = c1[k] & c2[k];
+        if (bitlen_in1 && bitlen_out)
+            memcpy(bitlen_out, bitlen_in1, dl * sizeof(uint64_t));
+        return newlen;
+    }
+
+    /* general path: src/Ciphertext.cpp:150-163.  Output term (i*T2 + j) is the AND of
+     * left term i with right term j; the left operand is the slow index. */
+    uint64_t t1 = len1 / dl, t2 = len2 / dl;
+    uint64_t *dst = out;
+    for (uint64_t i = 0; i < t1; ++i) {
+        const uint64_t *lhs = c1 + i * dl;
+        const uint64_t *rhs = c2;
+        for (uint64_t j = 0; j < t2; ++j, rhs += dl, dst += dl)
+            for (uint64_t k = 0; k < dl; ++k)
+                dst[k] = lhs[k] & rhs[k];
+    }
+    /* words the reference leaves unwritten when len2 is not a multiple of dl */
+    for (uint64_t w = t1 * t2 * dl; w < newlen; ++w)
+        out[w] = 0;
+
+    if (bitlen_in1 && bitlen_out) {
+        /* second pass: src/Ciphertext.cpp:165-176 -- bitlen comes from the LEFT term */
+        uint64_t *bd = bitlen_out;
+        for (uint64_t i = 0; i < t1; ++i)
+            for (uint64_t j = 0; j < t2; ++j, bd += dl)
+                memcpy(bd, bitlen_in1 + i * dl, dl * sizeof(uint64_t));
+        for (uint64_t w = t1 * t2 * dl; w < newlen; ++w)
+            bitlen_out[w] = 0;
+    }
+    return newlen;
+}
+
+uint64_t csgn_oracle_mul_reference_cost(uint64_t dl,
+                                        const uint64_t *c1, uint64_t len1,
+                                        const uint64_t *c2, uint64_t len2)
+{
+    /* Cost structure of Ciphertext::operator* (src/Ciphertext.cpp:231-247): the L1
+     * kernel allocates res + bitlenout and makes two passes (:148-176); the result
+     * object then deep-copies both arrays (:344-358) and the temporaries are freed. */
+    uint64_t newlen = csgn_oracle_mul_len(dl, len1, len2);
+    uint64_t *bitlen1 = (uint64_t *)malloc((len1 ? len1 : 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < len1; ++i)
+        bitlen1[i] = WORD_BITS;
+    uint64_t *res = (uint64_t *)malloc((newlen ? newlen : 1) * sizeof(uint64_t));
+    uint64_t *blo = (uint64_t *)malloc((newlen ? newlen : 1) * sizeof(uint64_t));
+    csgn_oracle_mul(dl, c1, len1, bitlen1, c2, len2, res, blo);
+    uint64_t *v_copy = (uint64_t *)malloc((newlen ? newlen : 1) * sizeof(uint64_t));
+    uint64_t *b_copy = (uint64_t *)malloc((newlen ? newlen : 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < newlen; ++i) {
+        v_copy[i] = res[i];
+        b_copy[i] = blo[i];
+    }
+    free(res);
+    free(blo);
+    uint64_t dig = csgn_oracle_digest(v_copy, newlen, 0) + b_copy[newlen ? newlen - 1 : 0];
+    free(v_copy);
+    free(b_copy);
+    free(bitlen1);
+    return dig;
+}
+
+/* ---------------------------------------------------------------------- add ---- */
+
+uint64_t csgn_oracle_add(const uint64_t *c1, uint64_t len1, const uint64_t *bitlen1,
+                         const uint64_t *c2, uint64_t len2, const uint64_t *bitlen2,
+                         uint64_t *out, uint64_t *bitlen_out)
+{
+    /* src/Ciphertext.cpp:107-122: plain concatenation, no XOR / no de-duplication. */
+    if (len1)
+        memcpy(out, c1, len1 * sizeof(uint64_t));
+    if (len2)
+        memcpy(out + len1, c2, len2 * sizeof(uint64_t));
+    if (bitlen_out) {
+        /* src/Ciphertext.cpp:215-223 */
+        if (len1 && bitlen1)
+            memcpy(bitlen_out, bitlen1, len1 * sizeof(uint64_t));
+        if (len2 && bitlen2)
+            memcpy(bitlen_out + len1, bitlen2, len2 * sizeof(uint64_t));
+    }
+    return len1 + len2;
+}
+
+/* ------------------------------------------------------------------- keygen ---- */
+
+int64_t csgn_oracle_keygen(uint64_t n_bits, uint64_t d,
+                           const int32_t *draws, uint64_t n_draws, uint64_t *key)
+{
+    /* src/SecretKey.cpp:322-335: rejection-sample d distinct indices in [0,N).
+     * The reference tests membership against the whole (partly uninitialised) array;
+     * the restatement tests against the indices accepted so far. */
+    uint64_t used = 0, count = 0;
+    while (count < d) {
+        if (used >= n_draws)
+            return -1;
+        uint64_t cand = (uint64_t)draws[used++] % n_bits;
+        if (key_contains(key, count, cand))
+            continue;
+        key[count++] = cand;
+    }
+    return (int64_t)used;
+}
+
+void csgn_oracle_key_mask(uint64_t n_bits, const uint64_t *key, uint64_t d, uint64_t *mask)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    memset(mask, 0, dl * sizeof(uint64_t));
+    for (uint64_t i = 0; i < d; ++i)
+        mask[key[i] / WORD_BITS] |= 1ull << (WORD_BITS - 1u - (unsigned)(key[i] % WORD_BITS));
+}
+
+/* ------------------------------------------------------------------ encrypt ---- */
+
+int64_t csgn_oracle_encrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
+                            unsigned bit, const int32_t *draws, uint64_t n_draws,
+                            uint64_t *out)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint8_t *vec = (uint8_t *)calloc(n_bits ? n_bits : 1, 1);
+    uint64_t used = 0;
+    int ok = 1;
+
+#define NEXT_DRAW(dst)                         \
+    do {                                       \
+        if (used >= n_draws) { ok = 0; }       \
+        else { (dst) = draws[used++]; }        \
+    } while (0)
+
+    if (bit & 1u) {
+        /* src/SecretKey.cpp:41-48: secret positions forced to 1, the rest rand()%2 */
+        for (uint64_t i = 0; i < n_bits && ok; ++i) {
+            if (key_contains(key, d, i)) {
+                vec[i] = 1;
+            } else {
+                int32_t r = 0;
+                NEXT_DRAW(r);
+                vec[i] = (uint8_t)(r % 2);
+            }
+        }
+    } else {
+        /* src/SecretKey.cpp:51-76: pick one secret slot, randomise everything else,
+         * then force the chosen slot to 0 iff every OTHER secret slot came out 1. */
+        int32_t r = 0;
+        NEXT_DRAW(r);
+        uint64_t chosen = key[(uint64_t)r % d];
+        unsigned and_of_others = 0;
+        int first = 1;
+        for (uint64_t i = 0; i < n_bits && ok; ++i) {
+            if (i == chosen)
+                continue;
+            NEXT_DRAW(r);
+            vec[i] = (uint8_t)(r % 2);
+            if (key_contains(key, d, i)) {
+                if (first) {
+                    and_of_others = vec[i];
+                    first = 0;
+                }
+                and_of_others &= vec[i];
+            }
+        }
+        if (ok) {
+            if (and_of_others == 1u) {
+                vec[chosen] = 0;
+            } else {
+                NEXT_DRAW(r);
+                vec[chosen] = (uint8_t)(r % 2);
+            }
+        }
+    }
+#undef NEXT_DRAW
+
+    if (ok) {
+        /* src/SecretKey.cpp:175-197: pack MSB-first, word j/64, bit 63 - j%64 */
+        memset(out, 0, dl * sizeof(uint64_t));
+        for (uint64_t j = 0; j < n_bits; ++j)
+            out[j / WORD_BITS] |= (uint64_t)(vec[j] & 1u)
+                                  << (WORD_BITS - 1u - (unsigned)(j % WORD_BITS));
+    }
+    free(vec);
+    return ok ? (int64_t)used : -1;
+}
+
+/* ------------------------------------------------------------------ decrypt ---- */
+
+unsigned csgn_oracle_decrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
+                             const uint64_t *v, uint64_t len, const uint64_t *bitlen)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint8_t *bits = NULL;
+    uint64_t total = unpack_stream(n_bits, v, len, bitlen, &bits);
+    unsigned result = 0;
+
+    if (len == dl) {
+        /* src/SecretKey.cpp:97-99: single term, logical AND over the key */
+        unsigned dec = 1;
+        for (uint64_t i = 0; i < d; ++i)
+            dec = dec && (key[i] < total ? bits[key[i]] : 0);
+        result = dec;
+    } else {
+        /* src/SecretKey.cpp:126-140: XOR over terms of (AND over the key) */
+        uint64_t terms = dl ? len / dl : 0;
+        for (uint64_t k = 0; k < terms; ++k) {
+            unsigned dec = 1;
+            for (uint64_t i = 0; i < d; ++i) {
+                uint64_t q = n_bits * k + key[i];
+                dec &= (q < total ? bits[q] : 0);
+            }
+            result = (dec + result) % 2;
+        }
+    }
+    free(bits);
+    return result;
+}
+
+unsigned csgn_oracle_decrypt_canonical(uint64_t n_bits, uint64_t d, const uint64_t *key,
+                                       const uint64_t *v, uint64_t len)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint64_t terms = dl ? len / dl : 0;
+    unsigned result = 0;
+    for (uint64_t k = 0; k < terms; ++k) {
+        const uint64_t *term = v + k * dl;
+        unsigned dec = 1;
+        for (uint64_t i = 0; i < d && dec; ++i)
+            dec &= msb_bit(term[key[i] / WORD_BITS], (unsigned)(key[i] % WORD_BITS));
+        result ^= dec;
+    }
+    return result;
+}
+
+/* ------------------------------------------------------------- permutations ---- */
+
+int64_t csgn_oracle_perm_random(uint64_t size, const int32_t *draws, uint64_t n_draws,
+                                uint64_t *perm)
+{
+    /* src/Permutation.cpp:145-156: slot i takes the first draw (mod size) not yet used.
+     * Slots start at (uint64_t)-1, which never collides with a candidate. */
+    uint64_t used = 0;
+    for (uint64_t i = 0; i < size; ++i)
+        perm[i] = UINT64_MAX;
+    for (uint64_t i = 0; i < size; ++i) {
+        for (;;) {
+            if (used >= n_draws)
+                return -1;
+            uint64_t cand = (uint64_t)draws[used++] % size;
+            if (!key_contains(perm, size, cand)) {
+                perm[i] = cand;
+                break;
+            }
+        }
+    }
+    return (int64_t)used;
+}
+
+void csgn_oracle_perm_inverse(const uint64_t *perm, uint64_t size, uint64_t *inv)
+{
+    /* src/Permutation.cpp:12-22: inv[i] = smallest j with perm[j] == i */
+    for (uint64_t i = 0; i < size; ++i)
+        inv[i] = 0;
+    for (uint64_t j = size; j-- > 0;)
+        if (perm[j] < size)
+            inv[perm[j]] = j;
+}
+
+int csgn_oracle_perm_compose(const uint64_t *a, uint64_t len_a,
+                             const uint64_t *b, uint64_t len_b, uint64_t *out)
+{
+    /* src/Permutation.cpp:65-73: length mismatch yields the empty permutation */
+    if (len_a != len_b)
+        return -1;
+    for (uint64_t i = 0; i < len_a; ++i)
+        out[i] = a[b[i]];
+    return 0;
+}
+
+uint64_t csgn_oracle_permute_ciphertext(uint64_t n_bits, const uint64_t *perm,
+                                        const uint64_t *v, uint64_t len,
+                                        const uint64_t *bitlen, uint64_t *out)
+{
+    /* src/Ciphertext.cpp:16-69.  temp2[i] = temp[perm[i % N]] never adds the term
+     * offset, and only the first N permuted bits are re-packed (:36-69), so the
+     * result is the permuted FIRST term whatever the input length. */
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    uint8_t *bits = NULL;
+    uint64_t total = unpack_stream(n_bits, v, len, bitlen, &bits);
+    memset(out, 0, dl * sizeof(uint64_t));
+    for (uint64_t j = 0; j < n_bits && j < total; ++j) {
+        uint64_t src = perm[j];
+        unsigned b = (src < total) ? bits[src] : 0u;
+        out[j / WORD_BITS] |= (uint64_t)b << (WORD_BITS - 1u - (unsigned)(j % WORD_BITS));
+    }
+    free(bits);
+    return dl;
+}
+
+uint64_t csgn_oracle_permute_key(uint64_t n_bits, const uint64_t *perm,
+                                 const uint64_t *key, uint64_t d, uint64_t *new_key)
+{
+    /* src/SecretKey.cpp:231-250: index i belongs to the new key iff perm[i] belonged
+     * to the old one; indices come out in ascending order. */
+    uint8_t *member = (uint8_t *)calloc(n_bits ? n_bits : 1, 1);
+    for (uint64_t i = 0; i < d; ++i)
+        if (key[i] < n_bits)
+            member[key[i]] = 1;
+    uint64_t count = 0;
+    for (uint64_t i = 0; i < n_bits; ++i)
+        if (perm[i] < n_bits && member[perm[i]] && count < d)
+            new_key[count++] = i;
+    free(member);
+    return count;
+}
+
+/* ---------------------------------------------------------- harness helpers ---- */
+
+uint64_t csgn_oracle_synth_word(uint64_t seed, uint64_t idx)
+{
+    return splitmix64(seed + GOLDEN * (idx + 1));
+}
+
+void csgn_oracle_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word,
+                            uint64_t n_words, uint64_t *out)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    unsigned rem = (unsigned)(n_bits % WORD_BITS);
+    uint64_t tail_mask = rem ? ~0ull << (WORD_BITS - rem) : ~0ull;
+    for (uint64_t i = 0; i < n_words; ++i) {
+        uint64_t idx = first_word + i;
+        uint64_t w = csgn_oracle_synth_word(seed, idx);
+        if (dl && (idx % dl) == dl - 1)
+            w &= tail_mask;
+        out[i] = w;
+    }
+}
+
+uint64_t csgn_oracle_digest(const uint64_t *w, uint64_t n_words, uint64_t first_index)
+{
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < n_words; ++i)
+        acc += splitmix64(w[i] + GOLDEN * (first_index + i + 1));
+    return acc;
+}

@@ -1,0 +1,152 @@
+"""Pin the CPU restatement against the committed known-answer vectors.
+
+tests/golden/csgn_kat.json was produced from the genuine reference by
+tests/golden/gen_golden.py; this test needs neither /root/reference nor oracle/_ref.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.binding import canonical_bitlen, glibc_draws
+
+KAT_PATH = os.path.join(os.path.dirname(__file__), "golden", "csgn_kat.json")
+
+
+def words(hex_list):
+    return np.array([int(h, 16) for h in hex_list], dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(KAT_PATH) as f:
+        return json.load(f)
+
+
+def test_golden_encrypt(oracle, kat):
+    for case in kat["encrypt"]:
+        n, d, seed = case["n"], case["d"], case["seed"]
+        key = np.array(case["key"], dtype=np.uint64)
+        draws = glibc_draws(seed, (n + 2) * len(case["bits"]))
+        got, _ = oracle.encrypt_seq(n, key, case["bits"], draws)
+        assert np.array_equal(got, words(case["ct"])), (n, d, seed)
+        dl = oracle.default_len(n)
+        for i, want in enumerate(case["dec"]):
+            assert oracle.decrypt(n, key, got[i * dl:(i + 1) * dl]) == want
+            assert oracle.decrypt_canonical(n, key, got[i * dl:(i + 1) * dl]) == want
+
+
+def test_golden_mul(oracle, kat):
+    for case in kat["mul"]:
+        out, bl = oracle.mul(case["n"], words(case["a"]), words(case["b"]),
+                             np.array(case["bitlen_a"], dtype=np.uint64))
+        assert np.array_equal(out, words(case["out"])), (case["n"], case["t1"], case["t2"])
+        assert np.array_equal(bl, np.array(case["bitlen_out"], dtype=np.uint64))
+
+
+def test_golden_add(oracle, kat):
+    for case in kat["add"]:
+        n, t1, t2 = case["n"], case["t1"], case["t2"]
+        out, bl = oracle.add(words(case["a"]), words(case["b"]),
+                             canonical_bitlen(n, t1), canonical_bitlen(n, t2))
+        assert np.array_equal(out, words(case["out"]))
+        assert np.array_equal(bl, np.array(case["bitlen_out"], dtype=np.uint64))
+
+
+def rebuild_decrypt_input(oracle, case):
+    n, terms, hits = case["n"], case["terms"], case["hits"]
+    key = np.array(case["key"], dtype=np.uint64)
+    dl = oracle.default_len(n)
+    v = oracle.synth(case["seed"], n, 0, terms * dl).reshape(terms, dl)
+    v[:hits] |= oracle.key_mask(n, key)
+    w, b = int(key[0]) // 64, 63 - int(key[0]) % 64
+    v[hits:, w] &= ~np.uint64(1 << b)
+    return key, np.ascontiguousarray(v.reshape(-1))
+
+
+def test_golden_decrypt(oracle, kat):
+    for case in kat["decrypt"]:
+        key, flat = rebuild_decrypt_input(oracle, case)
+        assert "%016x" % oracle.digest(flat) == case["digest"]
+        if case["v"] is not None:
+            assert np.array_equal(flat, words(case["v"]))
+        assert oracle.decrypt(case["n"], key, flat) == case["bit"]
+        assert oracle.decrypt_canonical(case["n"], key, flat) == case["bit"]
+
+
+def test_golden_permutation(oracle, kat):
+    for case in kat["permutation"]:
+        n, seed = case["n"], case["seed"]
+        key = np.array(case["key"], dtype=np.uint64)
+        perm = np.array(case["perm"], dtype=np.uint64)
+        got_perm, _ = oracle.perm_random(n, glibc_draws(seed, 64 * n + 1000))
+        assert np.array_equal(got_perm, perm)
+        inv = oracle.perm_inverse(perm)
+        assert np.array_equal(inv, np.array(case["inverse"], dtype=np.uint64))
+        assert case["compose_is_identity"]
+        assert np.array_equal(oracle.perm_compose(perm, inv), np.arange(n, dtype=np.uint64))
+        pkey = oracle.permute_key(n, perm, key)
+        assert np.array_equal(pkey, np.array(case["permuted_key"], dtype=np.uint64))
+        cts = words(case["ct"])
+        dl = oracle.default_len(n)
+        first = oracle.permute_ciphertext(n, perm, cts[:dl])
+        assert np.array_equal(first, words(case["permuted_first"]))
+        multi = oracle.permute_ciphertext(n, perm, cts)
+        assert np.array_equal(multi, words(case["permuted_multi"]))
+        assert np.array_equal(multi, first)          # the reference's truncation
+        assert oracle.decrypt(n, pkey, first) == case["dec_permuted"] == 1
+
+
+def test_golden_digests(oracle, kat):
+    for case in kat["digest"]:
+        n, t1, t2 = case["n"], case["t1"], case["t2"]
+        dl = oracle.default_len(n)
+        a = oracle.synth(case["seed_a"], n, 0, t1 * dl)
+        b = oracle.synth(case["seed_b"], n, 0, t2 * dl)
+        out, _ = oracle.mul(n, a, b)
+        assert out.size == case["out_len"]
+        assert "%016x" % oracle.digest(out) == case["digest"]
+        assert np.array_equal(out[:4], words(case["first_words"]))
+        assert np.array_equal(out[-4:], words(case["last_words"]))
+
+
+def test_golden_keygen(oracle, kat):
+    for case in kat["keygen"]:
+        key, used = oracle.keygen(case["n"], case["d"], glibc_draws(case["srand"], 64 * case["d"] + 64))
+        assert np.array_equal(key, np.array(case["key"], dtype=np.uint64))
+        assert used == case["draws_used"]
+
+
+def test_golden_basic_operations(oracle, kat):
+    c = kat["basic_operations"]
+    n = c["n"]
+    key = np.array(c["key"], dtype=np.uint64)
+    cts, _ = oracle.encrypt_seq(n, key, [1, 0], glibc_draws(c["seed"], 2 * (n + 2)))
+    assert np.array_equal(cts[:20], words(c["c1"])) and np.array_equal(cts[20:], words(c["c0"]))
+    added, _ = oracle.add(cts[:20], cts[20:])
+    mult, _ = oracle.mul(n, cts[:20], cts[20:])
+    assert np.array_equal(added, words(c["added"])) and np.array_equal(mult, words(c["multiplied"]))
+    assert oracle.decrypt(n, key, added) == c["dec_added"] == 1
+    assert oracle.decrypt(n, key, mult) == c["dec_multiplied"] == 0
+
+
+def test_oracle_homomorphic_properties(oracle):
+    """dec(a*b)=dec(a)&dec(b), dec(a+b)=dec(a)^dec(b) on small circuits."""
+    n, d = 1247, 16
+    rng = np.random.default_rng(9)
+    key = rng.permutation(n)[:d].astype(np.uint64)
+    draws = glibc_draws(4, 40 * (n + 2))
+    bits = [int(b) for b in rng.integers(0, 2, size=32)]
+    cts, _ = oracle.encrypt_seq(n, key, bits, draws)
+    dl = oracle.default_len(n)
+    ct = [cts[i * dl:(i + 1) * dl] for i in range(len(bits))]
+    acc, accb = ct[0], bits[0]
+    for i in range(1, 12):
+        if i % 2:
+            acc, _ = oracle.add(acc, ct[i]); accb ^= bits[i]
+        else:
+            rhs, _ = oracle.add(ct[i], ct[i + 12]); rb = bits[i] ^ bits[i + 12]
+            acc, _ = oracle.mul(n, acc, rhs); accb &= rb
+        assert oracle.decrypt(n, key, acc) == accb
+        assert oracle.decrypt_canonical(n, key, acc) == accb
