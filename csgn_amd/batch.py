@@ -1,0 +1,188 @@
+"""Torch-backed plumbing over the C ABI: device buffers, streams, batch calls.
+
+PyTorch is used here ONLY for HBM allocation (`torch.empty(..., device="cuda")`), the current
+HIP stream and `torch.distributed`; every arithmetic result comes from libcsgn_hip.so through
+`csgn_amd.capi`.  Term words are uint64 on the wire; torch holds them as int64 (same bits).
+
+All methods enqueue on torch's current stream, so `torch.cuda.Event` brackets them correctly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import check
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class HipPath:
+    """One GPU's view of the hot path.  Construct one per process / device."""
+
+    def __init__(self, device: int = 0):
+        self.lib = capi.load_library()
+        if not torch.cuda.is_available():
+            raise capi.CsgnError(capi.CSGN_ERR_NO_DEVICE,
+                                 "torch sees no GPU; csgn_amd has no CPU fallback")
+        torch.cuda.set_device(device)
+        check(self.lib.csgn_init(device))
+        self.device = torch.device("cuda", device)
+
+    # -- plumbing -------------------------------------------------------------------
+    @property
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty_words(self, n_words: int) -> torch.Tensor:
+        return torch.empty(int(n_words), dtype=torch.int64, device=self.device)
+
+    def upload(self, a: np.ndarray) -> torch.Tensor:
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint64:
+            return torch.from_numpy(a.view(np.int64)).to(self.device)
+        if a.dtype == np.uint32:
+            return torch.from_numpy(a.view(np.int32)).to(self.device)
+        return torch.from_numpy(a).to(self.device)
+
+    @staticmethod
+    def download(t: torch.Tensor) -> np.ndarray:
+        a = t.detach().cpu().numpy()
+        if a.dtype == np.int64:
+            return a.view(np.uint64)
+        if a.dtype == np.int32:
+            return a.view(np.uint32)
+        return a
+
+    def default_len(self, n_bits: int) -> int:
+        return int(self.lib.csgn_default_len(n_bits))
+
+    def key_mask(self, n_bits: int, key) -> np.ndarray:
+        key = np.ascontiguousarray(np.asarray(key, dtype=np.uint64))
+        mask = np.zeros(self.default_len(n_bits), dtype=np.uint64)
+        check(self.lib.csgn_key_mask(n_bits, key.ctypes.data, key.size, mask.ctypes.data))
+        return mask
+
+    # -- multiply -------------------------------------------------------------------
+    def mul_uniform(self, n_bits: int, batch: int, t1: int, t2: int, left: torch.Tensor,
+                    right: torch.Tensor, out: Optional[torch.Tensor] = None,
+                    out_slots: int = 0) -> torch.Tensor:
+        dl = self.default_len(n_bits)
+        assert left.numel() >= batch * t1 * dl and right.numel() >= batch * t2 * dl
+        slots = batch if out_slots == 0 else min(out_slots, batch)
+        if out is None:
+            out = self.empty_words(slots * t1 * t2 * dl)
+        assert out.numel() >= slots * t1 * t2 * dl
+        check(self.lib.csgn_mul_uniform(n_bits, batch, t1, t2, _ptr(left), _ptr(right), _ptr(out),
+                                        out_slots, self.stream))
+        return out
+
+    def mul_ragged(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor,
+                   right: torch.Tensor, off_right: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        batch = off_left.numel() - 1
+        dl = self.default_len(n_bits)
+        off_out = self.empty_words(batch + 1)
+        plan = (C.c_uint64 * 4)()
+        check(self.lib.csgn_mul_ragged_plan(batch, _ptr(off_left), _ptr(off_right), _ptr(off_out),
+                                            C.byref(plan), self.stream))
+        total, max_t1, max_t2 = int(plan[0]), int(plan[1]), int(plan[2])
+        out = self.empty_words(max(total * dl, 1))
+        check(self.lib.csgn_mul_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
+                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_t1, max_t2,
+                                       self.stream))
+        return out[: total * dl], off_out
+
+    # -- add ------------------------------------------------------------------------
+    def add_uniform(self, n_bits: int, batch: int, t1: int, t2: int, left: torch.Tensor,
+                    right: torch.Tensor) -> torch.Tensor:
+        dl = self.default_len(n_bits)
+        out = self.empty_words(max(batch * (t1 + t2) * dl, 1))
+        check(self.lib.csgn_add_uniform(n_bits, batch, t1, t2, _ptr(left), _ptr(right), _ptr(out),
+                                        self.stream))
+        return out[: batch * (t1 + t2) * dl]
+
+    def add_ragged(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor,
+                   right: torch.Tensor, off_right: torch.Tensor,
+                   max_terms_out: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        batch = off_left.numel() - 1
+        dl = self.default_len(n_bits)
+        ol, orr = self.download(off_left), self.download(off_right)
+        total = int(ol[-1] + orr[-1])
+        if max_terms_out is None:
+            max_terms_out = int(((ol[1:] - ol[:-1]) + (orr[1:] - orr[:-1])).max()) if batch else 0
+        out = self.empty_words(max(total * dl, 1))
+        off_out = self.empty_words(batch + 1)
+        check(self.lib.csgn_add_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
+                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_terms_out,
+                                       self.stream))
+        return out[: total * dl], off_out
+
+    # -- decrypt ----------------------------------------------------------------------
+    def decrypt_uniform(self, n_bits: int, batch: int, terms: int, words: torch.Tensor,
+                        mask: torch.Tensor) -> torch.Tensor:
+        bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
+        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(batch * terms)),
+                              dtype=torch.uint8, device=self.device)
+        check(self.lib.csgn_decrypt_uniform(n_bits, batch, terms, _ptr(words), _ptr(mask), _ptr(bits),
+                                            _ptr(scratch), self.stream))
+        return bits[:batch]
+
+    def decrypt_ragged(self, n_bits: int, words: torch.Tensor, off: torch.Tensor,
+                       mask: torch.Tensor, total_terms: Optional[int] = None) -> torch.Tensor:
+        batch = off.numel() - 1
+        if total_terms is None:
+            total_terms = int(self.download(off[-1:])[0])
+        bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
+        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(total_terms)),
+                              dtype=torch.uint8, device=self.device)
+        check(self.lib.csgn_decrypt_ragged(n_bits, batch, total_terms, _ptr(words), _ptr(off),
+                                           _ptr(mask), _ptr(bits), _ptr(scratch), self.stream))
+        return bits[:batch]
+
+    # -- encrypt ----------------------------------------------------------------------
+    def encrypt_explicit(self, n_bits: int, d: int, plain: torch.Tensor, rnd: torch.Tensor,
+                         chosen: torch.Tensor, last: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        batch = plain.numel()
+        out = self.empty_words(max(batch * self.default_len(n_bits), 1))
+        check(self.lib.csgn_encrypt_explicit(n_bits, d, batch, _ptr(plain), _ptr(rnd), _ptr(chosen),
+                                             _ptr(last), _ptr(mask), _ptr(out), self.stream))
+        return out[: batch * self.default_len(n_bits)]
+
+    def encrypt_device_rng(self, n_bits: int, d: int, plain: torch.Tensor, key: torch.Tensor,
+                           mask: torch.Tensor, seed: int) -> torch.Tensor:
+        batch = plain.numel()
+        out = self.empty_words(max(batch * self.default_len(n_bits), 1))
+        check(self.lib.csgn_encrypt_device_rng(n_bits, d, batch, _ptr(plain), _ptr(key), _ptr(mask),
+                                               seed & (2**64 - 1), _ptr(out), self.stream))
+        return out[: batch * self.default_len(n_bits)]
+
+    # -- permutation --------------------------------------------------------------------
+    def permute_uniform(self, n_bits: int, batch: int, terms_in: int, words: torch.Tensor,
+                        perm: torch.Tensor, per_term: bool = False) -> torch.Tensor:
+        dl = self.default_len(n_bits)
+        n_out = batch * (terms_in if per_term else 1) * dl
+        out = self.empty_words(max(n_out, 1))
+        check(self.lib.csgn_permute_uniform(n_bits, batch, terms_in, int(per_term), _ptr(words),
+                                            _ptr(perm), _ptr(out), self.stream))
+        return out[:n_out]
+
+    # -- harness --------------------------------------------------------------------------
+    def synth_fill(self, seed: int, n_bits: int, first_word: int, n_words: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = self.empty_words(n_words)
+        check(self.lib.csgn_synth_fill(seed & (2**64 - 1), n_bits, first_word, n_words, _ptr(out),
+                                       self.stream))
+        return out
+
+    def digest(self, words: torch.Tensor, n_words: Optional[int] = None, first_index: int = 0) -> int:
+        if n_words is None:
+            n_words = words.numel()
+        acc = torch.zeros(1, dtype=torch.int64, device=self.device)
+        check(self.lib.csgn_digest(_ptr(words), n_words, first_index, _ptr(acc), self.stream))
+        return int(acc.item()) & (2**64 - 1)

@@ -1,0 +1,83 @@
+"""Build the in-tree native libraries for gfx950.
+
+    python -m csgn_amd.build            # libcsgn_hip.so (+ libcertFHE.so once present)
+
+hipcc cross-compiles without a GPU; the .so files land in csgn_amd/lib/ (git-ignored, but
+they travel to the GPU box with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(LIBDIR, "libcsgn_hip.so")
+CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
+
+HIP_SOURCES = ["csgn_capi.hip", "csgn_kernels.hip"]
+HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "csgn_hip.h")]
+    if force or _stale(HIP_LIB, deps):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-I" + INCLUDE, "-I" + CSRC, "-o", HIP_LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_certfhe(force: bool = False, verbose: bool = False):
+    """The drop-in certFHE:: C++ classes over the C ABI (csgn_amd/csrc/certfhe/*.cpp)."""
+    src_dir = os.path.join(CSRC, "certfhe")
+    if not os.path.isdir(src_dir):
+        return None
+    srcs = sorted(os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith(".cpp"))
+    if not srcs:
+        return None
+    hdr_dir = os.path.join(INCLUDE, "certfhe")
+    hdrs = [os.path.join(hdr_dir, f) for f in os.listdir(hdr_dir)] if os.path.isdir(hdr_dir) else []
+    if force or _stale(CERTFHE_LIB, srcs + hdrs + [HIP_LIB]):
+        cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + hdr_dir,
+               "-o", CERTFHE_LIB] + srcs + ["-L" + LIBDIR, "-lcsgn_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CERTFHE_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    out = [build_hip(force, verbose)]
+    c = build_certfhe(force, verbose)
+    if c:
+        out.append(c)
+    return out
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))

@@ -1,0 +1,112 @@
+"""ctypes binding of include/csgn_hip.h (libcsgn_hip.so).
+
+Every wrapper returns nothing and raises CsgnError(status, message) on failure -- there is no
+fallback path.  Device pointers are plain ints (e.g. torch.Tensor.data_ptr()); `stream` is a
+hipStream_t handle as int (torch.cuda.current_stream().cuda_stream) or 0.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(PKG, "lib", "libcsgn_hip.so")
+
+CSGN_OK = 0
+CSGN_ERR_INVALID = -1
+CSGN_ERR_UNSUPPORTED = -2
+CSGN_ERR_NO_DEVICE = -3
+CSGN_ERR_HIP = -4
+
+u64 = C.c_uint64
+vp = C.c_void_p
+
+# name -> (restype, argtypes).  Must list EVERY symbol declared in include/csgn_hip.h
+# (tests/test_capi_symbols.py cross-checks this table against the header).
+SIGNATURES = {
+    "csgn_abi_version": (C.c_int, []),
+    "csgn_last_error": (C.c_char_p, []),
+    "csgn_init": (C.c_int, [C.c_int]),
+    "csgn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "csgn_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(u64)]),
+    "csgn_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "csgn_free": (C.c_int, [vp]),
+    "csgn_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "csgn_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "csgn_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "csgn_memset": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
+    "csgn_stream_create": (C.c_int, [C.POINTER(vp)]),
+    "csgn_stream_destroy": (C.c_int, [vp]),
+    "csgn_stream_sync": (C.c_int, [vp]),
+    "csgn_event_create": (C.c_int, [C.POINTER(vp)]),
+    "csgn_event_destroy": (C.c_int, [vp]),
+    "csgn_event_record": (C.c_int, [vp, vp]),
+    "csgn_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "csgn_default_len": (u64, [u64]),
+    "csgn_context_s": (u64, [u64, u64]),
+    "csgn_mul_len": (u64, [u64, u64, u64]),
+    "csgn_bitlen_canonical": (C.c_int, [u64, u64, vp]),
+    "csgn_key_mask": (C.c_int, [u64, vp, u64, vp]),
+    "csgn_mul_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, u64, vp]),
+    "csgn_mul_ragged_plan": (C.c_int, [u64, vp, vp, vp, C.POINTER(u64 * 4), vp]),
+    "csgn_mul_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, u64, vp]),
+    "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
+    "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
+    "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64]),
+    "csgn_decrypt_uniform": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp]),
+    "csgn_decrypt_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_encrypt_explicit": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp, vp]),
+    "csgn_encrypt_device_rng": (C.c_int, [u64, u64, u64, vp, vp, vp, u64, vp, vp]),
+    "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
+    "csgn_synth_fill": (C.c_int, [u64, u64, u64, u64, vp, vp]),
+    "csgn_digest": (C.c_int, [vp, u64, u64, vp, vp]),
+    "csgn_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+}
+
+
+class CsgnError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"csgn status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libcsgn_hip.so (once).  Raises if it has not been built -- run
+    `python -m csgn_amd.build` (or __graft_entry__.build()) first."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} is missing: the HIP library has not been built (python -m csgn_amd.build). "
+            "csgn_amd has no CPU fallback.")
+    try:
+        # torch bundles its own libamdhip64.so.7; importing it first makes this library bind
+        # to that same runtime instance, so torch streams/tensors can be handed across.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != CSGN_OK:
+        msg = load_library().csgn_last_error()
+        raise CsgnError(rc, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,464 @@
+// csgn_capi.hip -- the extern "C" surface of libcsgn_hip.so (declared in include/csgn_hip.h).
+// Argument validation, error reporting and stream plumbing only; the kernels live in
+// csgn_kernels.hip.  There is deliberately no CPU fallback anywhere in this library.
+#include "csgn_hip.h"
+#include "csgn_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+        return fail(CSGN_ERR_NO_DEVICE, "%s: %s (no usable HIP device; this library has no CPU path)",
+                    what, hipGetErrorString(e));
+    return fail(CSGN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess)                  \
+            return hip_fail(e_, #expr);        \
+    } while (0)
+
+#define REQUIRE(cond, ...)                               \
+    do {                                                 \
+        if (!(cond))                                     \
+            return fail(CSGN_ERR_INVALID, __VA_ARGS__);  \
+    } while (0)
+
+inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
+
+// Shape limits shared by every compute entry point.
+int check_n(uint64_t n_bits)
+{
+    if (n_bits == 0)
+        return fail(CSGN_ERR_INVALID, "n_bits must be > 0");
+    if (((n_bits + 63) / 64) * 8 > 16384)
+        return fail(CSGN_ERR_UNSUPPORTED, "n_bits=%llu: terms above 16384 bytes are not supported",
+                    (unsigned long long)n_bits);
+    return CSGN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int csgn_abi_version(void) { return CSGN_ABI_VERSION; }
+
+const char *csgn_last_error(void) { return g_err; }
+
+int csgn_device_count(int *h_count)
+{
+    REQUIRE(h_count, "h_count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *h_count = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *h_count = n;
+    return CSGN_OK;
+}
+
+int csgn_device_info(int device, char *h_name, size_t cap, int *h_cu_count, uint64_t *h_hbm_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (h_name && cap) {
+        strncpy(h_name, prop.gcnArchName, cap - 1);
+        h_name[cap - 1] = 0;
+    }
+    if (h_cu_count)
+        *h_cu_count = prop.multiProcessorCount;
+    if (h_hbm_bytes)
+        *h_hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return CSGN_OK;
+}
+
+int csgn_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(CSGN_ERR_NO_DEVICE,
+                    "csgn_init: no HIP device visible (%s); libcsgn_hip has no CPU fallback",
+                    e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    REQUIRE(device >= 0 && device < n, "csgn_init: device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CSGN_ERR_NO_DEVICE, "csgn_init: device %d is %s; the kernels are built for gfx950 only",
+                    device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    return CSGN_OK;
+}
+
+int csgn_malloc(void **d_ptr, size_t bytes)
+{
+    REQUIRE(d_ptr, "d_ptr is null");
+    *d_ptr = nullptr;
+    if (bytes == 0)
+        return CSGN_OK;
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return CSGN_OK;
+}
+
+int csgn_free(void *d_ptr)
+{
+    if (d_ptr)
+        HIP_TRY(hipFree(d_ptr));
+    return CSGN_OK;
+}
+
+int csgn_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    if (bytes == 0)
+        return CSGN_OK;
+    REQUIRE(d_dst && h_src, "null pointer");
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (bytes == 0)
+        return CSGN_OK;
+    REQUIRE(h_dst && d_src, "null pointer");
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (bytes == 0)
+        return CSGN_OK;
+    REQUIRE(d_dst && d_src, "null pointer");
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_memset(void *d_dst, int value, size_t bytes, void *stream)
+{
+    if (bytes == 0)
+        return CSGN_OK;
+    REQUIRE(d_dst, "null pointer");
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_stream_create(void **stream)
+{
+    REQUIRE(stream, "stream is null");
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return CSGN_OK;
+}
+
+int csgn_stream_destroy(void *stream)
+{
+    if (stream)
+        HIP_TRY(hipStreamDestroy(S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_stream_sync(void *stream)
+{
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_event_create(void **event)
+{
+    REQUIRE(event, "event is null");
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    *event = ev;
+    return CSGN_OK;
+}
+
+int csgn_event_destroy(void *event)
+{
+    if (event)
+        HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return CSGN_OK;
+}
+
+int csgn_event_record(void *event, void *stream)
+{
+    REQUIRE(event, "event is null");
+    HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_event_elapsed_ms(void *start, void *stop, float *h_ms)
+{
+    REQUIRE(start && stop && h_ms, "null argument");
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    HIP_TRY(hipEventElapsedTime(h_ms, reinterpret_cast<hipEvent_t>(start),
+                                reinterpret_cast<hipEvent_t>(stop)));
+    return CSGN_OK;
+}
+
+/* ------------------------------------------------------------ host-side metadata -- */
+
+uint64_t csgn_default_len(uint64_t n_bits) { return n_bits / 64 + ((n_bits % 64) ? 1 : 0); }
+
+uint64_t csgn_context_s(uint64_t n_bits, uint64_t d) { return d ? n_bits / (2 * d) : 0; }
+
+uint64_t csgn_mul_len(uint64_t n_bits, uint64_t len1, uint64_t len2)
+{
+    const uint64_t dl = csgn_default_len(n_bits);
+    if (dl == 0)
+        return 0;
+    if (len1 == dl && len1 == len2)
+        return len1;
+    return ((len1 / dl) * len2) / dl * dl;
+}
+
+int csgn_bitlen_canonical(uint64_t n_bits, uint64_t terms, uint64_t *h_bitlen)
+{
+    REQUIRE(n_bits > 0, "n_bits must be > 0");
+    REQUIRE(h_bitlen || terms == 0, "h_bitlen is null");
+    const uint64_t dl = csgn_default_len(n_bits), rem = n_bits % 64;
+    for (uint64_t t = 0; t < terms; ++t)
+        for (uint64_t k = 0; k < dl; ++k)
+            h_bitlen[t * dl + k] = (rem && k == dl - 1) ? rem : 64;
+    return CSGN_OK;
+}
+
+int csgn_key_mask(uint64_t n_bits, const uint64_t *h_key, uint64_t d, uint64_t *h_mask)
+{
+    REQUIRE(n_bits > 0 && h_key && h_mask && d > 0, "bad argument");
+    const uint64_t dl = csgn_default_len(n_bits);
+    memset(h_mask, 0, dl * sizeof(uint64_t));
+    for (uint64_t i = 0; i < d; ++i) {
+        REQUIRE(h_key[i] < n_bits, "key index %llu (slot %llu) is outside [0,%llu)",
+                (unsigned long long)h_key[i], (unsigned long long)i, (unsigned long long)n_bits);
+        h_mask[h_key[i] / 64] |= 1ull << (63 - (h_key[i] % 64));
+    }
+    return CSGN_OK;
+}
+
+/* ---------------------------------------------------------------------- hot path -- */
+
+int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                     const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out,
+                     uint64_t out_slots, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0 || t1 == 0 || t2 == 0)
+        return CSGN_OK;
+    REQUIRE(d_left && d_right && d_out, "null device pointer");
+    const uint64_t dl = csgn_default_len(n_bits);
+    if (t1 >= (1ull << 31) || t2 >= (1ull << 31) || t1 * t2 * dl >= (1ull << 32))
+        return fail(CSGN_ERR_UNSUPPORTED, "pair product of %llu x %llu terms exceeds 2^32 words",
+                    (unsigned long long)t1, (unsigned long long)t2);
+    HIP_TRY(csgn::mul_uniform(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
+                              (u64 *)d_out, out_slots, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
+                         uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
+{
+    REQUIRE(d_off_left && d_off_right && d_off_out && h_plan, "null pointer");
+    u64 *d_plan = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_plan, 4 * sizeof(u64)));
+    hipError_t e = csgn::mul_ragged_plan(batch, (const u64 *)d_off_left, (const u64 *)d_off_right,
+                                         (u64 *)d_off_out, d_plan, S(stream));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h_plan, d_plan, 4 * sizeof(u64), hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(S(stream));
+    (void)hipFree(d_plan);
+    if (e != hipSuccess)
+        return hip_fail(e, "csgn_mul_ragged_plan");
+    return CSGN_OK;
+}
+
+int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
+                    const uint64_t *d_left, const uint64_t *d_off_left,
+                    const uint64_t *d_right, const uint64_t *d_off_right,
+                    uint64_t *d_out, const uint64_t *d_off_out,
+                    uint64_t max_t1, uint64_t max_t2, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0 || max_t1 == 0 || max_t2 == 0)
+        return CSGN_OK;
+    REQUIRE(d_left && d_right && d_out && d_off_left && d_off_right && d_off_out, "null device pointer");
+    const uint64_t dl = csgn_default_len(n_bits);
+    if (max_t1 >= (1ull << 31) || max_t2 >= (1ull << 31) || max_t1 * max_t2 * dl >= (1ull << 32))
+        return fail(CSGN_ERR_UNSUPPORTED, "pair product of %llu x %llu terms exceeds 2^32 words",
+                    (unsigned long long)max_t1, (unsigned long long)max_t2);
+    hipError_t e = csgn::mul_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
+                                    (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
+                                    (const u64 *)d_off_out, max_t1, max_t2, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch needs more than 2^30 workgroups; split it");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+int csgn_add_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                     const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0 || t1 + t2 == 0)
+        return CSGN_OK;
+    REQUIRE(d_out && (d_left || t1 == 0) && (d_right || t2 == 0), "null device pointer");
+    const uint64_t dl = csgn_default_len(n_bits);
+    if ((t1 + t2) * dl >= (1ull << 31))
+        return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu + %llu terms exceeds 2^31 words per pair",
+                    (unsigned long long)t1, (unsigned long long)t2);
+    HIP_TRY(csgn::add_uniform(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
+                              (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
+                    const uint64_t *d_left, const uint64_t *d_off_left,
+                    const uint64_t *d_right, const uint64_t *d_off_right,
+                    uint64_t *d_out, uint64_t *d_off_out, uint64_t max_terms_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(d_off_left && d_off_right && d_off_out, "null offset pointer");
+    REQUIRE(max_terms_out == 0 || batch == 0 || (d_left && d_right && d_out), "null device pointer");
+    hipError_t e = csgn::add_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
+                                    (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
+                                    (u64 *)d_off_out, max_terms_out, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch needs more than 2^30 workgroups; split it");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+size_t csgn_decrypt_scratch_bytes(uint64_t total_terms)
+{
+    return csgn::decrypt_scratch_bytes(total_terms);
+}
+
+int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,
+                         const uint64_t *d_terms, const uint64_t *d_mask,
+                         uint8_t *d_bits, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_mask && d_bits && d_scratch && (d_terms || terms == 0), "null device pointer");
+    HIP_TRY(csgn::decrypt(n_bits, batch, terms, batch * terms, (const u64 *)d_terms, nullptr,
+                          (const u64 *)d_mask, d_bits, d_scratch, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+                        const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
+                        uint8_t *d_bits, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_off && d_mask && d_bits && d_scratch && (d_terms || total_terms == 0),
+            "null device pointer");
+    HIP_TRY(csgn::decrypt(n_bits, batch, 0, total_terms, (const u64 *)d_terms, (const u64 *)d_off,
+                          (const u64 *)d_mask, d_bits, d_scratch, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
+                          const uint8_t *d_plain, const uint64_t *d_rnd,
+                          const uint32_t *d_chosen, const uint8_t *d_last,
+                          const uint64_t *d_mask, uint64_t *d_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d >= 1, "d must be >= 1");
+    REQUIRE(d_plain && d_rnd && d_chosen && d_last && d_mask && d_out, "null device pointer");
+    HIP_TRY(csgn::encrypt(n_bits, d, batch, d_plain, (const u64 *)d_rnd, d_chosen, d_last, nullptr,
+                          (const u64 *)d_mask, 0, false, (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,
+                            const uint8_t *d_plain, const uint64_t *d_key,
+                            const uint64_t *d_mask, uint64_t seed, uint64_t *d_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d >= 1, "d must be >= 1");
+    REQUIRE(d_plain && d_key && d_mask && d_out, "null device pointer");
+    HIP_TRY(csgn::encrypt(n_bits, d, batch, d_plain, nullptr, nullptr, nullptr, (const u64 *)d_key,
+                          (const u64 *)d_mask, seed, true, (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_permute_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms_in, int per_term,
+                         const uint64_t *d_terms, const uint32_t *d_perm, uint64_t *d_out,
+                         void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_perm && d_out && (d_terms || terms_in == 0), "null device pointer");
+    HIP_TRY(csgn::permute(n_bits, batch, terms_in, per_term != 0, (const u64 *)d_terms, d_perm,
+                          (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_t n_words,
+                    uint64_t *d_out, void *stream)
+{
+    REQUIRE(n_bits > 0, "n_bits must be > 0");
+    if (n_words == 0)
+        return CSGN_OK;
+    REQUIRE(d_out, "null device pointer");
+    HIP_TRY(csgn::synth_fill(seed, n_bits, first_word, n_words, (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
+                uint64_t *d_digest, void *stream)
+{
+    REQUIRE(d_digest, "null device pointer");
+    if (n_words == 0)
+        return CSGN_OK;
+    REQUIRE(d_words, "null device pointer");
+    HIP_TRY(csgn::digest((const u64 *)d_words, n_words, first_index, (u64 *)d_digest, S(stream)));
+    return CSGN_OK;
+}
+
+/* debug hook used by the CPU tests to pin the division-by-invariant helper */
+uint32_t csgn_debug_fastdiv(uint32_t n, uint32_t d)
+{
+    return csgn_fastdiv(n, csgn_fastdiv_make(d));
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+// csgn_kernels.h -- launchers for the gfx950 kernels (internal; the public surface is
+// include/csgn_hip.h).
+#pragma once
+
+#include "csgn_common.h"
+
+namespace csgn {
+
+// Tunables of the tiled all-pairs kernel; defaults chosen by measurement on MI355X
+// ("all-pairs multiply").  Overridable through the environment for sweeps:
+// CSGN_MUL_M (column units per lane), CSGN_MUL_TI (left terms per tile),
+// CSGN_MUL_NT (1 = non-temporal stores).
+struct MulTuning {
+    int m;
+    int ti;
+    int nt;
+};
+MulTuning mul_tuning();
+
+hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
+                       u64 out_slots, hipStream_t s);
+hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_plan4,
+                           hipStream_t s);
+hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
+                      const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
+                      hipStream_t s);
+hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
+                       hipStream_t s);
+hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
+                      const u64 *offR, u64 *out, u64 *offOut, u64 max_terms_out, hipStream_t s);
+hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
+                   const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s);
+hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
+                   const u32 *chosen, const uint8_t *last, const u64 *key, const u64 *mask, u64 seed,
+                   bool device_rng, u64 *out, hipStream_t s);
+hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64 *terms,
+                   const u32 *perm, u64 *out, hipStream_t s);
+hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);
+hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
+
+size_t decrypt_scratch_bytes(u64 total_terms);
+
+} // namespace csgn

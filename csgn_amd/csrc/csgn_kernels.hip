@@ -1,0 +1,897 @@
+// csgn_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the certFHE/CSGN
+// ciphertext-arithmetic hot path.  Everything here is bitwise integer work bound by HBM
+// bandwidth: there is no MFMA anywhere.  Design notes live in DESIGN.md; reference
+// citations (/root/reference/...) name the scalar loop each kernel replaces.
+//
+// Common shape of the data path: lanes own consecutive 16-byte units so every wave-level
+// load/store is one global_{load,store}_dwordx4 covering 1 KiB of contiguous, 128-B-aligned
+// HBM; anything that is re-used across a tile (the opposing operand's terms, the key mask)
+// is staged once in LDS and read back with ds_read_b128.
+#include "csgn_kernels.h"
+
+#include <cstdlib>
+
+namespace csgn {
+
+namespace {
+
+constexpr u32 kWave = 64;
+
+template <typename Unit, bool NT>
+__device__ inline void unit_store(Unit *p, Unit v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+// true iff every mask bit is set in x
+__device__ inline bool unit_covers(unit16 x, unit16 m)
+{
+    unit16 d = (x & m) ^ m;
+    return (d.x | d.y | d.z | d.w) == 0u;
+}
+__device__ inline bool unit_covers(unit8 x, unit8 m) { return (x & m) == m; }
+
+inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// 1x1 batch: out = a & b over a flat stream of units.
+// Replaces Ciphertext::defaultN_multiply (src/Ciphertext.cpp:124-131) for a whole batch of
+// fresh ciphertext pairs (BASELINE configs 2 and 4): 3 x 16 B of HBM traffic per unit.
+// ---------------------------------------------------------------------------------------
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
+                                                    const Unit *__restrict__ b,
+                                                    Unit *__restrict__ o, u64 n_units)
+{
+    constexpr u32 kPer = 4;
+    u64 base = (u64)blockIdx.x * (256u * kPer) + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * (256u * kPer);
+    for (; base < n_units; base += stride) {
+        Unit x[kPer], y[kPer];
+#pragma unroll
+        for (u32 j = 0; j < kPer; ++j) {
+            u64 i = base + (u64)j * 256u;
+            if (i < n_units) {
+                x[j] = a[i];
+                y[j] = b[i];
+            }
+        }
+#pragma unroll
+        for (u32 j = 0; j < kPer; ++j) {
+            u64 i = base + (u64)j * 256u;
+            if (i < n_units)
+                o[i] = x[j] & y[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Small uniform shapes (t1*t2*U below one tile): flat map from output unit to
+// (pair, left term i, right column c).  Operands are tiny and re-read through L1/L2.
+// Replaces the general path of Ciphertext::multiply (src/Ciphertext.cpp:146-163).
+// ---------------------------------------------------------------------------------------
+template <typename Unit, int MF>
+__global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
+                                                  const Unit *__restrict__ R,
+                                                  Unit *__restrict__ out, u64 total_units, u32 t1,
+                                                  u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU)
+{
+    const u32 CU = t2 * U, LU = t1 * U, PU = t1 * CU;
+    const u64 g0 = (u64)blockIdx.x * (256u * MF);
+    const u64 pair0 = g0 / PU;
+    const u32 r0 = (u32)(g0 - pair0 * PU);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u32 local = (u32)m * 256u + threadIdx.x;
+        const u64 g = g0 + local;
+        if (g < total_units) {
+            u32 r = r0 + local;
+            const u32 dp = csgn_fastdiv(r, dPU);
+            r -= dp * PU;
+            const u64 pair = pair0 + dp;
+            const u32 i = csgn_fastdiv(r, dCU);
+            const u32 c = r - i * CU;
+            const u32 k = c - csgn_fastdiv(c, dU) * U;
+            out[g] = L[pair * LU + (u64)i * U + k] & R[pair * CU + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// All-pairs multiply, LDS-tiled.  Replaces Ciphertext::multiply's general path
+// (src/Ciphertext.cpp:146-163):  out[(i*t2 + j)*dL + k] = L[i*dL + k] & R[j*dL + k].
+//
+// For a fixed left term i the output row is the WHOLE right operand masked by one
+// broadcast term, so the product is a pure streaming write (reads are < 0.3 % of the
+// bytes at 1024x1024).  A workgroup owns TI left terms x (BS*M) right-operand units:
+//   - the TI left terms sit in LDS (TI*U units, 10 KB at N=1247, TI=64);
+//   - each lane keeps its M right units in registers for the whole tile;
+//   - per row, a lane reads the one left unit it needs (index c mod U) with ds_read_b128
+//     and issues M global_store_dwordx4; a wave instruction writes 1 KiB contiguous.
+// When U divides the block size every one of a lane's M columns needs the same left unit
+// (SAMEK), so there is one LDS read per row instead of M.
+// ---------------------------------------------------------------------------------------
+struct MulArgs {
+    const void *L;
+    const void *R;
+    void *out;
+    const u64 *offL;
+    const u64 *offR;
+    const u64 *offOut;
+    u32 t1, t2, U, TI, col_tiles, row_tiles;
+};
+
+template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
+__global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Unit *lds = reinterpret_cast<Unit *>(smem_raw);
+
+    const u32 BS = blockDim.x, tid = threadIdx.x, U = a.U;
+    const u32 tiles = a.col_tiles * a.row_tiles;
+    const u32 pair = blockIdx.x / tiles;
+    const u32 tile = blockIdx.x - pair * tiles;
+    const u32 row_tile = tile / a.col_tiles;
+    const u32 col_tile = tile - row_tile * a.col_tiles;
+
+    u32 t1, t2;
+    u64 lbase, rbase, obase;   // in units
+    if (RAGGED) {
+        const u64 l0 = a.offL[pair], r0 = a.offR[pair];
+        t1 = (u32)(a.offL[pair + 1] - l0);
+        t2 = (u32)(a.offR[pair + 1] - r0);
+        lbase = l0 * U;
+        rbase = r0 * U;
+        obase = a.offOut[pair] * U;
+    } else {
+        t1 = a.t1;
+        t2 = a.t2;
+        lbase = (u64)pair * t1 * U;
+        rbase = (u64)pair * t2 * U;
+        obase = (u64)pair * t1 * t2 * U;
+    }
+    const u32 cu = t2 * U;
+    const u32 i0 = row_tile * a.TI;
+    const u32 c0 = col_tile * BS * M;
+    if (i0 >= t1 || c0 >= cu)
+        return;                               // whole workgroup leaves together
+    const u32 rows = min(a.TI, t1 - i0);
+
+    // stage the left tile: rows*U consecutive units, coalesced
+    const Unit *Lp = reinterpret_cast<const Unit *>(a.L) + lbase + (u64)i0 * U;
+    for (u32 u = tid; u < rows * U; u += BS)
+        lds[u] = Lp[u];
+
+    // this lane's right-operand units stay in registers for the whole tile
+    const Unit *Rp = reinterpret_cast<const Unit *>(a.R) + rbase;
+    Unit r[M];
+    u32 k[M];
+    bool valid[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const u32 c = c0 + (u32)m * BS + tid;
+        valid[m] = c < cu;
+        if (valid[m])
+            r[m] = Rp[c];
+        k[m] = c % U;
+    }
+    __syncthreads();
+
+    Unit *orow = reinterpret_cast<Unit *>(a.out) + obase + (u64)i0 * cu + c0 + tid;
+#pragma unroll 2
+    for (u32 i = 0; i < rows; ++i) {
+        if (SAMEK) {
+            const Unit l = lds[i * U + k[0]];
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                if (valid[m])
+                    unit_store<Unit, NT>(orow + (u32)m * BS, r[m] & l);
+        } else {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                if (valid[m])
+                    unit_store<Unit, NT>(orow + (u32)m * BS, r[m] & lds[i * U + k[m]]);
+        }
+        orow += cu;
+    }
+}
+
+// Exclusive scan of t1_b*t2_b -> product term offsets; also max shapes.  One workgroup:
+// planning is O(batch) on 16 bytes per pair and is not on the bandwidth-critical path.
+__global__ void __launch_bounds__(1024) k_mul_plan(u64 batch, const u64 *__restrict__ offL,
+                                                   const u64 *__restrict__ offR,
+                                                   u64 *__restrict__ offOut, u64 *__restrict__ plan4)
+{
+    __shared__ u64 part[1024];
+    __shared__ u64 mx[3][1024];
+    const u32 tid = threadIdx.x;
+    const u64 chunk = (batch + 1023) / 1024;
+    const u64 b0 = min(batch, (u64)tid * chunk), b1 = min(batch, b0 + chunk);
+    u64 sum = 0, m1 = 0, m2 = 0, mp = 0;
+    for (u64 b = b0; b < b1; ++b) {
+        const u64 t1 = offL[b + 1] - offL[b], t2 = offR[b + 1] - offR[b];
+        sum += t1 * t2;
+        m1 = max(m1, t1);
+        m2 = max(m2, t2);
+        mp = max(mp, t1 * t2);
+    }
+    part[tid] = sum;
+    mx[0][tid] = m1;
+    mx[1][tid] = m2;
+    mx[2][tid] = mp;
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0, a1 = 0, a2 = 0, ap = 0;
+        for (u32 t = 0; t < 1024; ++t) {
+            const u64 v = part[t];
+            part[t] = run;
+            run += v;
+            a1 = max(a1, mx[0][t]);
+            a2 = max(a2, mx[1][t]);
+            ap = max(ap, mx[2][t]);
+        }
+        offOut[batch] = run;
+        plan4[0] = run;
+        plan4[1] = a1;
+        plan4[2] = a2;
+        plan4[3] = ap;
+    }
+    __syncthreads();
+    u64 run = part[tid];
+    for (u64 b = b0; b < b1; ++b) {
+        offOut[b] = run;
+        run += (offL[b + 1] - offL[b]) * (offR[b + 1] - offR[b]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// add = concatenation (src/Ciphertext.cpp:107-122).  Flat map over output units.
+// ---------------------------------------------------------------------------------------
+template <typename Unit, int MF>
+__global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
+                                                  const Unit *__restrict__ R,
+                                                  Unit *__restrict__ out, u64 total_units, u32 LU,
+                                                  u32 RU, FastDiv dOU)
+{
+    const u32 OU = LU + RU;
+    const u64 g0 = (u64)blockIdx.x * (256u * MF);
+    const u64 pair0 = g0 / OU;
+    const u32 r0 = (u32)(g0 - pair0 * OU);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u32 local = (u32)m * 256u + threadIdx.x;
+        const u64 g = g0 + local;
+        if (g < total_units) {
+            u32 r = r0 + local;
+            const u32 dp = csgn_fastdiv(r, dOU);
+            r -= dp * OU;
+            const u64 pair = pair0 + dp;
+            out[g] = (r < LU) ? L[pair * LU + r] : R[pair * RU + (r - LU)];
+        }
+    }
+}
+
+// Ragged add: workgroup (pair, tile) copies one tile of the pair's output.
+template <typename Unit, int MF>
+__global__ void __launch_bounds__(256) k_add_ragged(const Unit *__restrict__ L,
+                                                    const u64 *__restrict__ offL,
+                                                    const Unit *__restrict__ R,
+                                                    const u64 *__restrict__ offR,
+                                                    Unit *__restrict__ out, u32 U, u32 tiles)
+{
+    const u32 pair = blockIdx.x / tiles;
+    const u32 tile = blockIdx.x - pair * tiles;
+    const u64 l0 = offL[pair], r0 = offR[pair];
+    const u64 LU = (offL[pair + 1] - l0) * U, RU = (offR[pair + 1] - r0) * U;
+    const Unit *Lp = L + l0 * U;
+    const Unit *Rp = R + r0 * U;
+    Unit *Op = out + (l0 + r0) * U;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u64 u = (u64)tile * (256u * MF) + (u32)m * 256u + threadIdx.x;
+        if (u < LU + RU)
+            Op[u] = (u < LU) ? Lp[u] : Rp[u - LU];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_off_sum(u64 n, const u64 *__restrict__ a,
+                                                 const u64 *__restrict__ b, u64 *__restrict__ o)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        o[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// decrypt, pass 1: one hit bit per term.  Replaces the unpack-everything loops of
+// SecretKey::decrypt (src/SecretKey.cpp:110-137): a term "hits" iff all D secret positions
+// are 1, i.e. (term & mask) == mask over its dL words.  A workgroup streams 256 consecutive
+// terms with coalesced 16-B loads; a unit that misses the mask flags its term in LDS; the
+// 256 verdicts leave as four __ballot words, so the bitmap needs no atomics.
+// ---------------------------------------------------------------------------------------
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_term_hits(const Unit *__restrict__ terms,
+                                                   const Unit *__restrict__ mask, u64 total_terms,
+                                                   u32 U, FastDiv dU, u64 *__restrict__ hits)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Unit *lmask = reinterpret_cast<Unit *>(smem_raw);                  // U units
+    u32 *fail = reinterpret_cast<u32 *>(smem_raw + (size_t)U * sizeof(Unit));   // 256 flags
+
+    const u32 tid = threadIdx.x;
+    const u64 term0 = (u64)blockIdx.x * 256u;
+    const u32 nterms = (u32)min((u64)256, total_terms - term0);
+    const u32 nunits = nterms * U;
+    for (u32 k = tid; k < U; k += 256u)
+        lmask[k] = mask[k];
+    fail[tid] = 0;
+    __syncthreads();
+
+    const Unit *base = terms + term0 * U;
+#pragma unroll 4
+    for (u32 u = tid; u < nunits; u += 256u) {
+        const Unit x = base[u];
+        const u32 t = csgn_fastdiv(u, dU);
+        const u32 k = u - t * U;
+        if (!unit_covers(x, lmask[k]))
+            fail[t] = 1;                        // benign race: every writer stores 1
+    }
+    __syncthreads();
+
+    const bool hit = (tid < nterms) && (fail[tid] == 0);
+    const u64 b = __ballot(hit);
+    if ((tid & (kWave - 1)) == 0)
+        hits[(u64)blockIdx.x * 4u + (tid >> 6)] = b;
+}
+
+// decrypt, pass 2: XOR over the terms of each ciphertext = parity of the popcount of its
+// bit range (src/SecretKey.cpp:139, `_dec = (dec + _dec) % 2`).  G lanes per ciphertext:
+// 1 for small term counts, a whole wave (with a __ballot/__popcll fold) for large ones.
+template <int G>
+__global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hits,
+                                                     const u64 *__restrict__ off, u64 T, u64 batch,
+                                                     uint8_t *__restrict__ bits)
+{
+    const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 b = gid / G;
+    const u32 lane = (u32)(gid % G);
+    if (b >= batch)
+        return;
+    const u64 s = off ? off[b] : b * T;
+    const u64 e = off ? off[b + 1] : s + T;
+    u32 par = 0;
+    if (e > s) {
+        const u64 w0 = s >> 6, w1 = (e - 1) >> 6;
+        for (u64 w = w0 + lane; w <= w1; w += G) {
+            u64 x = hits[w];
+            if (w == w0)
+                x &= ~0ull << (s & 63);
+            if (w == w1 && (e & 63))
+                x &= (1ull << (e & 63)) - 1;
+            par ^= (u32)__popcll(x);
+        }
+    }
+    if (G == 1) {
+        bits[b] = (uint8_t)(par & 1u);
+    } else {
+        const u64 odd = __ballot(par & 1u);
+        if (lane == 0)
+            bits[b] = (uint8_t)(__popcll(odd) & 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// encrypt.  Replaces SecretKey::encrypt (bit vector src/SecretKey.cpp:35-80, packing
+// :175-197) with the per-position randomness supplied packed (or generated in place).
+// A workgroup builds CB ciphertexts in LDS: load/generate the random words, one lane per
+// ciphertext applies the plaintext-0 rule (pick one secret slot; clear it iff every OTHER
+// secret slot came out 1, else give it the spare random bit), then all lanes write the
+// tile out coalesced, OR-ing the key mask into plaintext-1 ciphertexts.
+// ---------------------------------------------------------------------------------------
+template <bool DEVRNG>
+__global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 batch, u32 CB,
+                                                 FastDiv ddL, const uint8_t *__restrict__ plain,
+                                                 const u64 *__restrict__ rnd,
+                                                 const u32 *__restrict__ chosen,
+                                                 const uint8_t *__restrict__ last,
+                                                 const u64 *__restrict__ key,
+                                                 const u64 *__restrict__ mask, u64 seed,
+                                                 u64 *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u64 *tile = reinterpret_cast<u64 *>(smem_raw);     // CB*dL words
+    u64 *lmask = tile + (size_t)CB * dL;               // dL words
+
+    const u32 tid = threadIdx.x;
+    const u64 c0 = (u64)blockIdx.x * CB;
+    const u32 nc = (u32)min((u64)CB, batch - c0);
+    const u32 nw = nc * dL;
+    const u32 rem = (u32)(n_bits & 63);
+    const u64 tail = rem ? ~0ull << (64 - rem) : ~0ull;
+
+    for (u32 u = tid; u < nw; u += 256u) {
+        const u32 c = csgn_fastdiv(u, ddL);
+        const u32 k = u - c * dL;
+        const u64 gw = c0 * dL + u;
+        u64 w = DEVRNG ? csgn_splitmix64(seed + CSGN_GOLDEN * (gw + 1)) : rnd[gw];
+        if (k == dL - 1)
+            w &= tail;
+        tile[u] = w;
+    }
+    for (u32 k = tid; k < dL; k += 256u)
+        lmask[k] = mask[k];
+    __syncthreads();
+
+    if (tid < nc && !(plain[c0 + tid] & 1u)) {
+        const u64 c = c0 + tid;
+        u64 pos;
+        u32 spare;
+        if (DEVRNG) {
+            pos = key[csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1)) % D];
+            spare = (u32)(csgn_splitmix64((seed ^ 0x8CB92BA72F3D8DD7ull) + CSGN_GOLDEN * (c + 1)) >> 32) & 1u;
+        } else {
+            pos = chosen[c];
+            spare = last[c] & 1u;
+        }
+        if (pos < n_bits) {
+            const u32 wsel = (u32)(pos >> 6), bsel = 63u - (u32)(pos & 63);
+            u64 *mine = tile + (size_t)tid * dL;
+            bool others = false, all_one = true;
+            for (u32 k = 0; k < dL; ++k) {
+                u64 m = lmask[k];
+                if (k == wsel)
+                    m &= ~(1ull << bsel);
+                if (m) {
+                    others = true;
+                    if ((mine[k] & m) != m)
+                        all_one = false;
+                }
+            }
+            // src/SecretKey.cpp:73-76; with no other secret slot the reference's v stays 0
+            const u64 newbit = (others && all_one) ? 0ull : (u64)spare;
+            mine[wsel] = (mine[wsel] & ~(1ull << bsel)) | (newbit << bsel);
+        }
+    }
+    __syncthreads();
+
+    for (u32 u = tid; u < nw; u += 256u) {
+        const u32 c = csgn_fastdiv(u, ddL);
+        const u32 k = u - c * dL;
+        u64 w = tile[u];
+        if (plain[c0 + c] & 1u)
+            w |= lmask[k];                      // src/SecretKey.cpp:44-45
+        out[c0 * dL + u] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Ciphertext::applyPermutation (src/Ciphertext.cpp:7-82): new bit j = old bit perm[j],
+// MSB-first.  One lane per output word gathers its 64 bits; the source term (<= a few
+// hundred bytes) stays in L1.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, u64 out_terms, u64 in_stride_words,
+                                                 u64 terms_in, const u64 *__restrict__ terms,
+                                                 const u32 *__restrict__ perm, u64 *__restrict__ out)
+{
+    const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (gid >= out_terms * dL)
+        return;
+    const u64 ct = gid / dL;
+    const u32 k = (u32)(gid - ct * dL);
+    u64 acc = 0;
+    if (terms_in != 0) {
+        const u64 *src = terms + ct * in_stride_words;
+        for (u32 s = 0; s < 64u; ++s) {
+            const u64 j = (u64)k * 64u + s;
+            if (j < n_bits) {
+                const u32 p = perm[j];
+                if (p < n_bits)
+                    acc |= ((src[p >> 6] >> (63u - (p & 63u))) & 1ull) << (63u - s);
+            }
+        }
+    }
+    out[gid] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// harness kernels (definitions shared with oracle/csgn_oracle.c)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_synth_fill(u64 seed, u32 dL, u64 tail, u64 first_word,
+                                                    u64 n_words, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256u;
+    for (; i < n_words; i += stride) {
+        const u64 idx = first_word + i;
+        u64 w = csgn_splitmix64(seed + CSGN_GOLDEN * (idx + 1));
+        if (idx % dL == dL - 1)
+            w &= tail;
+        out[i] = w;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_digest(const u64 *__restrict__ w, u64 n_words,
+                                                u64 first_index, u64 *__restrict__ d_digest)
+{
+    u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256u;
+    u64 acc = 0;
+    for (; i < n_words; i += stride)
+        acc += csgn_splitmix64(w[i] + CSGN_GOLDEN * (first_index + i + 1));
+    // wave-level fold, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & (kWave - 1)) == 0 && acc != 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(d_digest), acc);
+}
+
+// ------------------------------------------------------------------------- launch helpers
+
+template <typename T>
+bool aligned16(const T *p)
+{
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Block size for the tiled kernel: a multiple of 64 that U divides (so every column a lane
+// owns needs the same left unit), at least 256 threads, at most 512.  0 = none exists.
+u32 samek_block(u32 U)
+{
+    for (u32 bs = 256; bs <= 512; bs += 64)
+        if (bs % U == 0)
+            return bs;
+    return 0;
+}
+
+template <typename Unit, int M, bool RAGGED>
+hipError_t launch_tiled_m(const MulArgs &a, u32 bs, bool samek, bool nt, u32 blocks, size_t lds,
+                          hipStream_t s)
+{
+    if (samek) {
+        if (nt)
+            k_mul_tiled<Unit, M, true, RAGGED, true><<<blocks, bs, lds, s>>>(a);
+        else
+            k_mul_tiled<Unit, M, true, RAGGED, false><<<blocks, bs, lds, s>>>(a);
+    } else {
+        if (nt)
+            k_mul_tiled<Unit, M, false, RAGGED, true><<<blocks, bs, lds, s>>>(a);
+        else
+            k_mul_tiled<Unit, M, false, RAGGED, false><<<blocks, bs, lds, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+// Launch the tiled kernel for `pairs` pairs whose shapes are bounded by (t1, t2).
+template <typename Unit, bool RAGGED>
+hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
+{
+    const MulTuning tune = mul_tuning();
+    u32 bs = samek_block(U);
+    const bool samek = bs != 0;
+    if (!samek)
+        bs = 256;
+    const u32 cu = a.t2 * U;
+    // do not give a lane more columns than the row has
+    int m = tune.m;
+    while (m > 1 && (u64)bs * (m / 2) >= cu)
+        m /= 2;
+    // left tile: TI terms, capped so the LDS image stays <= 32 KB
+    u32 ti = (u32)tune.ti;
+    const u32 cap = (u32)(32768u / (U * sizeof(Unit)));
+    if (ti > cap)
+        ti = cap ? cap : 1;
+    if (ti > a.t1)
+        ti = a.t1;
+    a.U = U;
+    a.TI = ti;
+    a.col_tiles = (cu + bs * m - 1) / (bs * m);
+    a.row_tiles = (a.t1 + ti - 1) / ti;
+    const u64 tiles = (u64)a.col_tiles * a.row_tiles;
+    const size_t lds = (size_t)ti * U * sizeof(Unit);
+    // keep blockIdx.x / the u32 pair index in range: at most 2^30 workgroups per launch
+    const u64 max_pairs = ((1ull << 30) / tiles) ? ((1ull << 30) / tiles) : 1;
+    if (RAGGED && pairs > max_pairs)
+        return hipErrorInvalidValue;
+    for (u64 p0 = 0; p0 < pairs; p0 += max_pairs) {
+        const u64 np = (pairs - p0 < max_pairs) ? pairs - p0 : max_pairs;
+        MulArgs b = a;
+        if (!RAGGED) {
+            b.L = reinterpret_cast<const Unit *>(a.L) + p0 * a.t1 * U;
+            b.R = reinterpret_cast<const Unit *>(a.R) + p0 * a.t2 * U;
+            b.out = reinterpret_cast<Unit *>(a.out) + p0 * a.t1 * a.t2 * U;
+        }
+        const u32 blocks = (u32)(np * tiles);
+        hipError_t e;
+        switch (m) {
+        case 1: e = launch_tiled_m<Unit, 1, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        case 2: e = launch_tiled_m<Unit, 2, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        case 4: e = launch_tiled_m<Unit, 4, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        default: e = launch_tiled_m<Unit, 8, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        }
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+// One uniform chunk (pairs are contiguous in L, R and out).
+template <typename Unit>
+hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, const u64 *R, u64 *out,
+                             hipStream_t s)
+{
+    const Unit *Lu = reinterpret_cast<const Unit *>(L);
+    const Unit *Ru = reinterpret_cast<const Unit *>(R);
+    Unit *Ou = reinterpret_cast<Unit *>(out);
+    const u64 PU = (u64)t1 * t2 * U;
+    const u64 total = pairs * PU;
+    if (total == 0)
+        return hipSuccess;
+    if (t1 == 1 && t2 == 1) {
+        const u64 want = (total + 1023) / 1024;
+        const u32 blocks = (u32)(want < 65536 ? want : 65536);
+        k_and_stream<Unit><<<blocks, 256, 0, s>>>(Lu, Ru, Ou, total);
+        return hipGetLastError();
+    }
+    if (PU <= 8192) {
+        constexpr int MF = 8;
+        const u64 per_launch = (1ull << 30) * (256u * MF);
+        const u64 pairs_per = per_launch / PU ? per_launch / PU : 1;
+        for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
+            const u64 np = (pairs - p0 < pairs_per) ? pairs - p0 : pairs_per;
+            const u64 tot = np * PU;
+            k_mul_flat<Unit, MF><<<ceil_div_u64(tot, 256u * MF), 256, 0, s>>>(
+                Lu + p0 * t1 * U, Ru + p0 * t2 * U, Ou + p0 * PU, tot, t1, t2, U,
+                csgn_fastdiv_make((u32)PU), csgn_fastdiv_make(t2 * U), csgn_fastdiv_make(U));
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+    MulArgs a = {};
+    a.L = L;
+    a.R = R;
+    a.out = out;
+    a.t1 = t1;
+    a.t2 = t2;
+    return launch_tiled<Unit, false>(a, pairs, U, s);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------ public
+
+MulTuning mul_tuning()
+{
+    MulTuning t;
+    t.m = env_int("CSGN_MUL_M", 4);
+    if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
+        t.m = 4;
+    t.ti = env_int("CSGN_MUL_TI", 64);
+    if (t.ti < 1)
+        t.ti = 1;
+    t.nt = env_int("CSGN_MUL_NT", 0) ? 1 : 0;
+    return t;
+}
+
+hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
+                       u64 out_slots, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0 || t1 == 0 || t2 == 0)
+        return hipSuccess;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    const u64 slots = (out_slots == 0 || out_slots > batch) ? batch : out_slots;
+    for (u64 p0 = 0; p0 < batch; p0 += slots) {
+        const u64 np = (batch - p0 < slots) ? batch - p0 : slots;
+        const u64 *Lc = L + p0 * t1 * dL;
+        const u64 *Rc = R + p0 * t2 * dL;
+        hipError_t e = wide ? mul_uniform_chunk<unit16>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s)
+                            : mul_uniform_chunk<unit8>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_plan4,
+                           hipStream_t s)
+{
+    k_mul_plan<<<1, 1024, 0, s>>>(batch, offL, offR, offOut, d_plan4);
+    return hipGetLastError();
+}
+
+hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
+                      const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
+                      hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0 || max_t1 == 0 || max_t2 == 0)
+        return hipSuccess;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    MulArgs a = {};
+    a.L = L;
+    a.R = R;
+    a.out = out;
+    a.offL = offL;
+    a.offR = offR;
+    a.offOut = offOut;
+    a.t1 = (u32)max_t1;
+    a.t2 = (u32)max_t2;
+    return wide ? launch_tiled<unit16, true>(a, batch, U, s) : launch_tiled<unit8, true>(a, batch, U, s);
+}
+
+hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
+                       hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0 || t1 + t2 == 0)
+        return hipSuccess;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    constexpr int MF = 8;
+    const u64 OU = (t1 + t2) * U;
+    const u64 per_launch = (1ull << 30) * (256u * MF);
+    const u64 pairs_per = per_launch / OU ? per_launch / OU : 1;
+    for (u64 p0 = 0; p0 < batch; p0 += pairs_per) {
+        const u64 np = (batch - p0 < pairs_per) ? batch - p0 : pairs_per;
+        const u64 tot = np * OU;
+        const u32 blocks = ceil_div_u64(tot, 256u * MF);
+        const FastDiv d = csgn_fastdiv_make((u32)OU);
+        if (wide)
+            k_add_flat<unit16, MF><<<blocks, 256, 0, s>>>(
+                reinterpret_cast<const unit16 *>(L) + p0 * t1 * U,
+                reinterpret_cast<const unit16 *>(R) + p0 * t2 * U,
+                reinterpret_cast<unit16 *>(out) + p0 * OU, tot, (u32)(t1 * U), (u32)(t2 * U), d);
+        else
+            k_add_flat<unit8, MF><<<blocks, 256, 0, s>>>(L + p0 * t1 * U, R + p0 * t2 * U,
+                                                         out + p0 * OU, tot, (u32)(t1 * U),
+                                                         (u32)(t2 * U), d);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
+                      const u64 *offR, u64 *out, u64 *offOut, u64 max_terms_out, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    k_off_sum<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch + 1, offL, offR, offOut);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || batch == 0 || max_terms_out == 0)
+        return e;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    constexpr int MF = 4;
+    const u64 tiles = (max_terms_out * U + 256u * MF - 1) / (256u * MF);
+    if (batch * tiles > (1ull << 30))
+        return hipErrorInvalidValue;
+    const u32 blocks = (u32)(batch * tiles);
+    if (wide)
+        k_add_ragged<unit16, MF><<<blocks, 256, 0, s>>>(reinterpret_cast<const unit16 *>(L), offL,
+                                                        reinterpret_cast<const unit16 *>(R), offR,
+                                                        reinterpret_cast<unit16 *>(out), U, (u32)tiles);
+    else
+        k_add_ragged<unit8, MF><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, U, (u32)tiles);
+    return hipGetLastError();
+}
+
+size_t decrypt_scratch_bytes(u64 total_terms)
+{
+    return (size_t)((total_terms + 255) / 256) * 32u + 32u;
+}
+
+hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
+                   const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0)
+        return hipSuccess;
+    u64 *hits = reinterpret_cast<u64 *>(scratch);
+    if (total_terms) {
+        const bool wide = (dL % 2 == 0) && aligned16(terms) && aligned16(mask);
+        const u32 U = (u32)(wide ? dL / 2 : dL);
+        const u64 blocks64 = (total_terms + 255) / 256;
+        if (blocks64 > (1ull << 31) - 1)
+            return hipErrorInvalidValue;
+        const u32 blocks = (u32)blocks64;
+        const FastDiv dU = csgn_fastdiv_make(U);
+        if (wide)
+            k_term_hits<unit16><<<blocks, 256, (size_t)U * 16 + 1024, s>>>(
+                reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask),
+                total_terms, U, dU, hits);
+        else
+            k_term_hits<unit8><<<blocks, 256, (size_t)U * 8 + 1024, s>>>(terms, mask, total_terms, U,
+                                                                        dU, hits);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    const u64 avg = total_terms / batch;
+    if (avg <= 4096) {
+        k_hits_parity<1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
+    } else {
+        const u64 blocks64 = (batch * 64 + 255) / 256;
+        if (blocks64 > (1ull << 31) - 1)
+            return hipErrorInvalidValue;
+        k_hits_parity<64><<<(u32)blocks64, 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
+    }
+    return hipGetLastError();
+}
+
+hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
+                   const u32 *chosen, const uint8_t *last, const u64 *key, const u64 *mask, u64 seed,
+                   bool device_rng, u64 *out, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0)
+        return hipSuccess;
+    u32 cb = 64;
+    while (cb > 1 && (u64)cb * dL * 8 > 32768)
+        cb /= 2;
+    const size_t lds = ((size_t)cb * dL + dL) * 8;
+    const u64 blocks64 = (batch + cb - 1) / cb;
+    if (blocks64 > (1ull << 31) - 1)
+        return hipErrorInvalidValue;
+    const FastDiv ddL = csgn_fastdiv_make((u32)dL);
+    if (device_rng)
+        k_encrypt<true><<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, d, batch, cb, ddL, plain, rnd,
+                                                        chosen, last, key, mask, seed, out);
+    else
+        k_encrypt<false><<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, d, batch, cb, ddL, plain, rnd,
+                                                         chosen, last, key, mask, seed, out);
+    return hipGetLastError();
+}
+
+hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64 *terms,
+                   const u32 *perm, u64 *out, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    const u64 out_terms = per_term ? batch * terms_in : batch;
+    if (out_terms == 0)
+        return hipSuccess;
+    const u64 stride = per_term ? dL : terms_in * dL;
+    const u64 blocks64 = (out_terms * dL + 255) / 256;
+    if (blocks64 > (1ull << 31) - 1)
+        return hipErrorInvalidValue;
+    k_permute<<<(u32)blocks64, 256, 0, s>>>(n_bits, (u32)dL, out_terms, stride, terms_in, terms, perm, out);
+    return hipGetLastError();
+}
+
+hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s)
+{
+    if (n_words == 0)
+        return hipSuccess;
+    const u64 dL = (n_bits + 63) / 64;
+    const u32 rem = (u32)(n_bits & 63);
+    const u64 tail = rem ? ~0ull << (64 - rem) : ~0ull;
+    const u64 want = (n_words + 255) / 256;
+    const u32 blocks = (u32)(want < 16384 ? want : 16384);
+    k_synth_fill<<<blocks, 256, 0, s>>>(seed, (u32)dL, tail, first_word, n_words, out);
+    return hipGetLastError();
+}
+
+hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s)
+{
+    if (n_words == 0)
+        return hipSuccess;
+    const u64 want = (n_words + 255) / 256;
+    const u32 blocks = (u32)(want < 8192 ? want : 8192);
+    k_digest<<<blocks, 256, 0, s>>>(w, n_words, first_index, d_digest);
+    return hipGetLastError();
+}
+
+} // namespace csgn

@@ -1,0 +1,216 @@
+/*
+ * csgn_hip.h -- C ABI of libcsgn_hip.so: the MI355X (gfx950) implementation of the
+ * certFHE/CSGN ciphertext-arithmetic hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer; its seam is the set of
+ * six private array functions behind the certFHE:: classes:
+ *
+ *   Ciphertext::defaultN_multiply   /root/reference/src/Ciphertext.cpp:124-131
+ *   Ciphertext::multiply            /root/reference/src/Ciphertext.cpp:133-179
+ *   Ciphertext::add                 /root/reference/src/Ciphertext.cpp:107-122
+ *   SecretKey::encrypt(bit,n,d,s)   /root/reference/src/SecretKey.cpp:35-80   (+ packing :153-206)
+ *   SecretKey::defaultN_decrypt     /root/reference/src/SecretKey.cpp:82-102
+ *   SecretKey::decrypt(v,len,..)    /root/reference/src/SecretKey.cpp:104-147
+ *
+ * Each entry point below names the one(s) it replaces.  The certFHE:: C++ classes in
+ * include/certfhe/ are implemented on top of exactly these symbols; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - POD arguments only.  `const uint64_t *d_x` is a DEVICE pointer (HBM); `h_x` is a host
+ *     pointer.  Nothing here allocates memory the caller must free with delete[].
+ *   - Term buffers: a ciphertext of T terms at N bits is T*dL consecutive uint64 words,
+ *     dL = ceil(N/64); bit j of a term is word j/64, bit 63-(j%64) (MSB first); the unused
+ *     low bits of a term's last word are zero (src/Ciphertext.h:19-21, SecretKey.cpp:175-197).
+ *     The reference's parallel `bitlen` array is a pure function of (N, T) for every
+ *     ciphertext produced by encrypt/+/x and is NOT materialised on the device; see
+ *     csgn_bitlen_canonical().
+ *   - Batches: "uniform" = B ciphertexts of the same term count laid back to back;
+ *     "ragged" = CSR: d_off[B+1] term offsets into one flat term buffer (empty ciphertexts
+ *     allowed).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Compute calls
+ *     are asynchronous on that stream; the caller synchronises.
+ *   - Every function returns CSGN_OK (0) or a negative csgn_status; csgn_last_error() gives
+ *     a thread-local message.  The reference has no error convention at all;
+ *     misuse that is UB there is a reported error here.
+ *   - Thread safety: no hidden global state except the per-thread error string; one host
+ *     thread (or process) per GPU may call concurrently.
+ *   - There is NO CPU fallback: without a gfx950 device every compute call fails with
+ *     CSGN_ERR_NO_DEVICE.
+ */
+#ifndef CSGN_HIP_H
+#define CSGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum csgn_status {
+    CSGN_OK = 0,
+    CSGN_ERR_INVALID = -1,      /* bad argument (null pointer, N==0, key index >= N, ...) */
+    CSGN_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels handle (see each call) */
+    CSGN_ERR_NO_DEVICE = -3,    /* no HIP device / not gfx950 */
+    CSGN_ERR_HIP = -4           /* a HIP runtime call failed; message has the detail */
+} csgn_status;
+
+#define CSGN_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ runtime ---- */
+
+int csgn_abi_version(void);
+const char *csgn_last_error(void);
+
+/* Select `device` for the calling thread and verify it is a gfx950 part. */
+int csgn_init(int device);
+int csgn_device_count(int *h_count);
+/* Fills h_name (<= cap bytes) with the gcnArchName and reports CU count / HBM bytes. */
+int csgn_device_info(int device, char *h_name, size_t cap, int *h_cu_count, uint64_t *h_hbm_bytes);
+
+int csgn_malloc(void **d_ptr, size_t bytes);
+int csgn_free(void *d_ptr);
+int csgn_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int csgn_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int csgn_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+int csgn_memset(void *d_dst, int value, size_t bytes, void *stream);
+int csgn_stream_create(void **stream);
+int csgn_stream_destroy(void *stream);
+int csgn_stream_sync(void *stream);
+int csgn_event_create(void **event);
+int csgn_event_destroy(void *event);
+int csgn_event_record(void *event, void *stream);
+int csgn_event_elapsed_ms(void *start, void *stop, float *h_ms);   /* synchronises on stop */
+
+/* ------------------------------------------------- host-side metadata helpers ---- */
+
+/* Context::getDefaultN, src/Context.cpp:24-28. */
+uint64_t csgn_default_len(uint64_t n_bits);
+/* Context S = N/(2D), src/Context.cpp:22. */
+uint64_t csgn_context_s(uint64_t n_bits, uint64_t d);
+/* Result length in words of Ciphertext::multiply, src/Ciphertext.cpp:135-146. */
+uint64_t csgn_mul_len(uint64_t n_bits, uint64_t len1, uint64_t len2);
+/* The bitlen side-array the reference would hold for a T-term ciphertext
+ * (src/SecretKey.cpp:171-173 per term): h_bitlen[T*dL]. */
+int csgn_bitlen_canonical(uint64_t n_bits, uint64_t terms, uint64_t *h_bitlen);
+/* Pack a secret key (D indices in [0,N), src/SecretKey.h:22) into the dL-word MSB-first
+ * mask the decrypt/encrypt kernels consume.  Duplicate indices are allowed (setKey does
+ * not forbid them, src/SecretKey.cpp:292-302); an index >= N is CSGN_ERR_INVALID. */
+int csgn_key_mask(uint64_t n_bits, const uint64_t *h_key, uint64_t d, uint64_t *h_mask);
+
+/* ------------------------------------------------------------------ multiply ---- */
+
+/* Batched Ciphertext::multiply (src/Ciphertext.cpp:133-179) incl. the 1x1 fast path
+ * defaultN_multiply (:124-131).  For every pair b < batch:
+ *     out_b[(i*t2 + j)*dL + k] = L_b[i*dL + k] & R_b[j*dL + k]      i<t1, j<t2, k<dL
+ * d_left: batch*t1*dL words, d_right: batch*t2*dL, d_out: batch*t1*t2*dL.
+ * Pair p's product goes to slot (p % out_slots) of d_out when out_slots != 0 (streaming a
+ * batch through a fixed arena, SURVEY 8d "streaming rule"); out_slots == 0 means one slot
+ * per pair.  With out_slots < batch the call is split into launches of <= out_slots pairs
+ * in stream order so later pairs overwrite earlier ones deterministically.
+ * Limits: dL*8 <= 16384 bytes per term; t1*t2*dL < 2^32 per pair. */
+int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                     const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out,
+                     uint64_t out_slots, void *stream);
+
+/* Ragged form.  Step 1 (plan): from the operand term offsets compute the product term
+ * offsets d_off_out[batch+1] (exclusive scan of t1_b*t2_b) on the device and return
+ * h_plan[0] = total output terms, h_plan[1] = max t1, h_plan[2] = max t2,
+ * h_plan[3] = max t1*t2.  Synchronises `stream`.  d_off_out doubles as the per-pair result
+ * term counts the multi-GPU driver gathers (count_b = off[b+1]-off[b]). */
+int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
+                         uint64_t *d_off_out, uint64_t h_plan[4], void *stream);
+/* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets. */
+int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
+                    const uint64_t *d_left, const uint64_t *d_off_left,
+                    const uint64_t *d_right, const uint64_t *d_off_right,
+                    uint64_t *d_out, const uint64_t *d_off_out,
+                    uint64_t max_t1, uint64_t max_t2, void *stream);
+
+/* ----------------------------------------------------------------------- add ---- */
+
+/* Batched Ciphertext::add (src/Ciphertext.cpp:107-122): out_b = L_b || R_b, t1+t2 terms.
+ * No XOR, no de-duplication -- exactly the reference. */
+int csgn_add_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                     const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out,
+                     void *stream);
+/* Ragged: d_off_out[b] = d_off_left[b] + d_off_right[b] is written by the call. */
+int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
+                    const uint64_t *d_left, const uint64_t *d_off_left,
+                    const uint64_t *d_right, const uint64_t *d_off_right,
+                    uint64_t *d_out, uint64_t *d_off_out,
+                    uint64_t max_terms_out, void *stream);
+
+/* ------------------------------------------------------------------- decrypt ---- */
+
+/* Batched SecretKey::decrypt (src/SecretKey.cpp:104-147; single term :82-102):
+ *     bit_b = XOR over terms k of ( AND over key indices s of term_k[s] )
+ * d_mask is the dL-word key mask (csgn_key_mask) in device memory; d_bits receives one
+ * byte (0/1) per ciphertext.  d_scratch must hold csgn_decrypt_scratch_bytes(total terms)
+ * bytes (one hit bit per term).  An empty ciphertext decrypts to 0, as in the reference. */
+size_t csgn_decrypt_scratch_bytes(uint64_t total_terms);
+int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,
+                         const uint64_t *d_terms, const uint64_t *d_mask,
+                         uint8_t *d_bits, void *d_scratch, void *stream);
+int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+                        const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
+                        uint8_t *d_bits, void *d_scratch, void *stream);
+
+/* ------------------------------------------------------------------- encrypt ---- */
+
+/* Batched SecretKey::encrypt (bit vector src/SecretKey.cpp:35-80, MSB-first packing
+ * :153-206) with the randomness made an explicit argument (hard part 3).
+ * For ciphertext b:
+ *   d_rnd[b*dL ..]  the value rand()%2 the reference would have stored at each position,
+ *                   packed MSB-first (forced positions are ignored);
+ *   d_chosen[b]     for plaintext 0: the secret POSITION s[rand()%d] picked at :51;
+ *   d_last[b]       for plaintext 0: the final rand()%2 of :76 (used only when the other
+ *                   secret positions are not all 1).
+ * bit 1: out = rnd | mask.   bit 0: out = rnd with position `chosen` replaced by
+ * (all other secret positions are 1) ? 0 : last -- for D==1 the reference never clears it
+ * (its `v` stays 0), and neither does this.  Padding bits of the last word are cleared.
+ * The certFHE::SecretKey class maps the glibc rand() stream onto these arrays, which makes
+ * the device result bit-identical to the reference under the same srand(). */
+int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
+                          const uint8_t *d_plain, const uint64_t *d_rnd,
+                          const uint32_t *d_chosen, const uint8_t *d_last,
+                          const uint64_t *d_mask, uint64_t *d_out, void *stream);
+/* Throughput form: same construction, randomness from a counter-based generator on the
+ * device (splitmix64 of (seed, ciphertext, word)); d_key holds the D indices.  Same
+ * distribution as the reference, not the same bits. */
+int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,
+                            const uint8_t *d_plain, const uint64_t *d_key,
+                            const uint64_t *d_mask, uint64_t seed, uint64_t *d_out, void *stream);
+
+/* --------------------------------------------------------------- permutation ---- */
+
+/* Batched Ciphertext::applyPermutation (src/Ciphertext.cpp:7-82): new bit j = old bit
+ * perm[j].  d_perm: N uint32 indices.  The reference collapses a multi-term ciphertext to
+ * its permuted FIRST term; `per_term` = 0 reproduces that (d_out: batch*dL
+ * words, input stride terms_in*dL), `per_term` = 1 permutes every term (extension,
+ * d_out: batch*terms_in*dL). */
+int csgn_permute_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms_in, int per_term,
+                         const uint64_t *d_terms, const uint32_t *d_perm, uint64_t *d_out,
+                         void *stream);
+
+/* ------------------------------------------------------------------- harness ---- */
+
+/* Synthetic operand words: word idx = splitmix64(seed + GOLDEN*(idx+1)), the
+ * last word of each term masked to its top N%64 bits (the test checker restates this
+ * definition independently). */
+int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_t n_words,
+                    uint64_t *d_out, void *stream);
+/* 64-bit order-sensitive digest, ADDED into *d_digest (zero it first):
+ * sum_i splitmix64(w[i] + GOLDEN*(first_index+i+1)). */
+int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
+                uint64_t *d_digest, void *stream);
+
+/* Debug hook: quotient n/d computed by the same division-by-invariant helper the kernels
+ * use (csgn_amd/csrc/csgn_common.h); lets the CPU tests pin it without a GPU. */
+uint32_t csgn_debug_fastdiv(uint32_t n, uint32_t d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

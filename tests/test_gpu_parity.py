@@ -1,0 +1,483 @@
+"""GPU parity tests: every result comes from libcsgn_hip.so through the C ABI
+(include/csgn_hip.h) on cuda:0 and is compared bit-for-bit with the CPU oracle and with
+the committed golden vectors (tests/golden/, generated from the genuine reference).
+
+Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.binding import canonical_bitlen, glibc_draws
+
+pytestmark = pytest.mark.gpu
+
+KAT_PATH = os.path.join(os.path.dirname(__file__), "golden", "csgn_kat.json")
+CONTEXTS = [(1247, 16), (4096, 32), (65, 4), (64, 4), (63, 4), (130, 5), (129, 3)]
+
+
+def words(hex_list):
+    return np.array([int(h, 16) for h in hex_list], dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from csgn_amd.batch import HipPath
+    return HipPath(0)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(KAT_PATH) as f:
+        return json.load(f)
+
+
+def make_key(n, d, seed):
+    rng = np.random.default_rng(seed)
+    return rng.permutation(n)[:d].astype(np.uint64)
+
+
+def csr(counts):
+    off = np.zeros(len(counts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(np.asarray(counts, dtype=np.uint64))
+    return off
+
+
+# ------------------------------------------------------------------------------ harness
+
+def test_library_is_the_hip_one(hip):
+    import csgn_amd
+    assert os.path.exists(csgn_amd.lib_path())
+    assert hip.lib.csgn_abi_version() == 1
+
+
+@pytest.mark.parametrize("n", [1247, 4096, 65, 63])
+def test_synth_and_digest_match_oracle(hip, oracle, n):
+    nw = 12345 * oracle.default_len(n)
+    dev = hip.synth_fill(0xABCDEF, n, 0, nw)
+    host = oracle.synth(0xABCDEF, n, 0, nw)
+    assert np.array_equal(hip.download(dev), host)
+    assert hip.digest(dev) == oracle.digest(host)
+    assert hip.digest(dev, first_index=77) == oracle.digest(host, 77)
+    # offset window
+    dev2 = hip.synth_fill(0xABCDEF, n, 1000 * oracle.default_len(n), 500)
+    assert np.array_equal(hip.download(dev2), host[1000 * oracle.default_len(n):][:500])
+
+
+# ----------------------------------------------------------------------------- multiply
+
+@pytest.mark.parametrize("n,d", CONTEXTS)
+@pytest.mark.parametrize("t1,t2", [(1, 1), (1, 2), (2, 1), (2, 2), (3, 5), (7, 1), (1, 7), (32, 32),
+                                   (33, 65), (5, 300), (300, 5), (129, 130)])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_mul_uniform_matches_oracle(hip, oracle, n, d, t1, t2, batch):
+    dl = oracle.default_len(n)
+    L = oracle.synth(1000 + t1, n, 0, batch * t1 * dl)
+    R = oracle.synth(2000 + t2, n, 0, batch * t2 * dl)
+    out = hip.download(hip.mul_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R)))
+    per = t1 * t2 * dl
+    assert out.size == batch * per
+    for b in range(batch):
+        want, _ = oracle.mul(n, L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+        assert want.size == per
+        assert np.array_equal(out[b * per:(b + 1) * per], want), (n, t1, t2, b)
+
+
+@pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
+def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
+    monkeypatch.setenv("CSGN_MUL_M", str(m))
+    monkeypatch.setenv("CSGN_MUL_TI", str(ti))
+    monkeypatch.setenv("CSGN_MUL_NT", str(nt))
+    n = 1247
+    dl = 20
+    for (t1, t2) in [(100, 77), (64, 128), (257, 33)]:
+        L = oracle.synth(5, n, 0, 2 * t1 * dl)
+        R = oracle.synth(6, n, 0, 2 * t2 * dl)
+        out = hip.download(hip.mul_uniform(n, 2, t1, t2, hip.upload(L), hip.upload(R)))
+        per = t1 * t2 * dl
+        for b in range(2):
+            want, _ = oracle.mul(n, L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+            assert np.array_equal(out[b * per:(b + 1) * per], want)
+
+
+def test_mul_fresh_batch_65536(hip, oracle):
+    """BASELINE config 2: batch=65536 independent 1x1 products at N=1247."""
+    n, batch, dl = 1247, 65536, 20
+    L = oracle.synth(11, n, 0, batch * dl)
+    R = oracle.synth(12, n, 0, batch * dl)
+    out = hip.download(hip.mul_uniform(n, batch, 1, 1, hip.upload(L), hip.upload(R)))
+    assert np.array_equal(out, L & R)
+    # spot-check against the oracle's 1x1 path
+    for b in (0, 1, 4097, 65535):
+        want, _ = oracle.mul(n, L[b * dl:(b + 1) * dl], R[b * dl:(b + 1) * dl])
+        assert np.array_equal(out[b * dl:(b + 1) * dl], want)
+
+
+def test_mul_arena_slots(hip, oracle):
+    """Streaming a batch through a fixed arena: pair p lands in slot p % slots, later pairs
+    overwrite earlier ones (SURVEY 8d streaming rule)."""
+    n, dl, t1, t2, batch, slots = 1247, 20, 40, 50, 10, 4
+    L = oracle.synth(21, n, 0, batch * t1 * dl)
+    R = oracle.synth(22, n, 0, batch * t2 * dl)
+    out = hip.download(hip.mul_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R), out_slots=slots))
+    per = t1 * t2 * dl
+    assert out.size == slots * per
+    survivors = {p % slots: p for p in range(batch)}          # last writer per slot
+    for slot, p in survivors.items():
+        want, _ = oracle.mul(n, L[p * t1 * dl:(p + 1) * t1 * dl], R[p * t2 * dl:(p + 1) * t2 * dl])
+        assert np.array_equal(out[slot * per:(slot + 1) * per], want)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (63, 4), (130, 5)])
+def test_mul_ragged_matches_oracle(hip, oracle, n, d):
+    dl = oracle.default_len(n)
+    t1s = [1, 0, 3, 17, 1, 64, 2, 0, 5]
+    t2s = [1, 4, 0, 9, 33, 65, 2, 0, 1]
+    offL, offR = csr(t1s), csr(t2s)
+    L = oracle.synth(31, n, 0, int(offL[-1]) * dl)
+    R = oracle.synth(32, n, 0, int(offR[-1]) * dl)
+    out, off_out = hip.mul_ragged(n, hip.upload(L), hip.upload(offL), hip.upload(R), hip.upload(offR))
+    out, off_out = hip.download(out), hip.download(off_out)
+    assert np.array_equal(off_out, csr([a * b for a, b in zip(t1s, t2s)]))   # the gathered term counts
+    for b, (t1, t2) in enumerate(zip(t1s, t2s)):
+        got = out[int(off_out[b]) * dl:int(off_out[b + 1]) * dl]
+        if t1 == 0 or t2 == 0:
+            assert got.size == 0
+            continue
+        want, _ = oracle.mul(n, L[int(offL[b]) * dl:int(offL[b + 1]) * dl],
+                             R[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+        assert np.array_equal(got, want), b
+
+
+def test_mul_rejects_bad_arguments(hip):
+    from csgn_amd.capi import CsgnError, check
+    x = hip.empty_words(64)
+    with pytest.raises(CsgnError):      # N == 0
+        check(hip.lib.csgn_mul_uniform(0, 1, 1, 1, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0))
+    with pytest.raises(CsgnError):      # null operand
+        check(hip.lib.csgn_mul_uniform(1247, 1, 1, 1, 0, x.data_ptr(), x.data_ptr(), 0, 0))
+    with pytest.raises(CsgnError):      # term larger than the kernels stage
+        check(hip.lib.csgn_mul_uniform(1 << 20, 1, 1, 1, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0))
+
+
+# ---------------------------------------------------------------------------------- add
+
+@pytest.mark.parametrize("n,d", CONTEXTS)
+@pytest.mark.parametrize("t1,t2", [(1, 1), (1, 3), (4, 2), (17, 9), (0, 3), (5, 0), (300, 211)])
+def test_add_uniform_matches_oracle(hip, oracle, n, d, t1, t2):
+    dl = oracle.default_len(n)
+    batch = 5
+    L = oracle.synth(41, n, 0, max(batch * t1 * dl, 1))
+    R = oracle.synth(42, n, 0, max(batch * t2 * dl, 1))
+    out = hip.download(hip.add_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R)))
+    per = (t1 + t2) * dl
+    for b in range(batch):
+        want, _ = oracle.add(L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+        assert np.array_equal(out[b * per:(b + 1) * per], want)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (63, 4), (4096, 32)])
+def test_add_ragged_matches_oracle(hip, oracle, n, d):
+    dl = oracle.default_len(n)
+    t1s = [1, 0, 3, 170, 1, 0]
+    t2s = [1, 4, 0, 9, 333, 0]
+    offL, offR = csr(t1s), csr(t2s)
+    L = oracle.synth(51, n, 0, int(offL[-1]) * dl)
+    R = oracle.synth(52, n, 0, int(offR[-1]) * dl)
+    out, off_out = hip.add_ragged(n, hip.upload(L), hip.upload(offL), hip.upload(R), hip.upload(offR))
+    out, off_out = hip.download(out), hip.download(off_out)
+    assert np.array_equal(off_out, offL + offR)
+    for b in range(len(t1s)):
+        want, _ = oracle.add(L[int(offL[b]) * dl:int(offL[b + 1]) * dl],
+                             R[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+        assert np.array_equal(out[int(off_out[b]) * dl:int(off_out[b + 1]) * dl], want)
+
+
+# ------------------------------------------------------------------------------ decrypt
+
+def planted(oracle, n, key, terms, hits, seed):
+    dl = oracle.default_len(n)
+    v = oracle.synth(seed, n, 0, terms * dl).reshape(terms, dl)
+    v[:hits] |= oracle.key_mask(n, key)
+    w, b = int(key[0]) // 64, 63 - int(key[0]) % 64
+    v[hits:, w] &= ~np.uint64(1 << b)
+    rng = np.random.default_rng(seed)
+    rng.shuffle(v, axis=0)
+    return np.ascontiguousarray(v.reshape(-1))
+
+
+@pytest.mark.parametrize("n,d", CONTEXTS)
+def test_decrypt_uniform_matches_oracle(hip, oracle, n, d):
+    key = make_key(n, d, 3)
+    mask = hip.key_mask(n, key)
+    assert np.array_equal(mask, oracle.key_mask(n, key))
+    dmask = hip.upload(mask)
+    for terms in (1, 2, 5, 64, 255, 256, 257, 1000):
+        batch = 7
+        parts = [planted(oracle, n, key, terms, (b * 3) % (terms + 1), 100 + b) for b in range(batch)]
+        flat = np.concatenate(parts)
+        bits = hip.download(hip.decrypt_uniform(n, batch, terms, hip.upload(flat), dmask))
+        for b in range(batch):
+            want = oracle.decrypt(n, key, parts[b]) if terms <= 64 else oracle.decrypt_canonical(n, key, parts[b])
+            assert want == ((b * 3) % (terms + 1)) % 2
+            assert bits[b] == want, (n, terms, b)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (63, 4)])
+def test_decrypt_ragged_matches_oracle(hip, oracle, n, d):
+    key = make_key(n, d, 4)
+    dmask = hip.upload(hip.key_mask(n, key))
+    counts = [1, 0, 3, 300, 64, 0, 65, 1]
+    parts = [planted(oracle, n, key, t, t // 2 + (t % 3 == 0), 200 + i) if t else np.zeros(0, np.uint64)
+             for i, t in enumerate(counts)]
+    flat = np.concatenate(parts)
+    off = csr(counts)
+    bits = hip.download(hip.decrypt_ragged(n, hip.upload(flat), hip.upload(off), dmask))
+    for i, t in enumerate(counts):
+        want = oracle.decrypt(n, key, parts[i]) if t else 0     # empty ciphertext -> 0
+        assert bits[i] == want, i
+
+
+def test_decrypt_one_million_terms(hip, oracle):
+    """The stress shape of SURVEY 6 (1,048,576 terms): wave-per-ciphertext parity fold."""
+    n, d, terms = 1247, 16, 1 << 20
+    key = make_key(n, d, 5)
+    dmask = hip.upload(hip.key_mask(n, key))
+    for hits in (0, 1, 12345, 54321):
+        flat = planted(oracle, n, key, terms, hits, 300 + hits)
+        bits = hip.download(hip.decrypt_uniform(n, 1, terms, hip.upload(flat), dmask))
+        assert bits[0] == hits % 2 == oracle.decrypt_canonical(n, key, flat)
+
+
+# ------------------------------------------------------------------------------ encrypt
+
+def explicit_randomness(n, key, bit, draws):
+    """Map the reference's rand() stream (src/SecretKey.cpp:35-80) onto the explicit
+    arguments of csgn_encrypt_explicit.  Returns (rnd words, chosen, last, draws used)."""
+    dl = (n + 63) // 64
+    keyset = set(int(k) for k in key)
+    rnd = np.zeros(dl, dtype=np.uint64)
+    pos = 0
+
+    def setbit(i, v):
+        if v:
+            rnd[i // 64] |= np.uint64(1 << (63 - i % 64))
+
+    if bit & 1:
+        for i in range(n):
+            if i not in keyset:
+                setbit(i, int(draws[pos]) % 2)
+                pos += 1
+        return rnd, 0, 0, pos
+    chosen = int(key[int(draws[pos]) % len(key)])
+    pos += 1
+    others = []
+    for i in range(n):
+        if i == chosen:
+            continue
+        v = int(draws[pos]) % 2
+        pos += 1
+        setbit(i, v)
+        if i in keyset:
+            others.append(v)
+    last = 0
+    if not (others and all(others)):
+        last = int(draws[pos]) % 2
+        pos += 1
+    return rnd, chosen, last, pos
+
+
+def test_encrypt_explicit_reproduces_reference_ciphertexts(hip, oracle, kat):
+    """Golden fresh ciphertexts (from the genuine reference under srand(seed)) rebuilt on the GPU."""
+    for case in kat["encrypt"]:
+        n, d, seed, bits = case["n"], case["d"], case["seed"], case["bits"]
+        key = np.array(case["key"], dtype=np.uint64)
+        draws = glibc_draws(seed, (n + 2) * len(bits))
+        dl = oracle.default_len(n)
+        rnd = np.zeros(len(bits) * dl, dtype=np.uint64)
+        chosen = np.zeros(len(bits), dtype=np.uint32)
+        last = np.zeros(len(bits), dtype=np.uint8)
+        pos = 0
+        for i, b in enumerate(bits):
+            r, c, l, used = explicit_randomness(n, key, b, draws[pos:])
+            rnd[i * dl:(i + 1) * dl] = r
+            chosen[i], last[i] = c, l
+            pos += used
+        out = hip.encrypt_explicit(n, d, hip.upload(np.array(bits, dtype=np.uint8)), hip.upload(rnd),
+                                   hip.upload(chosen), hip.upload(last), hip.upload(hip.key_mask(n, key)))
+        assert np.array_equal(hip.download(out), words(case["ct"])), (n, d, seed)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (65, 4), (63, 4), (100, 1), (128, 8)])
+def test_encrypt_device_rng_properties(hip, oracle, n, d):
+    key = make_key(n, d, 6)
+    mask = hip.key_mask(n, key)
+    rng = np.random.default_rng(7)
+    batch = 4099
+    plain = rng.integers(0, 2, size=batch).astype(np.uint8)
+    dmask = hip.upload(mask)
+    out = hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=99)
+    dl = oracle.default_len(n)
+    host = hip.download(out).reshape(batch, dl)
+    rem = n % 64
+    if rem:
+        assert not np.any(host[:, -1] & np.uint64((1 << (64 - rem)) - 1))      # padding stays zero
+    bits = hip.download(hip.decrypt_uniform(n, batch, 1, out, dmask))
+    if d > 1:
+        assert np.array_equal(bits, plain)
+    for b in range(0, batch, 257):
+        assert bits[b] == oracle.decrypt(n, key, host[b])
+    # non-secret positions look random: overall density near 1/2
+    dens = np.unpackbits(host.view(np.uint8)).mean() * (dl * 64) / n
+    assert 0.45 < dens < 0.56
+    # different seed -> different ciphertexts, same seed -> identical
+    again = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=99))
+    other = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=100))
+    assert np.array_equal(again.reshape(batch, dl), host) and not np.array_equal(other.reshape(batch, dl), host)
+
+
+# -------------------------------------------------------------------------- permutation
+
+def test_permutation_golden(hip, oracle, kat):
+    for case in kat["permutation"]:
+        n, d = case["n"], case["d"]
+        dl = oracle.default_len(n)
+        perm = np.array(case["perm"], dtype=np.uint32)
+        cts = words(case["ct"])
+        dperm = hip.upload(perm)
+        # three single-term ciphertexts as a batch
+        out = hip.download(hip.permute_uniform(n, 3, 1, hip.upload(cts), dperm))
+        for i in range(3):
+            assert np.array_equal(out[i * dl:(i + 1) * dl],
+                                  oracle.permute_ciphertext(n, perm.astype(np.uint64), cts[i * dl:(i + 1) * dl]))
+        assert np.array_equal(out[:dl], words(case["permuted_first"]))
+        # one 3-term ciphertext: the reference's truncation to the permuted first term
+        multi = hip.download(hip.permute_uniform(n, 1, 3, hip.upload(cts), dperm))
+        assert np.array_equal(multi, words(case["permuted_multi"]))
+        # per-term extension permutes every term
+        allp = hip.download(hip.permute_uniform(n, 1, 3, hip.upload(cts), dperm, per_term=True))
+        assert np.array_equal(allp, out)
+        # decrypt with the permuted key
+        pkey = np.array(case["permuted_key"], dtype=np.uint64)
+        bit = hip.download(hip.decrypt_uniform(n, 1, 1, hip.upload(multi), hip.upload(hip.key_mask(n, pkey))))
+        assert bit[0] == case["dec_permuted"] == 1
+
+
+# ------------------------------------------------------------------------ golden vectors
+
+def test_golden_mul_add_decrypt(hip, oracle, kat):
+    for case in kat["mul"]:
+        n, t1, t2 = case["n"], case["t1"], case["t2"]
+        out = hip.download(hip.mul_uniform(n, 1, t1, t2, hip.upload(words(case["a"])), hip.upload(words(case["b"]))))
+        assert np.array_equal(out, words(case["out"])), (n, t1, t2)
+    for case in kat["add"]:
+        n, t1, t2 = case["n"], case["t1"], case["t2"]
+        out = hip.download(hip.add_uniform(n, 1, t1, t2, hip.upload(words(case["a"])), hip.upload(words(case["b"]))))
+        assert np.array_equal(out, words(case["out"]))
+    for case in kat["decrypt"]:
+        n, terms, hits = case["n"], case["terms"], case["hits"]
+        key = np.array(case["key"], dtype=np.uint64)
+        dl = oracle.default_len(n)
+        v = oracle.synth(case["seed"], n, 0, terms * dl).reshape(terms, dl)
+        v[:hits] |= oracle.key_mask(n, key)
+        w, b = int(key[0]) // 64, 63 - int(key[0]) % 64
+        v[hits:, w] &= ~np.uint64(1 << b)
+        flat = np.ascontiguousarray(v.reshape(-1))
+        dev = hip.upload(flat)
+        assert "%016x" % hip.digest(dev) == case["digest"]
+        bit = hip.download(hip.decrypt_uniform(n, 1, terms, dev, hip.upload(hip.key_mask(n, key))))
+        assert bit[0] == case["bit"]
+
+
+def test_golden_basic_operations(hip, oracle, kat):
+    """tests/basic_operations.cpp on the GPU: Dec(Enc(1)+Enc(0)) = 1, Dec(Enc(1)*Enc(0)) = 0."""
+    c = kat["basic_operations"]
+    n = c["n"]
+    key = np.array(c["key"], dtype=np.uint64)
+    c1, c0 = hip.upload(words(c["c1"])), hip.upload(words(c["c0"]))
+    added = hip.add_uniform(n, 1, 1, 1, c1, c0)
+    mult = hip.mul_uniform(n, 1, 1, 1, c1, c0)
+    assert np.array_equal(hip.download(added), words(c["added"]))
+    assert np.array_equal(hip.download(mult), words(c["multiplied"]))
+    dmask = hip.upload(hip.key_mask(n, key))
+    assert hip.download(hip.decrypt_uniform(n, 1, 2, added, dmask))[0] == c["dec_added"] == 1
+    assert hip.download(hip.decrypt_uniform(n, 1, 1, mult, dmask))[0] == c["dec_multiplied"] == 0
+
+
+def test_golden_large_product_digests(hip, oracle, kat):
+    """32x32, 256x256 and the 1024x1024 metric shape: digest of the GPU product equals the
+    digest of the genuine reference's product (SURVEY 8c vi)."""
+    for case in kat["digest"]:
+        n, t1, t2 = case["n"], case["t1"], case["t2"]
+        dl = oracle.default_len(n)
+        a = hip.synth_fill(case["seed_a"], n, 0, t1 * dl)
+        b = hip.synth_fill(case["seed_b"], n, 0, t2 * dl)
+        out = hip.mul_uniform(n, 1, t1, t2, a, b)
+        assert out.numel() == case["out_len"]
+        assert "%016x" % hip.digest(out) == case["digest"], (t1, t2)
+        host = hip.download(out[:4]), hip.download(out[-4:])
+        assert np.array_equal(host[0], words(case["first_words"]))
+        assert np.array_equal(host[1], words(case["last_words"]))
+
+
+# ------------------------------------------------------- full-size, size-independent checks
+
+def test_full_size_product_row_structure_and_decrypt_homomorphism(hip, oracle):
+    """1024x1024 at N=1247: (i) every sampled output row i equals R masked by left term i;
+    (ii) dec(a*b) = dec(a) & dec(b) with the 1M-term product decrypted on the GPU."""
+    n, d, t, dl = 1247, 16, 1024, 20
+    key = make_key(n, d, 8)
+    mask = hip.key_mask(n, key)
+    dmask = hip.upload(mask)
+    for ha, hb in [(3, 5), (4, 7), (0, 9)]:
+        A = planted(oracle, n, key, t, ha, 900 + ha)
+        B = planted(oracle, n, key, t, hb, 950 + hb)
+        dA, dB = hip.upload(A), hip.upload(B)
+        prod = hip.mul_uniform(n, 1, t, t, dA, dB)
+        P = hip.download(prod).reshape(t, t, dl)
+        Ar, Br = A.reshape(t, dl), B.reshape(t, dl)
+        for i in (0, 1, 63, 64, 511, 1023):
+            assert np.array_equal(P[i], Br & Ar[i][None, :])
+        bit = hip.download(hip.decrypt_uniform(n, 1, t * t, prod, dmask))[0]
+        da = hip.download(hip.decrypt_uniform(n, 1, t, dA, dmask))[0]
+        db = hip.download(hip.decrypt_uniform(n, 1, t, dB, dmask))[0]
+        assert da == ha % 2 and db == hb % 2
+        assert bit == (da & db) == (ha * hb) % 2
+
+
+def test_circuit_config5_style(hip, oracle):
+    """Context(4096,32): depth-8 mixed add/mul circuit on device-resident ciphertexts,
+    permutation applied to the fresh inputs and to the key; plaintext tracked in the clear."""
+    n, d = 4096, 32
+    dl = 64
+    key = make_key(n, d, 10)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n).astype(np.uint64)
+    pkey = oracle.permute_key(n, perm, key)
+    dperm = hip.upload(perm.astype(np.uint32))
+    dmask = hip.upload(hip.key_mask(n, key))
+    dpmask = hip.upload(hip.key_mask(n, pkey))
+    nb = 40
+    plain = rng.integers(0, 2, size=nb).astype(np.uint8)
+    fresh = hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5)
+    fresh = hip.permute_uniform(n, nb, 1, fresh, dperm)           # permuted fresh inputs
+    assert np.array_equal(hip.download(hip.decrypt_uniform(n, nb, 1, fresh, dpmask)), plain)
+    ct = lambda i: fresh[i * dl:(i + 1) * dl]
+    x, xb, xt = ct(0), int(plain[0]), 1
+    host_x = hip.download(x)
+    k = 1
+    for level in range(1, 9):
+        if level % 2:
+            x = hip.add_uniform(n, 1, xt, 1, x, ct(k)); xb ^= int(plain[k]); xt += 1
+            host_x, _ = oracle.add(host_x, hip.download(ct(k)))
+            k += 1
+        else:
+            rhs = hip.add_uniform(n, 1, 1, 1, ct(k), ct(k + 1)); rb = int(plain[k]) ^ int(plain[k + 1])
+            host_rhs, _ = oracle.add(hip.download(ct(k)), hip.download(ct(k + 1)))
+            x = hip.mul_uniform(n, 1, xt, 2, x, rhs); xb &= rb; xt *= 2
+            host_x, _ = oracle.mul(n, host_x, host_rhs)
+            k += 2
+        assert np.array_equal(hip.download(x), host_x)
+        assert hip.download(hip.decrypt_uniform(n, 1, xt, x, dpmask))[0] == xb == oracle.decrypt_canonical(n, pkey, host_x)
