@@ -87,6 +87,22 @@ def cpu_baseline(terms: int, budget_s: float):
     }
 
 
+def measured_traffic(kernel: str, terms: int, pairs_per_launch: float):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile
+    (profiles/traffic_current.json, produced by tools/prof_pmc.sh + tools/pmc_summary.py).
+    Returned only when it was measured on this exact launch shape; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "traffic_current.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (t.get("kernel") == kernel and t.get("n_bits") == N_BITS and t.get("terms") == terms
+            and t.get("pairs_per_launch") == pairs_per_launch):
+        return t.get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -212,7 +228,9 @@ def main():
                 "peak": HBM_PEAK_BPS / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_BPS,
-                "traffic": None,
+                "traffic": measured_traffic("k_mul_tiled", T, pairs_per_launch),
+                "traffic_unit": "bytes/launch (PMC, profiles/traffic_current.json)",
+                "algorithmic_bytes_per_launch": pairs_per_launch * bytes_per_mul,
                 "kernel": "k_mul_tiled",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": n_launches,

@@ -14,6 +14,8 @@ struct MulTuning {
     int m;
     int ti;
     int nt;
+    int flat;   // CSGN_MUL_FLAT: force the flat kernel with this many units per lane (0 = auto)
+    int bs;     // CSGN_MUL_BS: override the tiled kernel's block size (0 = auto)
 };
 MulTuning mul_tuning();
 

@@ -575,10 +575,13 @@ template <typename Unit, bool RAGGED>
 hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 {
     const MulTuning tune = mul_tuning();
-    u32 bs = samek_block(U);
-    const bool samek = bs != 0;
-    if (!samek)
+    // With M > 1 a block size that U divides lets every column of a lane share one LDS read
+    // (SAMEK); with the default M == 1 there is a single column per lane and 256 threads
+    // (4 KiB-aligned row segments) measured fastest.
+    u32 bs = tune.bs ? (u32)tune.bs : (tune.m > 1 ? samek_block(U) : 256u);
+    if (bs == 0)
         bs = 256;
+    const bool samek = bs % U == 0;
     const u32 cu = a.t2 * U;
     // do not give a lane more columns than the row has
     int m = tune.m;
@@ -641,16 +644,25 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         k_and_stream<Unit><<<blocks, 256, 0, s>>>(Lu, Ru, Ou, total);
         return hipGetLastError();
     }
-    if (PU <= 8192) {
-        constexpr int MF = 8;
-        const u64 per_launch = (1ull << 30) * (256u * MF);
+    const MulTuning tune = mul_tuning();
+    if ((PU <= 8192 || tune.flat) && PU < (1ull << 31)) {
+        const int mf = tune.flat ? tune.flat : 8;
+        const u64 per_launch = (1ull << 30) * (256u * (u64)mf);
         const u64 pairs_per = per_launch / PU ? per_launch / PU : 1;
+        const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
+                      dU = csgn_fastdiv_make(U);
         for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
             const u64 np = (pairs - p0 < pairs_per) ? pairs - p0 : pairs_per;
             const u64 tot = np * PU;
-            k_mul_flat<Unit, MF><<<ceil_div_u64(tot, 256u * MF), 256, 0, s>>>(
-                Lu + p0 * t1 * U, Ru + p0 * t2 * U, Ou + p0 * PU, tot, t1, t2, U,
-                csgn_fastdiv_make((u32)PU), csgn_fastdiv_make(t2 * U), csgn_fastdiv_make(U));
+            const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
+            const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
+            Unit *Oc = Ou + p0 * PU;
+            switch (mf) {
+            case 1: k_mul_flat<Unit, 1><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
+            case 2: k_mul_flat<Unit, 2><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
+            case 4: k_mul_flat<Unit, 4><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
+            default: k_mul_flat<Unit, 8><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
+            }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess)
                 return e;
@@ -673,13 +685,23 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
 MulTuning mul_tuning()
 {
     MulTuning t;
-    t.m = env_int("CSGN_MUL_M", 4);
+    // Defaults from the MI355X sweeps recorded in DESIGN.md / profiles/: 256-thread workgroups
+    // (4 KiB row segments), one column unit per lane, 4 left terms per tile, non-temporal
+    // stores.  Short-lived workgroups keep the chip-wide write front dense in address space,
+    // which is what HBM rewards; TI=64 tiles lose ~20 % to the scattered store pattern.
+    t.m = env_int("CSGN_MUL_M", 1);
     if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
-        t.m = 4;
-    t.ti = env_int("CSGN_MUL_TI", 64);
+        t.m = 1;
+    t.ti = env_int("CSGN_MUL_TI", 4);
     if (t.ti < 1)
         t.ti = 1;
-    t.nt = env_int("CSGN_MUL_NT", 0) ? 1 : 0;
+    t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
+    t.flat = env_int("CSGN_MUL_FLAT", 0);
+    if (t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
+        t.flat = 0;
+    t.bs = env_int("CSGN_MUL_BS", 0);
+    if (t.bs % 64 != 0 || t.bs < 64 || t.bs > 512)
+        t.bs = 0;
     return t;
 }
 

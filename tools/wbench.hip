@@ -1,0 +1,151 @@
+// wbench.hip -- dev microbenchmark: what write-stream shapes reach on MI355X HBM.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/wbench tools/wbench.hip
+// Not part of the product; used to size the all-pairs kernel's store pattern.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int unit16;
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+// A: linear fill, grid-stride
+template <bool NT>
+__global__ void __launch_bounds__(256) fill_stride(unit16 *o, u64 n, unit16 v)
+{
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 s = (u64)gridDim.x * 256;
+    for (; i < n; i += s) { if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v; }
+}
+
+// B: linear fill, each block owns a contiguous chunk of CH units per thread-column (block writes 256*K units contiguous)
+template <int K, bool NT>
+__global__ void __launch_bounds__(256) fill_chunk(unit16 *o, u64 n, unit16 v)
+{
+    u64 base = (u64)blockIdx.x * (256 * K) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        u64 i = base + (u64)k * 256;
+        if (i < n) { if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v; }
+    }
+}
+
+// C: the all-pairs tile pattern with constant data: block = (pair, row_tile, col_tile); BS threads,
+// M columns per lane, TI rows; row stride cu units.
+template <int M, bool NT>
+__global__ void __launch_bounds__(512) fill_tiled(unit16 *o, u32 cu, u32 rows_total, u32 TI, u32 col_tiles, u32 row_tiles, unit16 v)
+{
+    const u32 BS = blockDim.x;
+    const u32 tiles = col_tiles * row_tiles;
+    const u32 pair = blockIdx.x / tiles;
+    const u32 tile = blockIdx.x - pair * tiles;
+    const u32 row_tile = tile / col_tiles, col_tile = tile - row_tile * col_tiles;
+    const u32 i0 = row_tile * TI, c0 = col_tile * BS * M;
+    unit16 *p = o + (u64)pair * rows_total * cu + (u64)i0 * cu + c0 + threadIdx.x;
+    const u32 rows = min(TI, rows_total - i0);
+    for (u32 i = 0; i < rows; ++i) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            if (c0 + m * BS + threadIdx.x < cu) { if (NT) __builtin_nontemporal_store(v, p + m * BS); else p[m * BS] = v; }
+        }
+        p += cu;
+    }
+}
+
+// D: row-sequential: block owns TI full rows (contiguous TI*cu units), loops columns inner.
+template <bool NT>
+__global__ void __launch_bounds__(512) fill_rows(unit16 *o, u32 cu, u32 rows_total, u32 TI, u32 row_tiles, unit16 v)
+{
+    const u32 BS = blockDim.x;
+    const u32 pair = blockIdx.x / row_tiles;
+    const u32 row_tile = blockIdx.x - pair * row_tiles;
+    const u32 i0 = row_tile * TI;
+    const u32 rows = min(TI, rows_total - i0);
+    unit16 *p = o + (u64)pair * rows_total * cu + (u64)i0 * cu;
+    const u64 n = (u64)rows * cu;
+    for (u64 i = threadIdx.x; i < n; i += BS) { if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
+}
+
+template <typename F>
+double bench(const char *name, double bytes, int rounds, F launch)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(); CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < rounds; ++r) {
+        CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    double med = ts[ts.size() / 2], best = ts[0];
+    printf("%-44s median %7.1f GB/s  best %7.1f GB/s  (%.3f ms)\n", name, bytes / med / 1e6, bytes / best / 1e6, med);
+    fflush(stdout);
+    return med;
+}
+
+int main(int argc, char **argv)
+{
+    const int slots = argc > 1 ? atoi(argv[1]) : 64;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 7;
+    const u32 T = 1024, U = 10;
+    const u32 cu = T * U;                       // units per output row
+    const u64 n = (u64)slots * T * cu;          // units in the arena
+    const double bytes = (double)n * 16;
+    unit16 *o;
+    CK(hipMalloc((void **)&o, n * 16));
+    unit16 v = {1, 2, 3, 4};
+    printf("arena %.2f GiB (%d slots of %ux%u terms)\n", bytes / (1 << 30) / 1.0, slots, T, T);
+
+    bench("hipMemsetAsync", bytes, rounds, [&] { CK(hipMemsetAsync(o, 0x5A, n * 16, 0)); });
+    for (int g : {1024, 2048, 4096, 8192, 16384}) {
+        char nm[64]; snprintf(nm, 64, "fill_stride grid=%d", g);
+        bench(nm, bytes, rounds, [&] { fill_stride<false><<<g, 256>>>(o, n, v); });
+    }
+    bench("fill_stride grid=4096 NT", bytes, rounds, [&] { fill_stride<true><<<4096, 256>>>(o, n, v); });
+    bench("fill_chunk K=1", bytes, rounds, [&] { fill_chunk<1, false><<<(u32)((n + 255) / 256), 256>>>(o, n, v); });
+    bench("fill_chunk K=4", bytes, rounds, [&] { fill_chunk<4, false><<<(u32)((n + 1023) / 1024), 256>>>(o, n, v); });
+    bench("fill_chunk K=16", bytes, rounds, [&] { fill_chunk<16, false><<<(u32)((n + 4095) / 4096), 256>>>(o, n, v); });
+    bench("fill_chunk K=16 NT", bytes, rounds, [&] { fill_chunk<16, true><<<(u32)((n + 4095) / 4096), 256>>>(o, n, v); });
+    bench("fill_chunk K=64", bytes, rounds, [&] { fill_chunk<64, false><<<(u32)((n + 16383) / 16384), 256>>>(o, n, v); });
+
+    for (u32 bs : {64u, 128u, 256u, 320u, 512u}) {
+        for (u32 ti : {1u, 2u, 4u, 8u}) {
+            const u32 M = 1; u32 ct = (cu + bs * M - 1) / (bs * M), rt = (T + ti - 1) / ti;
+            char nm[64]; snprintf(nm, 64, "fill_tiled bs=%u M=1 TI=%u", bs, ti);
+            bench(nm, bytes, rounds, [&] { fill_tiled<1, false><<<slots * ct * rt, bs>>>(o, cu, T, ti, ct, rt, v); });
+        }
+    }
+    if (argc > 3) { CK(hipFree(o)); return 0; }
+    for (u32 bs : {256u, 320u, 512u, 640u}) {
+        for (u32 ti : {16u, 64u, 256u}) {
+            {
+                const u32 M = 4; u32 ct = (cu + bs * M - 1) / (bs * M), rt = (T + ti - 1) / ti;
+                char nm[64]; snprintf(nm, 64, "fill_tiled bs=%u M=4 TI=%u", bs, ti);
+                if (bs <= 512) bench(nm, bytes, rounds, [&] { fill_tiled<4, false><<<slots * ct * rt, bs>>>(o, cu, T, ti, ct, rt, v); });
+            }
+            {
+                const u32 M = 1; u32 ct = (cu + bs * M - 1) / (bs * M), rt = (T + ti - 1) / ti;
+                char nm[64]; snprintf(nm, 64, "fill_tiled bs=%u M=1 TI=%u", bs, ti);
+                if (bs <= 512) bench(nm, bytes, rounds, [&] { fill_tiled<1, false><<<slots * ct * rt, bs>>>(o, cu, T, ti, ct, rt, v); });
+            }
+        }
+    }
+    for (u32 bs : {256u, 512u}) {
+        for (u32 ti : {1u, 4u, 16u, 64u}) {
+            u32 rt = (T + ti - 1) / ti;
+            char nm[64]; snprintf(nm, 64, "fill_rows bs=%u TI=%u", bs, ti);
+            bench(nm, bytes, rounds, [&] { fill_rows<false><<<slots * rt, bs>>>(o, cu, T, ti, rt, v); });
+            snprintf(nm, 64, "fill_rows bs=%u TI=%u NT", bs, ti);
+            bench(nm, bytes, rounds, [&] { fill_rows<true><<<slots * rt, bs>>>(o, cu, T, ti, rt, v); });
+        }
+    }
+    CK(hipFree(o));
+    return 0;
+}
