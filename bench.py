@@ -109,6 +109,7 @@ def main():
     import torch
     import torch.distributed as dist
     from csgn_amd.batch import HipPath
+    from csgn_amd.shard import gather_term_counts, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,18 +131,23 @@ def main():
     bytes_per_mul = 8 * dl * (T + T + T * T)              # B_mul, SURVEY 8d
     launches_per_step = (batch + slots - 1) // slots
 
-    # ---- operands resident in HBM (seeded per rank so ranks hold different ciphertexts) ----
-    left = hip.synth_fill(SEED + 101 * rank + 1, N_BITS, 0, batch * words_per_operand)
-    right = hip.synth_fill(SEED + 101 * rank + 2, N_BITS, 0, batch * words_per_operand)
+    # ---- operands resident in HBM.  The global batch is world*batch pairs; this rank owns
+    # the contiguous range [lo, hi) and its words are a function of the GLOBAL pair index, so
+    # per-pair results do not depend on the GPU count. ----
+    total_pairs = world * batch
+    lo, hi = shard_range(total_pairs, rank, world)
+    assert hi - lo == batch
+    left = hip.synth_fill(SEED + 1, N_BITS, lo * words_per_operand, batch * words_per_operand)
+    right = hip.synth_fill(SEED + 2, N_BITS, lo * words_per_operand, batch * words_per_operand)
     arena = hip.empty_words(slots * words_per_product)
     counts = torch.full((batch,), T * T, dtype=torch.int64, device=dev)   # result term counts
-    gathered = torch.empty((world * batch,), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.empty((total_pairs,), dtype=torch.int64, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
     def step():
         hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, counts)
+            gather_term_counts(counts, total_pairs, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +163,7 @@ def main():
         hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
         ev[k][1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, counts)
+            gather_term_counts(counts, total_pairs, out=gathered)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,9 +190,9 @@ def main():
         ok = True
         first_of_last = (launches_per_step - 1) * slots
         for slot in sorted({0, (batch - first_of_last) - 1}):
-            p = first_of_last + slot
-            a = orc.synth(SEED + 101 * rank + 1, N_BITS, p * words_per_operand, words_per_operand)
-            b = orc.synth(SEED + 101 * rank + 2, N_BITS, p * words_per_operand, words_per_operand)
+            p = lo + first_of_last + slot                      # global pair index
+            a = orc.synth(SEED + 1, N_BITS, p * words_per_operand, words_per_operand)
+            b = orc.synth(SEED + 2, N_BITS, p * words_per_operand, words_per_operand)
             want, _ = orc.mul(N_BITS, a, b)
             got = hip.digest(arena[slot * words_per_product:(slot + 1) * words_per_product])
             ok = ok and (got == orc.digest(want))

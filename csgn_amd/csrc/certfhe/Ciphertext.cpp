@@ -1,0 +1,321 @@
+// Ciphertext.cpp -- device-resident ciphertext behind the reference's Ciphertext API.
+//
+// Results follow /root/reference/src/Ciphertext.cpp: operator* = all-pairs AND with the
+// left operand as the slow index (:133-179, :231-247), operator+ = concatenation
+// (:107-122, :204-229), applyPermutation = permuted FIRST term (:7-82).  The arithmetic runs
+// in libcsgn_hip (csgn_mul_uniform / csgn_add_uniform / csgn_permute_uniform); this file only
+// marshals handles and the host-side bitlen bookkeeping.
+//
+// Deliberate differences: operator= re-creates the Context instead of leaving
+// it deleted; operator*= does not mismatch delete/delete[]; 64-bit indices throughout.
+#include "Ciphertext.h"
+
+#include "runtime.h"
+
+namespace certFHE {
+
+using detail::DevicePayload;
+
+namespace {
+
+const Context &requireContext(const Context *ctx)
+{
+    if (!ctx)
+        throw std::logic_error("certFHE::Ciphertext: operation needs a Context (object was default-constructed)");
+    return *ctx;
+}
+
+bool isCanonicalBitlen(const uint64_t *bl, uint64_t len, uint64_t n)
+{
+    const uint64_t dl = csgn_default_len(n), rem = n % 64;
+    if (dl == 0)
+        return len == 0;
+    for (uint64_t i = 0; i < len; ++i) {
+        const uint64_t want = (rem && (i % dl) == dl - 1) ? rem : 64;
+        if (bl[i] != want)
+            return false;
+    }
+    return true;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ life cycle
+
+Ciphertext::Ciphertext()
+    : len(0), certFHEcontext(nullptr), host_v(nullptr), host_bitlen(nullptr), custom_bitlen(false)
+{
+}
+
+Ciphertext::Ciphertext(const uint64_t *V, const uint64_t *Bitlen, const uint64_t length,
+                       const Context &context)
+    : Ciphertext()
+{
+    certFHEcontext = new Context(context);
+    len = length;
+    payload = detail::uploadWords(V, length);
+    if (Bitlen && length && !isCanonicalBitlen(Bitlen, length, context.getN())) {
+        host_bitlen = new uint64_t[length];
+        memcpy(host_bitlen, Bitlen, length * sizeof(uint64_t));
+        custom_bitlen = true;
+    }
+}
+
+Ciphertext::Ciphertext(const Ciphertext &c) : Ciphertext() { *this = c; }
+
+Ciphertext::~Ciphertext()
+{
+    dropMirrors();
+    delete certFHEcontext;
+    certFHEcontext = nullptr;
+    len = 0;
+}
+
+void Ciphertext::dropMirrors()
+{
+    delete[] host_v;
+    host_v = nullptr;
+    delete[] host_bitlen;
+    host_bitlen = nullptr;
+    custom_bitlen = false;
+}
+
+void Ciphertext::publish(const std::shared_ptr<DevicePayload> &p, uint64_t words)
+{
+    dropMirrors();
+    payload = p;
+    len = words;
+}
+
+Ciphertext &Ciphertext::operator=(const Ciphertext &c)
+{
+    if (this == &c)
+        return *this;
+    dropMirrors();
+    payload = c.payload;                       // immutable payload: sharing == deep copy
+    len = c.len;
+    if (c.custom_bitlen && c.host_bitlen) {
+        host_bitlen = new uint64_t[len ? len : 1];
+        memcpy(host_bitlen, c.host_bitlen, len * sizeof(uint64_t));
+        custom_bitlen = true;
+    }
+    Context *fresh = c.certFHEcontext ? new Context(*c.certFHEcontext) : nullptr;
+    delete certFHEcontext;
+    certFHEcontext = fresh;
+    return *this;
+}
+
+// ------------------------------------------------------------------ accessors
+
+void Ciphertext::setValues(const uint64_t *V, const uint64_t length)
+{
+    std::shared_ptr<DevicePayload> p = detail::uploadWords(V, length);
+    delete[] host_v;
+    host_v = nullptr;
+    payload = p;
+    len = length;
+}
+
+void Ciphertext::setBitlen(const uint64_t *Bitlen, const uint64_t length)
+{
+    delete[] host_bitlen;
+    host_bitlen = nullptr;
+    custom_bitlen = false;
+    len = length;
+    const bool canonical = certFHEcontext && isCanonicalBitlen(Bitlen, length, certFHEcontext->getN());
+    if (!canonical && length) {
+        host_bitlen = new uint64_t[length];
+        memcpy(host_bitlen, Bitlen, length * sizeof(uint64_t));
+        custom_bitlen = true;
+    }
+}
+
+void Ciphertext::setContext(const Context &context)
+{
+    Context *fresh = new Context(context);
+    delete certFHEcontext;
+    certFHEcontext = fresh;
+}
+
+uint64_t Ciphertext::getLen() const { return len; }
+
+Context Ciphertext::getContext() const { return requireContext(certFHEcontext); }
+
+uint64_t *Ciphertext::getValues() const
+{
+    if (!host_v && len && payload) {
+        host_v = new uint64_t[len];
+        detail::downloadBytes(host_v, payload->ptr, (size_t)len * 8);
+    }
+    return host_v;
+}
+
+uint64_t *Ciphertext::getBitlen() const
+{
+    if (!host_bitlen && len && certFHEcontext) {
+        const uint64_t n = certFHEcontext->getN(), dl = certFHEcontext->getDefaultN(), rem = n % 64;
+        host_bitlen = new uint64_t[len];
+        for (uint64_t i = 0; i < len; ++i)
+            host_bitlen[i] = (rem && (i % dl) == dl - 1) ? rem : 64;   // src/SecretKey.cpp:171-173
+    }
+    return host_bitlen;
+}
+
+uint64_t Ciphertext::getTerms() const
+{
+    const uint64_t dl = certFHEcontext ? certFHEcontext->getDefaultN() : 0;
+    return dl ? len / dl : 0;
+}
+
+const uint64_t *Ciphertext::deviceValues() const { return payload ? payload->data() : nullptr; }
+
+bool Ciphertext::hasCanonicalBitlen() const { return !custom_bitlen; }
+
+long Ciphertext::size()
+{
+    // same arithmetic as src/Ciphertext.cpp:91-101: three pointers, one length, and the
+    // two len-word arrays of the reference's in-memory form
+    long bytes = 0;
+    bytes += sizeof(Context *) + sizeof(uint64_t) + 2 * sizeof(uint64_t *);
+    bytes += (long)(len * 2 * sizeof(uint64_t));
+    return bytes;
+}
+
+ostream &operator<<(ostream &out, const Ciphertext &c)
+{
+    const uint64_t *v = c.getValues();
+    const uint64_t *bl = c.getBitlen();
+    for (uint64_t w = 0; w < c.getLen(); ++w) {
+        const uint64_t nbits = bl ? bl[w] : 64;
+        for (uint64_t s = 0; s < nbits && s < 64; ++s)
+            out << ((v[w] >> (63 - s)) & 1ull);
+    }
+    out << std::endl;
+    return out;
+}
+
+// ------------------------------------------------------------------ arithmetic
+
+void Ciphertext::combineBitlen(const Ciphertext &lhs, const Ciphertext &rhs, bool product)
+{
+    // Only reached when an operand carries a non-canonical Bitlen (4-arg ctor / setBitlen).
+    const uint64_t dl = certFHEcontext->getDefaultN();
+    if (product) {
+        if (!lhs.custom_bitlen)
+            return;                                   // pattern comes from the LEFT term only
+        const uint64_t *src = lhs.getBitlen();
+        host_bitlen = new uint64_t[len ? len : 1];
+        if (lhs.len == dl && rhs.len == dl) {
+            memcpy(host_bitlen, src, dl * sizeof(uint64_t));            // src/Ciphertext.cpp:140-142
+        } else {
+            const uint64_t t1 = lhs.len / dl, t2 = rhs.len / dl;
+            uint64_t *dst = host_bitlen;
+            for (uint64_t i = 0; i < t1; ++i)
+                for (uint64_t j = 0; j < t2; ++j, dst += dl)
+                    memcpy(dst, src + i * dl, dl * sizeof(uint64_t));   // src/Ciphertext.cpp:165-176
+        }
+    } else {
+        host_bitlen = new uint64_t[len ? len : 1];
+        if (lhs.len)
+            memcpy(host_bitlen, lhs.getBitlen(), lhs.len * sizeof(uint64_t));          // :215-223
+        if (rhs.len)
+            memcpy(host_bitlen + lhs.len, rhs.getBitlen(), rhs.len * sizeof(uint64_t));
+    }
+    custom_bitlen = true;
+}
+
+Ciphertext Ciphertext::combine(const Ciphertext &a, const Ciphertext &b, bool product)
+{
+    const Context &ctx = requireContext(a.certFHEcontext);
+    const uint64_t n = ctx.getN(), dl = ctx.getDefaultN();
+    Ciphertext out;
+    out.certFHEcontext = new Context(ctx);
+
+    if (product) {
+        const uint64_t t1 = dl ? a.len / dl : 0, t2 = dl ? b.len / dl : 0;
+        const uint64_t newlen = csgn_mul_len(n, a.len, b.len);
+        std::shared_ptr<DevicePayload> p = detail::allocWords(newlen);
+        if (newlen > t1 * t2 * dl)      // ragged tail the reference leaves unwritten
+            detail::check(csgn_memset(p->ptr, 0, (size_t)newlen * 8, detail::stream()), "csgn_memset");
+        if (t1 && t2)
+            detail::check(csgn_mul_uniform(n, 1, t1, t2, a.deviceValues(), b.deviceValues(), p->data(),
+                                           0, detail::stream()),
+                          "csgn_mul_uniform");
+        out.publish(p, newlen);
+    } else {
+        const uint64_t newlen = a.len + b.len;
+        std::shared_ptr<DevicePayload> p = detail::allocWords(newlen);
+        if (dl && a.len % dl == 0 && b.len % dl == 0) {
+            if (newlen)
+                detail::check(csgn_add_uniform(n, 1, a.len / dl, b.len / dl, a.deviceValues(),
+                                               b.deviceValues(), p->data(), detail::stream()),
+                              "csgn_add_uniform");
+        } else {
+            // lengths that are not whole terms: plain device-to-device concatenation
+            detail::check(csgn_memcpy_d2d(p->data(), a.deviceValues(), (size_t)a.len * 8, detail::stream()),
+                          "csgn_memcpy_d2d");
+            detail::check(csgn_memcpy_d2d(p->data() + a.len, b.deviceValues(), (size_t)b.len * 8,
+                                          detail::stream()),
+                          "csgn_memcpy_d2d");
+        }
+        out.publish(p, newlen);
+    }
+    if (a.custom_bitlen || b.custom_bitlen)
+        out.combineBitlen(a, b, product);
+    return out;
+}
+
+Ciphertext Ciphertext::operator+(const Ciphertext &c) const { return combine(*this, c, false); }
+
+Ciphertext Ciphertext::operator*(const Ciphertext &c) const { return combine(*this, c, true); }
+
+Ciphertext &Ciphertext::operator+=(const Ciphertext &c)
+{
+    Ciphertext r = combine(*this, c, false);
+    *this = r;
+    return *this;
+}
+
+Ciphertext &Ciphertext::operator*=(const Ciphertext &c)
+{
+    Ciphertext r = combine(*this, c, true);
+    *this = r;
+    return *this;
+}
+
+// ------------------------------------------------------------------ permutation
+
+void Ciphertext::applyPermutation_inplace(const Permutation &permutation)
+{
+    const Context &ctx = requireContext(certFHEcontext);
+    const uint64_t n = ctx.getN(), dl = ctx.getDefaultN();
+    if (custom_bitlen)
+        throw std::runtime_error("certFHE::Ciphertext::applyPermutation: a ciphertext with a "
+                                 "non-canonical Bitlen cannot be permuted on the device");
+    if (permutation.getLength() < n)
+        throw std::invalid_argument("certFHE::Ciphertext::applyPermutation: permutation shorter than N");
+    std::vector<uint32_t> p32(n);
+    const uint64_t *p = permutation.getPermutation();
+    for (uint64_t i = 0; i < n; ++i)
+        p32[i] = (uint32_t)p[i];
+    // one staging block: [perm as u32, padded to 8 bytes]
+    std::shared_ptr<DevicePayload> dperm = detail::allocBytes(((size_t)n * 4 + 7) & ~(size_t)7);
+    detail::check(csgn_memcpy_h2d(dperm->ptr, p32.data(), (size_t)n * 4, detail::stream()), "csgn_memcpy_h2d");
+    std::shared_ptr<DevicePayload> out = detail::allocWords(dl);
+    // per_term = 0: the reference keeps only the permuted FIRST term (src/Ciphertext.cpp:33-47)
+    detail::check(csgn_permute_uniform(n, 1, dl ? len / dl : 0, 0, deviceValues(),
+                                       static_cast<const uint32_t *>(dperm->ptr), out->data(),
+                                       detail::stream()),
+                  "csgn_permute_uniform");
+    detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");   // p32 goes out of scope
+    publish(out, dl);
+}
+
+Ciphertext Ciphertext::applyPermutation(const Permutation &permutation)
+{
+    Ciphertext copy(*this);
+    copy.applyPermutation_inplace(permutation);
+    return copy;
+}
+
+} // namespace certFHE

@@ -1,0 +1,46 @@
+// runtime.h -- private glue between the certFHE:: classes and the C ABI (csgn_hip.h).
+// Not installed; user code only sees include/certfhe/.
+#pragma once
+
+#include <stdint.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "csgn_hip.h"
+
+namespace certFHE {
+namespace detail {
+
+// A block of HBM owned through csgn_malloc/csgn_free.  Published payloads are immutable:
+// operators allocate a new one, copies share it.
+struct DevicePayload {
+    void *ptr;
+    uint64_t words;
+    DevicePayload() : ptr(nullptr), words(0) {}
+    ~DevicePayload();
+    DevicePayload(const DevicePayload &) = delete;
+    DevicePayload &operator=(const DevicePayload &) = delete;
+    uint64_t *data() const { return static_cast<uint64_t *>(ptr); }
+};
+
+// Throws std::runtime_error carrying csgn_last_error() when rc != CSGN_OK.
+void check(int rc, const char *what);
+
+// Brings up the GPU for the calling thread on first use (device: Library::useDevice,
+// else $CSGN_DEVICE, else 0).  Throws when no gfx950 device is usable -- no CPU fallback.
+void ensureDevice();
+void selectDevice(int device);
+int activeDevice();
+
+std::shared_ptr<DevicePayload> allocBytes(size_t bytes);
+std::shared_ptr<DevicePayload> allocWords(uint64_t words);
+std::shared_ptr<DevicePayload> uploadWords(const uint64_t *host, uint64_t words);
+void downloadBytes(void *host, const void *dev, size_t bytes);
+void syncDevice();
+
+inline void *stream() { return nullptr; }   // the classes run on the default stream
+
+} // namespace detail
+} // namespace certFHE

@@ -1,0 +1,85 @@
+// certfhe/Ciphertext.h -- term-list ciphertext whose payload lives in MI355X HBM.
+//
+// Same public interface as /root/reference/src/Ciphertext.h:65-143, so user code compiles
+// unchanged.  What differs is where the data is:
+//   - the T*dL term words sit in device memory behind a reference-counted, immutable
+//     payload; copies share it, every operator produces a fresh payload through
+//     libcsgn_hip (csgn_mul_uniform / csgn_add_uniform / csgn_permute_uniform);
+//   - getValues() / getBitlen() return BORROWED host mirrors that are filled on demand
+//     and stay valid until the next mutating call on the object ("DO NOT DELETE", as in
+//     the reference).  Writing through them does not change the ciphertext;
+//   - the bitlen side-array is implied by (N, T) and only materialised when asked for;
+//     a ciphertext constructed with some other Bitlen keeps it on the host and follows
+//     the reference's propagation rules (left operand's term under *, concatenation
+//     under +), but cannot be decrypted or permuted on the device.
+#ifndef CERTFHE_CIPHERTEXT_H
+#define CERTFHE_CIPHERTEXT_H
+
+#include <memory>
+
+#include "Context.h"
+#include "Permutation.h"
+#include "utils.h"
+
+using namespace std;
+
+namespace certFHE {
+
+namespace detail {
+struct DevicePayload;   // device buffer + word count (csgn_amd/csrc/certfhe/runtime.h)
+}
+
+class SecretKey;
+
+class Ciphertext {
+    std::shared_ptr<detail::DevicePayload> payload; // immutable once published
+    uint64_t len;                                   // words (T * dL)
+    Context *certFHEcontext;                        // owned copy, may be null (default ctor)
+
+    mutable uint64_t *host_v;          // lazy mirror for getValues()
+    mutable uint64_t *host_bitlen;     // lazy canonical pattern, or the custom one
+    bool custom_bitlen;                // true: host_bitlen is authoritative
+
+    void dropMirrors();
+    void publish(const std::shared_ptr<detail::DevicePayload> &p, uint64_t words);
+    void combineBitlen(const Ciphertext &lhs, const Ciphertext &rhs, bool product);
+    static Ciphertext combine(const Ciphertext &a, const Ciphertext &b, bool product);
+
+    friend class SecretKey;
+
+  public:
+    Ciphertext();
+    Ciphertext(const uint64_t *V, const uint64_t *Bitlen, const uint64_t len, const Context &context);
+    Ciphertext(const Ciphertext &ctxt);
+    virtual ~Ciphertext();
+
+    void setValues(const uint64_t *V, const uint64_t length);
+    void setBitlen(const uint64_t *Bitlen, const uint64_t length);
+    void setContext(const Context &context);
+    uint64_t getLen() const;
+    Context getContext() const;
+    uint64_t *getValues() const;   // borrowed host mirror
+    uint64_t *getBitlen() const;   // borrowed
+
+    friend ostream &operator<<(ostream &out, const Ciphertext &c);
+
+    Ciphertext operator+(const Ciphertext &c) const;
+    Ciphertext &operator+=(const Ciphertext &c);
+    Ciphertext operator*(const Ciphertext &c) const;
+    Ciphertext &operator*=(const Ciphertext &c);
+    Ciphertext &operator=(const Ciphertext &c);
+
+    void applyPermutation_inplace(const Permutation &permutation);
+    Ciphertext applyPermutation(const Permutation &permutation);
+
+    long size();
+
+    // --- extensions (not in the reference) ---
+    uint64_t getTerms() const;               // len / dL
+    const uint64_t *deviceValues() const;    // HBM pointer, valid while this object is unchanged
+    bool hasCanonicalBitlen() const;
+};
+
+} // namespace certFHE
+
+#endif

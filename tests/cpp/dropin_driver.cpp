@@ -1,0 +1,379 @@
+// dropin_driver.cpp -- exercises the drop-in certFHE:: C++ API (include/certfhe/, libcertFHE.so)
+// the way user code of the reference does.  pytest (tests/test_dropin_cpp.py) builds it, runs
+// the sub-commands and compares the printed words with the oracle / the golden vectors.
+//
+//   dropin_driver basic [rounds]          tests/basic_operations.cpp flow, asserted
+//   dropin_driver permutations [rounds]   tests/permutations.cpp flow, asserted
+//   dropin_driver timings                 tests/timings.cpp flow (sizes asserted, times printed)
+//   dropin_driver encrypt N D seed nbits b0 b1 .. key0 key1 ..   deterministic fresh ciphertexts
+//   dropin_driver circuit N D seed        deterministic add/mul chain, prints every stage
+//   dropin_driver bitlen                  non-canonical Bitlen propagation (left-operand rule)
+//   dropin_driver api                     copy/assign/in-place operator semantics, printing
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+#include "certFHE.h"
+
+using namespace certFHE;
+
+#define EXPECT(cond)                                                                  \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            fprintf(stderr, "EXPECT failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+            exit(2);                                                                  \
+        }                                                                             \
+    } while (0)
+
+static void dump(const char *label, const Ciphertext &c)
+{
+    printf("%s len=%llu v=", label, (unsigned long long)c.getLen());
+    uint64_t *v = c.getValues();
+    for (uint64_t i = 0; i < c.getLen(); ++i)
+        printf("%016llx", (unsigned long long)v[i]);
+    printf("\n");
+}
+
+static int cmd_basic(int rounds)
+{
+    Library::initializeLibrary();
+    for (int r = 0; r < rounds; ++r) {
+        Context context(1247, 16);
+        SecretKey seckey(context);
+        Plaintext p1(1), p0(0);
+        Ciphertext c1 = seckey.encrypt(p1);
+        Ciphertext c0 = seckey.encrypt(p0);
+        Ciphertext added, multiplied;          // default-constructed, then assigned
+        added = c1 + c0;
+        multiplied = c1 * c0;
+        EXPECT(added.getLen() == 40 && multiplied.getLen() == 20);
+        Plaintext da = seckey.decrypt(added), dm = seckey.decrypt(multiplied);
+        EXPECT(da.getValue() == 1);
+        EXPECT(dm.getValue() == 0);
+        // the assigned objects stay usable as operands (the reference segfaults here)
+        Ciphertext again = added * multiplied;
+        EXPECT(again.getLen() == 40);
+        EXPECT(seckey.decrypt(again).getValue() == 0);
+        Ciphertext one_one = c1 * c1;
+        EXPECT(seckey.decrypt(one_one).getValue() == 1);
+        Ciphertext xor11 = c1 + c1;
+        EXPECT(seckey.decrypt(xor11).getValue() == 0);
+    }
+    std::cout << "Dec ( Enc (1) + Enc (0) ) = " << Plaintext(1);
+    std::cout << "Dec ( Enc (1) * Enc (0) ) = " << Plaintext(0);
+    printf("basic ok rounds=%d\n", rounds);
+    return 0;
+}
+
+static int cmd_permutations(int rounds)
+{
+    Library::initializeLibrary();
+    for (int r = 0; r < rounds; ++r) {
+        Context context(1247, 16);
+        SecretKey seckey(context);
+        for (int bit = 0; bit < 2; ++bit) {
+            Plaintext p(bit);
+            Ciphertext c = seckey.encrypt(p);
+            Permutation permutation(context);
+            SecretKey permutedKey = seckey.applyPermutation(permutation);
+            Ciphertext permuted = c.applyPermutation(permutation);
+            EXPECT(permuted.getLen() == 20);
+            EXPECT(permutedKey.decrypt(permuted).getValue() == bit);
+            Permutation inverse = permutation.getInverse();
+            Permutation identity;
+            identity = permutation + inverse;
+            EXPECT(identity.getLength() == 1247);
+            for (uint64_t i = 0; i < 1247; ++i)
+                EXPECT(identity.getPermutation()[i] == i);
+            // undoing the permutation brings ciphertext and key back
+            Ciphertext back = permuted.applyPermutation(inverse);
+            uint64_t *a = back.getValues(), *b = c.getValues();
+            for (int i = 0; i < 20; ++i)
+                EXPECT(a[i] == b[i]);
+            // multi-term input collapses to the permuted first term, as in the reference
+            Ciphertext two = c + c;
+            Ciphertext two_p = two.applyPermutation(permutation);
+            EXPECT(two_p.getLen() == 20);
+            uint64_t *x = two_p.getValues(), *y = permuted.getValues();
+            for (int i = 0; i < 20; ++i)
+                EXPECT(x[i] == y[i]);
+            Permutation shorter(10);
+            EXPECT((permutation + shorter).getLength() == 0);
+        }
+    }
+    printf("permutations ok rounds=%d\n", rounds);
+    return 0;
+}
+
+static int cmd_timings()
+{
+    Library::initializeLibrary();
+    Context context(1247, 16);
+    std::cout << context;
+    Timer t1("Key generation ");
+    t1.start();
+    SecretKey seckey(context);
+    t1.stopAndPrint();
+    Plaintext p1(1);
+    Timer t2("Encryption ");
+    t2.start();
+    Ciphertext c1 = seckey.encrypt(p1);
+    t2.stopAndPrint();
+    Ciphertext added, multiplicated;
+    Timer t3("Addition of fresh ciphertexts");
+    t3.start();
+    added = c1 + c1;
+    t3.stopAndPrint();
+    Timer t4("Multiplication of fresh ciphertexts");
+    t4.start();
+    multiplicated = c1 * c1;
+    t4.stopAndPrint();
+    Timer t5("Permutation generation ");
+    t5.start();
+    Permutation permutation(context);
+    t5.stopAndPrint();
+    Timer t6("Permuting the secret key ");
+    t6.start();
+    SecretKey permutedSecretKey = seckey.applyPermutation(permutation);
+    t6.stopAndPrint();
+    Timer t7("Permuting the ciphertext ");
+    t7.start();
+    Ciphertext permutedCiphertext = c1.applyPermutation(permutation);
+    t7.stopAndPrint();
+    Timer t8("Decryption ");
+    t8.start();
+    Plaintext decrypted = permutedSecretKey.decrypt(permutedCiphertext);
+    t8.stopAndPrint();
+    EXPECT(decrypted.getValue() == 1);
+    // the sizes the reference prints (tests/timings.cpp:69-72): 144 / 352 / 352 / 672 bytes
+    printf("sizes %ld %ld %ld %ld\n", seckey.size(), c1.size(), multiplicated.size(), added.size());
+    EXPECT(seckey.size() == 144 && c1.size() == 352 && multiplicated.size() == 352 && added.size() == 672);
+    return 0;
+}
+
+static int cmd_encrypt(int argc, char **argv)
+{
+    // encrypt N D seed nbits b.. key..
+    if (argc < 6)
+        return 64;
+    uint64_t n = strtoull(argv[2], 0, 10), d = strtoull(argv[3], 0, 10);
+    unsigned seed = (unsigned)strtoul(argv[4], 0, 10);
+    int nbits = atoi(argv[5]);
+    if (argc != 6 + nbits + (int)d)
+        return 64;
+    std::vector<uint64_t> key(d);
+    for (uint64_t i = 0; i < d; ++i)
+        key[i] = strtoull(argv[6 + nbits + i], 0, 10);
+    Context ctx(n, d);
+    SecretKey sk(ctx);
+    sk.setKey(key.data(), d);
+    srand(seed);                                   // SURVEY 5.1 determinism recipe
+    for (int i = 0; i < nbits; ++i) {
+        Plaintext p(atoi(argv[6 + i]));
+        Ciphertext c = sk.encrypt(p);
+        dump("ct", c);
+        printf("dec %d\n", (int)sk.decrypt(c).getValue());
+        uint64_t *bl = c.getBitlen();
+        printf("bitlen");
+        for (uint64_t w = 0; w < c.getLen(); ++w)
+            printf(" %llu", (unsigned long long)bl[w]);
+        printf("\n");
+    }
+    return 0;
+}
+
+static int cmd_circuit(int argc, char **argv)
+{
+    if (argc < 5)
+        return 64;
+    uint64_t n = strtoull(argv[2], 0, 10), d = strtoull(argv[3], 0, 10);
+    unsigned seed = (unsigned)strtoul(argv[4], 0, 10);
+    Context ctx(n, d);
+    SecretKey sk(ctx);
+    std::vector<uint64_t> key(d);
+    for (uint64_t i = 0; i < d; ++i)
+        key[i] = (i * 37 + 11) % n;                 // fixed, distinct for d < n/37
+    sk.setKey(key.data(), d);
+    srand(seed);
+    int bits[12] = {1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1};
+    std::vector<Ciphertext> ct;
+    for (int i = 0; i < 12; ++i) {
+        Plaintext p(bits[i]);
+        ct.push_back(sk.encrypt(p));
+        dump("fresh", ct.back());
+    }
+    Ciphertext x = ct[0];
+    int xb = bits[0];
+    int k = 1;
+    for (int level = 1; level <= 6; ++level) {
+        if (level % 2) {
+            x += ct[k];
+            xb ^= bits[k];
+            k += 1;
+        } else {
+            Ciphertext rhs = ct[k] + ct[k + 1];
+            x *= rhs;
+            xb &= (bits[k] ^ bits[k + 1]);
+            k += 2;
+        }
+        dump("stage", x);
+        int got = sk.decrypt(x).getValue();
+        printf("stage_dec %d expect %d terms %llu\n", got, xb, (unsigned long long)x.getTerms());
+        EXPECT(got == xb);
+    }
+    return 0;
+}
+
+static int cmd_bitlen()
+{
+    // operands with made-up Bitlen arrays: the product takes the LEFT operand's per-term
+    // pattern (src/Ciphertext.cpp:165-176), the sum concatenates (:215-223)
+    Context ctx(65, 4);
+    const uint64_t dl = 2;
+    uint64_t a[3 * dl], b[2 * dl], bla[3 * dl], blb[2 * dl];
+    for (uint64_t i = 0; i < 3 * dl; ++i) {
+        a[i] = 0xF0F0F0F0F0F0F0F0ull ^ (i * 0x0123456789ABCDEFull);
+        bla[i] = 1 + i;
+    }
+    for (uint64_t i = 0; i < 2 * dl; ++i) {
+        b[i] = 0xFFFF0000FFFF0000ull ^ (i * 0x1111111111111111ull);
+        blb[i] = 40 + i;
+    }
+    Ciphertext A(a, bla, 3 * dl, ctx), B(b, blb, 2 * dl, ctx);
+    EXPECT(!A.hasCanonicalBitlen());
+    Ciphertext P = A * B, S = A + B;
+    EXPECT(P.getLen() == 12 && S.getLen() == 10);
+    uint64_t *pv = P.getValues(), *pb = P.getBitlen(), *sb = S.getBitlen(), *sv = S.getValues();
+    for (uint64_t i = 0; i < 3; ++i)
+        for (uint64_t j = 0; j < 2; ++j)
+            for (uint64_t k = 0; k < dl; ++k) {
+                EXPECT(pv[(i * 2 + j) * dl + k] == (a[i * dl + k] & b[j * dl + k]));
+                EXPECT(pb[(i * 2 + j) * dl + k] == bla[i * dl + k]);
+            }
+    for (uint64_t i = 0; i < 6; ++i)
+        EXPECT(sv[i] == a[i] && sb[i] == bla[i]);
+    for (uint64_t i = 0; i < 4; ++i)
+        EXPECT(sv[6 + i] == b[i] && sb[6 + i] == blb[i]);
+    // canonical left operand => canonical product even if the right one is custom
+    uint64_t can[2 * dl] = {64, 1, 64, 1};
+    Ciphertext C(b, can, 2 * dl, ctx);
+    EXPECT(C.hasCanonicalBitlen());
+    Ciphertext Q = C * A;
+    EXPECT(Q.hasCanonicalBitlen());
+    // decrypting a custom-Bitlen ciphertext is refused loudly, not computed on the CPU
+    SecretKey sk(ctx);
+    bool threw = false;
+    try {
+        sk.decrypt(P);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    printf("bitlen ok\n");
+    return 0;
+}
+
+static int cmd_api()
+{
+    Context ctx(1247, 16);
+    EXPECT(ctx.getN() == 1247 && ctx.getD() == 16 && ctx.getS() == 38 && ctx.getDefaultN() == 20);
+    Context c2(ctx);
+    c2.setN(4096);
+    EXPECT(c2.getDefaultN() == 64 && c2.getS() == 128);
+    std::stringstream ss;
+    ss << ctx;
+    EXPECT(ss.str() == "N= 1247\nD= 16\nS= 38\n");
+    ss.str("");
+    ss << Plaintext(3) << Plaintext(0);
+    EXPECT(ss.str() == "1\n0\n");
+    EXPECT(Plaintext(2).getValue() == 0);
+
+    SecretKey sk(ctx);
+    EXPECT(sk.getLength() == 16);
+    for (int i = 0; i < 16; ++i) {
+        EXPECT(sk.getKey()[i] < 1247);
+        for (int j = 0; j < i; ++j)
+            EXPECT(sk.getKey()[i] != sk.getKey()[j]);
+    }
+    SecretKey copy(sk), assigned(ctx);
+    assigned = sk;
+    for (int i = 0; i < 16; ++i)
+        EXPECT(copy.getKey()[i] == sk.getKey()[i] && assigned.getKey()[i] == sk.getKey()[i]);
+    ss.str("");
+    ss << sk;
+    EXPECT(!ss.str().empty() && ss.str()[ss.str().size() - 1] == '\n');
+
+    Plaintext one(1), zero(0);
+    Ciphertext a = sk.encrypt(one), b = sk.encrypt(zero);
+    Ciphertext a_copy(a);
+    a += b;                                            // a = a || b
+    EXPECT(a.getLen() == 40 && a_copy.getLen() == 20);  // the copy is unaffected
+    EXPECT(copy.decrypt(a).getValue() == 1);
+    a *= a_copy;                                       // (1^0)&1
+    EXPECT(a.getLen() == 40 && assigned.decrypt(a).getValue() == 1);
+    // borrowed host mirror: same words as a fresh download, stable until the next mutation
+    uint64_t *m1 = a.getValues();
+    uint64_t *m2 = a.getValues();
+    EXPECT(m1 == m2);
+    // setValues / 4-arg ctor round trip (the de-facto wire format)
+    Ciphertext wire(a.getValues(), a.getBitlen(), a.getLen(), a.getContext());
+    EXPECT(wire.hasCanonicalBitlen() && sk.decrypt(wire).getValue() == 1);
+    Ciphertext setter;
+    setter.setContext(ctx);
+    setter.setValues(b.getValues(), b.getLen());
+    setter.setBitlen(b.getBitlen(), b.getLen());
+    EXPECT(sk.decrypt(setter).getValue() == 0);
+    // operator<< prints N bits per term and a newline
+    ss.str("");
+    ss << b;
+    EXPECT(ss.str().size() == 1247 + 1);
+    ss.str("");
+    ss << (b + b);
+    EXPECT(ss.str().size() == 2 * 1247 + 1);
+    // empty ciphertext decrypts to 0; an object without a context refuses arithmetic
+    Ciphertext empty;
+    EXPECT(sk.decrypt(empty).getValue() == 0);
+    bool threw = false;
+    try {
+        Ciphertext bad = empty * a;
+    } catch (const std::logic_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    EXPECT(Helper::exists(sk.getKey(), 16, sk.getKey()[3]) && !Helper::exists(sk.getKey(), 16, 5000));
+    Helper::deletePointer(new uint64_t[4], true);
+    printf("api ok device=%d\n", Library::currentDevice());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: dropin_driver <basic|permutations|timings|encrypt|circuit|bitlen|api> ...\n");
+        return 64;
+    }
+    try {
+        std::string cmd = argv[1];
+        if (cmd == "basic")
+            return cmd_basic(argc > 2 ? atoi(argv[2]) : 20);
+        if (cmd == "permutations")
+            return cmd_permutations(argc > 2 ? atoi(argv[2]) : 5);
+        if (cmd == "timings")
+            return cmd_timings();
+        if (cmd == "encrypt")
+            return cmd_encrypt(argc, argv);
+        if (cmd == "circuit")
+            return cmd_circuit(argc, argv);
+        if (cmd == "bitlen")
+            return cmd_bitlen();
+        if (cmd == "api")
+            return cmd_api();
+        return 64;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "certFHE error: %s\n", e.what());
+        return 3;
+    }
+}
