@@ -9,7 +9,9 @@ namespace certFHE {
 
 void Library::initializeLibrary()
 {
-    // same observable effect as src/Helpers.cpp:8-12: libc's generator seeded from the clock
+    // device first (HIP start-up consumes rand() draws of its own), then the same observable
+    // effect as src/Helpers.cpp:8-12: libc's generator seeded from the clock
+    detail::ensureDevice();
     srand((unsigned)time(NULL));
 }
 

@@ -29,6 +29,9 @@ const Context &requireContext(const Context *ctx)
 
 SecretKey::SecretKey(const Context &context) : s(nullptr), length(0), certFHEContext(nullptr)
 {
+    // Bring the GPU up BEFORE touching libc's generator: HIP runtime start-up draws from
+    // rand() itself, which would otherwise disturb a caller's srand(seed) ... encrypt sequence.
+    detail::ensureDevice();
     srand((unsigned)time(NULL));               // the reference re-seeds here (src/SecretKey.cpp:311-312)
     certFHEContext = new Context(context);
     const uint64_t d = context.getD(), n = context.getN();

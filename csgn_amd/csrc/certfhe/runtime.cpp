@@ -44,6 +44,17 @@ void ensureDevice()
     }
     check(csgn_init(dev), "csgn_init");
     g_device = dev;
+    // One round trip through every kind of call the classes make.  Measured on ROCm 7.2: the
+    // first host-to-device copy of a process draws from libc's rand(); later calls do not.
+    // Doing it here keeps a caller's `srand(seed); encrypt...` sequence bit-reproducible
+    // (SecretKey's constructor and Library::initializeLibrary reach this point first).
+    void *scratch = nullptr;
+    uint64_t probe[4] = {1, 2, 3, 4};
+    check(csgn_malloc(&scratch, sizeof(probe)), "csgn_malloc");
+    check(csgn_memcpy_h2d(scratch, probe, sizeof(probe), stream()), "csgn_memcpy_h2d");
+    check(csgn_synth_fill(0, 64, 0, 4, static_cast<uint64_t *>(scratch), stream()), "csgn_synth_fill");
+    check(csgn_memcpy_d2h(probe, scratch, sizeof(probe), stream()), "csgn_memcpy_d2h");
+    check(csgn_free(scratch), "csgn_free");
 }
 
 DevicePayload::~DevicePayload()
