@@ -469,31 +469,87 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
 
 // ---------------------------------------------------------------------------------------
 // Ciphertext::applyPermutation (src/Ciphertext.cpp:7-82): new bit j = old bit perm[j],
-// MSB-first.  One lane per output word gathers its 64 bits; the source term (<= a few
-// hundred bytes) stays in L1.
+// MSB-first.  A bit permutation is a gather of single bits, so the natural wavefront form
+// is one lane per OUTPUT BIT and a __ballot per output word:
+//   lane l of the wave owns position j = 64*w + 63 - l of output word w, so the 64-bit
+//   ballot of "source bit perm[j] is set" IS output word w (ballot bit l <-> word bit l).
+// The (word, shift) of every source bit depends only on perm, so each wave decodes it once
+// into registers (64 output words per pass) and then sweeps the terms of its tile; the
+// source terms sit in LDS (coalesced staging), the gather is one ds_read_b64 per lane.
+// The reference's O(N) byte-per-bit scratch arrays (src/Ciphertext.cpp:20-34) disappear.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, u64 out_terms, u64 in_stride_words,
-                                                 u64 terms_in, const u64 *__restrict__ terms,
+// NW = output words decoded per pass (a compile-time count so the per-word tables stay in
+// registers).  Per term and word the lane work is: one ds_read_b32 of the 32-bit half that
+// holds its source bit, one AND with its bit mask, the compare that forms the ballot, and
+// two v_writelane that drop the ballot into lane w -- all reads of a term are issued
+// before the first ballot so LDS latency overlaps.
+// v_writelane_b32: drop a wave-uniform 64-bit value into ONE lane of a VGPR pair (hipcc 7.2
+// exposes no builtin for it).  `lane` must be a compile-time constant.  The s_nop is the
+// gfx940+ "VALU writes SGPR -> VALU reads that SGPR" hazard (2 wait states): the ballot is
+// produced by a v_cmp immediately before, and hipcc pads nothing inside an asm statement
+// (observed: without it the low word of some lanes read a stale SGPR).
+__device__ inline void write_lane64(u64 uniform_value, int lane, u32 &lo, u32 &hi)
+{
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                 : "+v"(lo), "+v"(hi)
+                 : "s"((u32)uniform_value), "s"((u32)(uniform_value >> 32)), "n"(lane));
+}
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, FastDiv ddL, u64 out_terms,
+                                                 u64 in_stride_words, u32 have_input, u32 TB,
+                                                 const u64 *__restrict__ terms,
                                                  const u32 *__restrict__ perm, u64 *__restrict__ out)
 {
-    const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (gid >= out_terms * dL)
-        return;
-    const u64 ct = gid / dL;
-    const u32 k = (u32)(gid - ct * dL);
-    u64 acc = 0;
-    if (terms_in != 0) {
-        const u64 *src = terms + ct * in_stride_words;
-        for (u32 s = 0; s < 64u; ++s) {
-            const u64 j = (u64)k * 64u + s;
-            if (j < n_bits) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u64 *tile = reinterpret_cast<u64 *>(smem_raw);          // TB terms x dL words
+
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const u64 t0 = (u64)blockIdx.x * TB;
+    const u32 nt = (u32)min((u64)TB, out_terms - t0);
+
+    for (u32 u = tid; u < nt * dL; u += 256u) {
+        const u32 t = csgn_fastdiv(u, ddL);
+        const u32 k = u - t * dL;
+        tile[u] = have_input ? terms[(t0 + t) * in_stride_words + k] : 0ull;
+    }
+    __syncthreads();
+
+    for (u32 c0 = 0; c0 < dL; c0 += NW) {
+        const u32 nw = min((u32)NW, dL - c0);
+        // this lane's source for each of the NW output words: byte offset of the 32-bit half
+        // inside a term, and the bit inside that half (mask 0 = "no source": yields 0)
+        u32 off[NW], msk[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            off[w] = 0;
+            msk[w] = 0;
+            const u64 j = (u64)(c0 + w) * 64u + (63u - lane);
+            if ((u32)w < nw && j < n_bits) {
                 const u32 p = perm[j];
-                if (p < n_bits)
-                    acc |= ((src[p >> 6] >> (63u - (p & 63u))) & 1ull) << (63u - s);
+                if (p < n_bits) {
+                    const u32 b = 63u - (p & 63u);          // bit index in the uint64, LSB = 0
+                    off[w] = (p >> 6) * 8u + ((b >> 5) << 2);
+                    msk[w] = 1u << (b & 31u);
+                }
             }
         }
+        for (u32 t = wave; t < nt; t += 4u) {
+            const unsigned char *src = smem_raw + (size_t)t * dL * 8u;
+            u32 v[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                v[w] = *reinterpret_cast<const u32 *>(src + off[w]);
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const u64 b = __ballot((v[w] & msk[w]) != 0u);
+                write_lane64(b, w, lo, hi);
+            }
+            if (lane < nw)
+                out[(t0 + t) * dL + c0 + lane] = ((u64)hi << 32) | (u64)lo;
+        }
     }
-    out[gid] = acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -886,10 +942,32 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     if (out_terms == 0)
         return hipSuccess;
     const u64 stride = per_term ? dL : terms_in * dL;
-    const u64 blocks64 = (out_terms * dL + 255) / 256;
+    // terms per workgroup: a multiple of the 4 waves, LDS image <= 32 KB
+    u32 tb = 64;
+    while (tb > 4 && (u64)tb * dL * 8 > 32768)
+        tb /= 2;
+    const u64 blocks64 = (out_terms + tb - 1) / tb;
     if (blocks64 > (1ull << 31) - 1)
         return hipErrorInvalidValue;
-    k_permute<<<(u32)blocks64, 256, 0, s>>>(n_bits, (u32)dL, out_terms, stride, terms_in, terms, perm, out);
+    const FastDiv ddL = csgn_fastdiv_make((u32)dL);
+    const u32 have = terms_in != 0 ? 1u : 0u;
+    const size_t lds = (size_t)tb * dL * 8;
+#define CSGN_PERMUTE_LAUNCH(NW)                                                                     \
+    k_permute<NW><<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, ddL, out_terms, stride, have, tb, \
+                                                  terms, perm, out)
+    if (dL <= 4)
+        CSGN_PERMUTE_LAUNCH(4);
+    else if (dL <= 8)
+        CSGN_PERMUTE_LAUNCH(8);
+    else if (dL <= 16)
+        CSGN_PERMUTE_LAUNCH(16);
+    else if (dL <= 20)
+        CSGN_PERMUTE_LAUNCH(20);
+    else if (dL <= 32 || dL % 32 == 0 && dL % 64 != 0)
+        CSGN_PERMUTE_LAUNCH(32);
+    else
+        CSGN_PERMUTE_LAUNCH(64);
+#undef CSGN_PERMUTE_LAUNCH
     return hipGetLastError();
 }
 

@@ -481,3 +481,22 @@ def test_circuit_config5_style(hip, oracle):
             k += 2
         assert np.array_equal(hip.download(x), host_x)
         assert hip.download(hip.decrypt_uniform(n, 1, xt, x, dpmask))[0] == xb == oracle.decrypt_canonical(n, pkey, host_x)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 1247, 2048, 2100, 4032, 4096, 8192, 10000])
+def test_permute_all_word_counts(hip, oracle, n):
+    """Every instantiation of the ballot bit-gather (4..64 words per pass, multi-pass above 64)."""
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n)
+    perm = rng.permutation(n).astype(np.uint64)
+    nb = 9
+    w = oracle.synth(5, n, 0, nb * dl)
+    dperm = hip.upload(perm.astype(np.uint32))
+    out = hip.download(hip.permute_uniform(n, nb, 1, hip.upload(w), dperm))
+    for i in range(nb):
+        assert np.array_equal(out[i * dl:(i + 1) * dl], oracle.permute_ciphertext(n, perm, w[i * dl:(i + 1) * dl])), (n, i)
+    # 3-term inputs: first-term truncation vs per-term extension
+    first = hip.download(hip.permute_uniform(n, 3, 3, hip.upload(w), dperm))
+    for i in range(3):
+        assert np.array_equal(first[i * dl:(i + 1) * dl], out[3 * i * dl:(3 * i + 1) * dl])
+    assert np.array_equal(hip.download(hip.permute_uniform(n, 3, 3, hip.upload(w), dperm, per_term=True)), out)
