@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise RCCL and run the term-count all-gather even with one rank "
+                         "(exercises the N>1 code path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -114,7 +117,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
     if args.gpus != world and rank == 0:
@@ -141,20 +150,20 @@ def main():
     right = hip.synth_fill(SEED + 2, N_BITS, lo * words_per_operand, batch * words_per_operand)
     arena = hip.empty_words(slots * words_per_product)
     counts = torch.full((batch,), T * T, dtype=torch.int64, device=dev)   # result term counts
-    gathered = torch.empty((total_pairs,), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.empty((total_pairs,), dtype=torch.int64, device=dev) if use_dist else None
     torch.cuda.synchronize()
 
     def step():
         hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
-        if world > 1:
-            gather_term_counts(counts, total_pairs, out=gathered)
+        if use_dist:
+            gather_term_counts(counts, total_pairs, out=gathered, force=True)
 
     for _ in range(args.warmup):
         step()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -162,15 +171,15 @@ def main():
         ev[k][0].record()
         hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
         ev[k][1].record()
-        if world > 1:
-            gather_term_counts(counts, total_pairs, out=gathered)
+        if use_dist:
+            gather_term_counts(counts, total_pairs, out=gathered, force=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -196,7 +205,7 @@ def main():
             want, _ = orc.mul(N_BITS, a, b)
             got = hip.digest(arena[slot * words_per_product:(slot + 1) * words_per_product])
             ok = ok and (got == orc.digest(want))
-        if world > 1:
+        if use_dist:
             ok = ok and bool((gathered == T * T).all().item()) and gathered.numel() == world * batch
         verified = bool(ok)
         if not ok:
@@ -225,7 +234,7 @@ def main():
                 "n_bits": N_BITS, "terms": T, "batch_per_gpu": batch, "arena_slots": slots,
                 "pairs_per_launch": pairs_per_launch, "seed": SEED,
                 "bytes_per_mult": bytes_per_mul,
-                "collective": "all_gather(result term counts)" if world > 1 else "none",
+                "collective": "all_gather(result term counts)" if use_dist else "none",
                 "verified_vs_oracle": verified,
             },
             "roofline": {
@@ -246,7 +255,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_seconds)
         print(json.dumps(out))
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

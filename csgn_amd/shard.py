@@ -29,11 +29,11 @@ def owner_of(pair: int, total_pairs: int, world: int) -> int:
 
 def gather_term_counts(local_counts: torch.Tensor, total_pairs: int,
                        group: Optional[dist.ProcessGroup] = None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, force: bool = False) -> torch.Tensor:
     """All-gather the per-pair result term counts of every rank into one tensor of
     `total_pairs` int64, in global pair order.  Equal shards use one
     all_gather_into_tensor; uneven shards are padded to the largest shard first."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local_counts
     world = dist.get_world_size(group)
     sizes = [shard_range(total_pairs, r, world) for r in range(world)]
