@@ -126,7 +126,7 @@ class HipPath:
     def decrypt_uniform(self, n_bits: int, batch: int, terms: int, words: torch.Tensor,
                         mask: torch.Tensor) -> torch.Tensor:
         bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
-        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(batch * terms)),
+        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(batch, batch * terms)),
                               dtype=torch.uint8, device=self.device)
         check(self.lib.csgn_decrypt_uniform(n_bits, batch, terms, _ptr(words), _ptr(mask), _ptr(bits),
                                             _ptr(scratch), self.stream))
@@ -138,7 +138,7 @@ class HipPath:
         if total_terms is None:
             total_terms = int(self.download(off[-1:])[0])
         bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
-        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(total_terms)),
+        scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(batch, total_terms)),
                               dtype=torch.uint8, device=self.device)
         check(self.lib.csgn_decrypt_ragged(n_bits, batch, total_terms, _ptr(words), _ptr(off),
                                            _ptr(mask), _ptr(bits), _ptr(scratch), self.stream))

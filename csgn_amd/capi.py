@@ -53,7 +53,7 @@ SIGNATURES = {
     "csgn_mul_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, u64, vp]),
     "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
     "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
-    "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64]),
+    "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64, u64]),
     "csgn_decrypt_uniform": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp]),
     "csgn_decrypt_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_explicit": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp, vp]),

@@ -209,7 +209,7 @@ Plaintext SecretKey::decrypt(Ciphertext &ciphertext)
     if (terms == 0)
         return Plaintext(0);                   // empty term list XORs to 0
     ensureMask();
-    const size_t scratch = csgn_decrypt_scratch_bytes(terms);
+    const size_t scratch = (csgn_decrypt_scratch_bytes(1, terms) + 7) & ~(size_t)7;
     std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch + 8);
     unsigned char *d_bit = static_cast<unsigned char *>(work->ptr) + scratch;
     detail::check(csgn_decrypt_uniform(n, 1, terms, ciphertext.deviceValues(), device_mask->data(),

@@ -354,9 +354,9 @@ int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
     return CSGN_OK;
 }
 
-size_t csgn_decrypt_scratch_bytes(uint64_t total_terms)
+size_t csgn_decrypt_scratch_bytes(uint64_t batch, uint64_t total_terms)
 {
-    return csgn::decrypt_scratch_bytes(total_terms);
+    return csgn::decrypt_scratch_bytes(batch, total_terms);
 }
 
 int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,

@@ -40,6 +40,6 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
 hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 
-size_t decrypt_scratch_bytes(u64 total_terms);
+size_t decrypt_scratch_bytes(u64 batch, u64 total_terms);
 
 } // namespace csgn

@@ -41,31 +41,17 @@ inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 // Replaces Ciphertext::defaultN_multiply (src/Ciphertext.cpp:124-131) for a whole batch of
 // fresh ciphertext pairs (BASELINE configs 2 and 4): 3 x 16 B of HBM traffic per unit.
 // ---------------------------------------------------------------------------------------
-template <typename Unit>
+// One 16-byte unit per lane and one 4 KiB segment per short-lived workgroup: measured
+// (tools/rbench.hip) this beats every deeper-unrolled or grid-stride form on MI355X because the
+// chip-wide access front stays dense in address space (6.1 vs 5.3 TB/s).
+template <typename Unit, bool NT>
 __global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
                                                     const Unit *__restrict__ b,
                                                     Unit *__restrict__ o, u64 n_units)
 {
-    constexpr u32 kPer = 4;
-    u64 base = (u64)blockIdx.x * (256u * kPer) + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * (256u * kPer);
-    for (; base < n_units; base += stride) {
-        Unit x[kPer], y[kPer];
-#pragma unroll
-        for (u32 j = 0; j < kPer; ++j) {
-            u64 i = base + (u64)j * 256u;
-            if (i < n_units) {
-                x[j] = a[i];
-                y[j] = b[i];
-            }
-        }
-#pragma unroll
-        for (u32 j = 0; j < kPer; ++j) {
-            u64 i = base + (u64)j * 256u;
-            if (i < n_units)
-                o[i] = x[j] & y[j];
-        }
-    }
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n_units)
+        unit_store<Unit, NT>(o + i, a[i] & b[i]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -76,26 +62,21 @@ __global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
 template <typename Unit, int MF>
 __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
-                                                  Unit *__restrict__ out, u64 total_units, u32 t1,
+                                                  Unit *__restrict__ out, u32 total_units, u32 t1,
                                                   u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU)
 {
+    // one launch covers < 2^32 output units, so every index below is 32-bit
     const u32 CU = t2 * U, LU = t1 * U, PU = t1 * CU;
-    const u64 g0 = (u64)blockIdx.x * (256u * MF);
-    const u64 pair0 = g0 / PU;
-    const u32 r0 = (u32)(g0 - pair0 * PU);
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-        const u32 local = (u32)m * 256u + threadIdx.x;
-        const u64 g = g0 + local;
+        const u32 g = blockIdx.x * (256u * MF) + (u32)m * 256u + threadIdx.x;
         if (g < total_units) {
-            u32 r = r0 + local;
-            const u32 dp = csgn_fastdiv(r, dPU);
-            r -= dp * PU;
-            const u64 pair = pair0 + dp;
+            const u32 pair = csgn_fastdiv(g, dPU);
+            const u32 r = g - pair * PU;
             const u32 i = csgn_fastdiv(r, dCU);
             const u32 c = r - i * CU;
             const u32 k = c - csgn_fastdiv(c, dU) * U;
-            out[g] = L[pair * LU + (u64)i * U + k] & R[pair * CU + c];
+            out[g] = L[(u64)pair * LU + i * U + k] & R[(u64)pair * CU + c];
         }
     }
 }
@@ -250,27 +231,20 @@ __global__ void __launch_bounds__(1024) k_mul_plan(u64 batch, const u64 *__restr
 // ---------------------------------------------------------------------------------------
 // add = concatenation (src/Ciphertext.cpp:107-122).  Flat map over output units.
 // ---------------------------------------------------------------------------------------
-template <typename Unit, int MF>
+template <typename Unit, bool NT>
 __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
-                                                  Unit *__restrict__ out, u64 total_units, u32 LU,
+                                                  Unit *__restrict__ out, u32 total_units, u32 LU,
                                                   u32 RU, FastDiv dOU)
 {
+    // one unit per lane, < 2^32 units per launch (see k_and_stream for why)
     const u32 OU = LU + RU;
-    const u64 g0 = (u64)blockIdx.x * (256u * MF);
-    const u64 pair0 = g0 / OU;
-    const u32 r0 = (u32)(g0 - pair0 * OU);
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const u32 local = (u32)m * 256u + threadIdx.x;
-        const u64 g = g0 + local;
-        if (g < total_units) {
-            u32 r = r0 + local;
-            const u32 dp = csgn_fastdiv(r, dOU);
-            r -= dp * OU;
-            const u64 pair = pair0 + dp;
-            out[g] = (r < LU) ? L[pair * LU + r] : R[pair * RU + (r - LU)];
-        }
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g < total_units) {
+        const u32 pair = csgn_fastdiv(g, dOU);
+        const u32 r = g - pair * OU;
+        const Unit v = (r < LU) ? L[(u64)pair * LU + r] : R[(u64)pair * RU + (r - LU)];
+        unit_store<Unit, NT>(out + g, v);
     }
 }
 
@@ -347,6 +321,73 @@ __global__ void __launch_bounds__(256) k_term_hits(const Unit *__restrict__ term
         hits[(u64)blockIdx.x * 4u + (tid >> 6)] = b;
 }
 
+// decrypt, pass 1, fast form.  A 256-thread workgroup makes K passes over K consecutive
+// 4 KiB segments (K*256 units = TB whole terms, TB a multiple of 8), all K loads of a lane in
+// flight at once.  Every wave ballots "my unit covers the mask" per pass; the K*4 ballots form
+// a bit string in LDS in which term t owns bits [t*U, t*U+U); lane t < TB tests them and the
+// TB verdicts leave as TB/8 bytes of the hit bitmap.  Segments stay 4 KiB-aligned whatever U
+// is (320-thread / 5 KiB workgroups measured 15 % slower at N=1247), and workgroups stay
+// short-lived and in address order (see k_and_stream).
+template <typename Unit, int K>
+__global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ terms,
+                                                       const Unit *__restrict__ mask,
+                                                       u64 total_units, u32 U, FastDiv dU, u32 TB,
+                                                       unsigned char *__restrict__ hits)
+{
+    __shared__ u64 ok_bits[K * 4 + 1];
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const u64 g0 = (u64)blockIdx.x * (256u * K) + tid;
+
+    // Loads are unconditional (addresses clamped into range) so that all K of them, and the K
+    // mask units, are in flight together: a load under a divergent `if` makes hipcc wait
+    // vmcnt(0) right behind it.
+    Unit x[K], mk[K];
+    const u64 last = total_units - 1;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u64 g = g0 + (u32)j * 256u;
+        x[j] = terms[g < last ? g : last];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u32 local = (u32)j * 256u + tid;
+        mk[j] = mask[local - csgn_fastdiv(local, dU) * U];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool ok = (g0 + (u32)j * 256u <= last) && unit_covers(x[j], mk[j]);
+        const u64 b = __ballot(ok);
+        if (lane == 0)
+            ok_bits[j * 4 + wave] = b;
+    }
+    if (tid == 0)
+        ok_bits[K * 4] = 0;                       // pad word for the straddling shift below
+    __syncthreads();
+
+    const u64 need = (U >= 64u) ? ~0ull : ((1ull << U) - 1ull);
+    for (u32 t = tid; t < TB; t += 256u) {        // TB <= 256 unless U == 1 (TB = 256*K)
+        const u32 start = t * U, w = start >> 6, sh = start & 63u;
+        u64 v = ok_bits[w] >> sh;
+        if (sh)
+            v |= ok_bits[w + 1] << (64u - sh);
+        const bool hit = (v & need) == need;
+        const u64 hb = __ballot(hit);             // lanes past TB are not in this iteration
+        if (lane == 0) {
+            const u32 first = t;                  // first term of this wave's group
+            const u32 nbits = min(64u, TB - first);
+            unsigned char *dst = hits + (u64)blockIdx.x * (TB >> 3) + (first >> 3);
+            if (nbits == 64u)
+                *reinterpret_cast<u64 *>(dst) = hb;
+            else if (nbits == 32u)
+                *reinterpret_cast<u32 *>(dst) = (u32)hb;
+            else if (nbits == 16u)
+                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)hb;
+            else
+                *dst = (unsigned char)hb;
+        }
+    }
+}
+
 // decrypt, pass 2: XOR over the terms of each ciphertext = parity of the popcount of its
 // bit range (src/SecretKey.cpp:139, `_dec = (dec + _dec) % 2`).  G lanes per ciphertext:
 // 1 for small term counts, a whole wave (with a __ballot/__popcll fold) for large ones.
@@ -381,6 +422,49 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
         if (lane == 0)
             bits[b] = (uint8_t)(__popcll(odd) & 1);
     }
+}
+
+// decrypt, pass 2 for LONG uniform ciphertexts: a ciphertext's bit range is cut into chunks of
+// 65536 terms (1024 bitmap words); one workgroup per (ciphertext, chunk) folds its chunk with
+// __popcll / __ballot and XORs one bit into a per-ciphertext word, so a single 1M-term
+// ciphertext is reduced by 16 workgroups instead of one wave.
+__global__ void __launch_bounds__(256) k_hits_parity_chunked(const u64 *__restrict__ hits, u64 T,
+                                                             u32 chunks, u32 *__restrict__ partial)
+{
+    __shared__ u32 wave_par[4];
+    const u32 b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
+    const u64 s = (u64)b * T, e = s + T;
+    const u64 cs = s + (u64)c * 65536u;
+    const u64 ce = min(e, cs + 65536u);
+    u32 par = 0;
+    if (ce > cs) {
+        const u64 w0 = cs >> 6, w1 = (ce - 1) >> 6;
+        for (u64 w = w0 + threadIdx.x; w <= w1; w += 256u) {
+            u64 x = hits[w];
+            if (w == w0)
+                x &= ~0ull << (cs & 63);
+            if (w == w1 && (ce & 63))
+                x &= (1ull << (ce & 63)) - 1;
+            par ^= (u32)__popcll(x);
+        }
+    }
+    const u64 odd = __ballot(par & 1u);
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        wave_par[threadIdx.x >> 6] = (u32)__popcll(odd) & 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 p = wave_par[0] ^ wave_par[1] ^ wave_par[2] ^ wave_par[3];
+        if (p)
+            atomicXor(partial + b, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_partial_to_bits(const u32 *__restrict__ partial, u64 batch,
+                                                         uint8_t *__restrict__ bits)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < batch)
+        bits[i] = (uint8_t)(partial[i] & 1u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -694,22 +778,27 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
     const u64 total = pairs * PU;
     if (total == 0)
         return hipSuccess;
-    if (t1 == 1 && t2 == 1) {
-        const u64 want = (total + 1023) / 1024;
-        const u32 blocks = (u32)(want < 65536 ? want : 65536);
-        k_and_stream<Unit><<<blocks, 256, 0, s>>>(Lu, Ru, Ou, total);
-        return hipGetLastError();
-    }
     const MulTuning tune = mul_tuning();
+    if (t1 == 1 && t2 == 1) {
+        // at most 2^31-1 workgroups of 256 units per launch
+        const u64 per_launch = ((1ull << 31) - 1) * 256u;
+        for (u64 u0 = 0; u0 < total; u0 += per_launch) {
+            const u64 nu = (total - u0 < per_launch) ? total - u0 : per_launch;
+            k_and_stream<Unit, true><<<ceil_div_u64(nu, 256u), 256, 0, s>>>(Lu + u0, Ru + u0, Ou + u0, nu);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
     if ((PU <= 8192 || tune.flat) && PU < (1ull << 31)) {
-        const int mf = tune.flat ? tune.flat : 8;
-        const u64 per_launch = (1ull << 30) * (256u * (u64)mf);
-        const u64 pairs_per = per_launch / PU ? per_launch / PU : 1;
+        const int mf = tune.flat ? tune.flat : 1;
+        const u64 pairs_per = (0xFFFFFFFFull / PU) ? (0xFFFFFFFFull / PU) : 1;   // < 2^32 units per launch
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
                       dU = csgn_fastdiv_make(U);
         for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
             const u64 np = (pairs - p0 < pairs_per) ? pairs - p0 : pairs_per;
-            const u64 tot = np * PU;
+            const u32 tot = (u32)(np * PU);
             const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
             const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
             Unit *Oc = Ou + p0 * PU;
@@ -818,24 +907,22 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
         return hipSuccess;
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
-    constexpr int MF = 8;
     const u64 OU = (t1 + t2) * U;
-    const u64 per_launch = (1ull << 30) * (256u * MF);
-    const u64 pairs_per = per_launch / OU ? per_launch / OU : 1;
+    const u64 pairs_per = (0xFFFFFFFFull / OU) ? (0xFFFFFFFFull / OU) : 1;       // < 2^32 units per launch
+    const FastDiv d = csgn_fastdiv_make((u32)OU);
     for (u64 p0 = 0; p0 < batch; p0 += pairs_per) {
         const u64 np = (batch - p0 < pairs_per) ? batch - p0 : pairs_per;
-        const u64 tot = np * OU;
-        const u32 blocks = ceil_div_u64(tot, 256u * MF);
-        const FastDiv d = csgn_fastdiv_make((u32)OU);
+        const u32 tot = (u32)(np * OU);
+        const u32 blocks = ceil_div_u64(tot, 256u);
         if (wide)
-            k_add_flat<unit16, MF><<<blocks, 256, 0, s>>>(
+            k_add_flat<unit16, true><<<blocks, 256, 0, s>>>(
                 reinterpret_cast<const unit16 *>(L) + p0 * t1 * U,
                 reinterpret_cast<const unit16 *>(R) + p0 * t2 * U,
                 reinterpret_cast<unit16 *>(out) + p0 * OU, tot, (u32)(t1 * U), (u32)(t2 * U), d);
         else
-            k_add_flat<unit8, MF><<<blocks, 256, 0, s>>>(L + p0 * t1 * U, R + p0 * t2 * U,
-                                                         out + p0 * OU, tot, (u32)(t1 * U),
-                                                         (u32)(t2 * U), d);
+            k_add_flat<unit8, true><<<blocks, 256, 0, s>>>(L + p0 * t1 * U, R + p0 * t2 * U,
+                                                           out + p0 * OU, tot, (u32)(t1 * U),
+                                                           (u32)(t2 * U), d);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
@@ -867,9 +954,15 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     return hipGetLastError();
 }
 
-size_t decrypt_scratch_bytes(u64 total_terms)
+static size_t decrypt_bitmap_bytes(u64 total_terms)
 {
-    return (size_t)((total_terms + 255) / 256) * 32u + 32u;
+    return (size_t)((total_terms + 255) / 256) * 32u + 64u;
+}
+
+size_t decrypt_scratch_bytes(u64 batch, u64 total_terms)
+{
+    // [hit bitmap, one bit per term | pad][one u32 partial parity per ciphertext]
+    return decrypt_bitmap_bytes(total_terms) + (size_t)batch * 4u + 16u;
 }
 
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
@@ -887,7 +980,43 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
             return hipErrorInvalidValue;
         const u32 blocks = (u32)blocks64;
         const FastDiv dU = csgn_fastdiv_make(U);
-        if (wide)
+        // fast form: K 4-KiB segments per workgroup holding TB whole terms (TB % 8 == 0);
+        // term sizes that need K > 8 (or U > 64) use the looping form
+        int k_seg = 0;
+        if (U <= 64u)
+            for (int k = 1; k <= 8; ++k)
+                if ((256u * k) % U == 0 && ((256u * k) / U) % 8u == 0) {
+                    k_seg = k;
+                    break;
+                }
+        if (k_seg && env_int("CSGN_DEC_LOOP", 0) == 0) {
+            const u32 tb = 256u * k_seg / U;
+            const u64 nblk = (total_terms + tb - 1) / tb;
+            if (nblk > (1ull << 31) - 1)
+                return hipErrorInvalidValue;
+            unsigned char *hb = reinterpret_cast<unsigned char *>(scratch);
+            const u64 tu = total_terms * U;
+#define CSGN_HITS_SEG(K)                                                                              \
+    do {                                                                                              \
+        if (wide)                                                                                     \
+            k_term_hits_seg<unit16, K><<<(u32)nblk, 256, 0, s>>>(                                     \
+                reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask), tu, U, \
+                dU, tb, hb);                                                                          \
+        else                                                                                          \
+            k_term_hits_seg<unit8, K><<<(u32)nblk, 256, 0, s>>>(terms, mask, tu, U, dU, tb, hb);      \
+    } while (0)
+            switch (k_seg) {
+            case 1: CSGN_HITS_SEG(1); break;
+            case 2: CSGN_HITS_SEG(2); break;
+            case 3: CSGN_HITS_SEG(3); break;
+            case 4: CSGN_HITS_SEG(4); break;
+            case 5: CSGN_HITS_SEG(5); break;
+            case 6: CSGN_HITS_SEG(6); break;
+            case 7: CSGN_HITS_SEG(7); break;
+            default: CSGN_HITS_SEG(8); break;
+            }
+#undef CSGN_HITS_SEG
+        } else if (wide)
             k_term_hits<unit16><<<blocks, 256, (size_t)U * 16 + 1024, s>>>(
                 reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask),
                 total_terms, U, dU, hits);
@@ -901,6 +1030,16 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     const u64 avg = total_terms / batch;
     if (avg <= 4096) {
         k_hits_parity<1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
+    } else if (!off && batch * ((terms_uniform + 65535) / 65536) < (1ull << 31)) {
+        // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
+        u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
+                                               decrypt_bitmap_bytes(total_terms));
+        hipError_t e = hipMemsetAsync(partial, 0, (size_t)batch * 4u, s);
+        if (e != hipSuccess)
+            return e;
+        const u32 chunks = (u32)((terms_uniform + 65535) / 65536);
+        k_hits_parity_chunked<<<(u32)(batch * chunks), 256, 0, s>>>(hits, terms_uniform, chunks, partial);
+        k_partial_to_bits<<<ceil_div_u64(batch, 256), 256, 0, s>>>(partial, batch, bits);
     } else {
         const u64 blocks64 = (batch * 64 + 255) / 256;
         if (blocks64 > (1ull << 31) - 1)

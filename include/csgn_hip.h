@@ -147,9 +147,10 @@ int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
 /* Batched SecretKey::decrypt (src/SecretKey.cpp:104-147; single term :82-102):
  *     bit_b = XOR over terms k of ( AND over key indices s of term_k[s] )
  * d_mask is the dL-word key mask (csgn_key_mask) in device memory; d_bits receives one
- * byte (0/1) per ciphertext.  d_scratch must hold csgn_decrypt_scratch_bytes(total terms)
- * bytes (one hit bit per term).  An empty ciphertext decrypts to 0, as in the reference. */
-size_t csgn_decrypt_scratch_bytes(uint64_t total_terms);
+ * byte (0/1) per ciphertext.  d_scratch must hold csgn_decrypt_scratch_bytes(batch, total
+ * terms) bytes (one hit bit per term + one partial-parity word per ciphertext).  An empty
+ * ciphertext decrypts to 0, as in the reference. */
+size_t csgn_decrypt_scratch_bytes(uint64_t batch, uint64_t total_terms);
 int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,
                          const uint64_t *d_terms, const uint64_t *d_mask,
                          uint8_t *d_bits, void *d_scratch, void *stream);

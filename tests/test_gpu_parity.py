@@ -500,3 +500,19 @@ def test_permute_all_word_counts(hip, oracle, n):
     for i in range(3):
         assert np.array_equal(first[i * dl:(i + 1) * dl], out[3 * i * dl:(3 * i + 1) * dl])
     assert np.array_equal(hip.download(hip.permute_uniform(n, 3, 3, hip.upload(w), dperm, per_term=True)), out)
+
+
+@pytest.mark.parametrize("n,d", [(8320, 8), (8250, 5), (1247, 16), (193, 6), (704, 9), (1088, 7)])
+@pytest.mark.parametrize("loop", [0, 1])
+def test_decrypt_kernel_forms(hip, oracle, monkeypatch, n, d, loop):
+    """Both pass-1 forms (one-unit-per-lane workgroups of whole terms; looping 256-term
+    workgroups for term sizes that do not pack into <=1024 lanes) on awkward term sizes."""
+    monkeypatch.setenv("CSGN_DEC_LOOP", str(loop))
+    key = make_key(n, d, 13)
+    dmask = hip.upload(hip.key_mask(n, key))
+    for terms in (1, 7, 8, 9, 63, 64, 65, 300, 1031):
+        batch = 3
+        parts = [planted(oracle, n, key, terms, (5 * b + terms) % (terms + 1), 700 + b) for b in range(batch)]
+        bits = hip.download(hip.decrypt_uniform(n, batch, terms, hip.upload(np.concatenate(parts)), dmask))
+        for b in range(batch):
+            assert bits[b] == oracle.decrypt_canonical(n, key, parts[b]) == ((5 * b + terms) % (terms + 1)) % 2
