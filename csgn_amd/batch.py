@@ -144,6 +144,17 @@ class HipPath:
                                            _ptr(mask), _ptr(bits), _ptr(scratch), self.stream))
         return bits[:batch]
 
+    def decrypt_combined_uniform(self, n_bits: int, batch: int, t1: int, t2: int, left: torch.Tensor,
+                                 right: torch.Tensor, mask: torch.Tensor, product: bool) -> torch.Tensor:
+        """Dec(L*R) (product=True) or Dec(L+R) without materialising the result."""
+        bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
+        scratch = torch.empty(int(self.lib.csgn_decrypt_combined_scratch_bytes(batch, t1, t2)),
+                              dtype=torch.uint8, device=self.device)
+        fn = self.lib.csgn_decrypt_product_uniform if product else self.lib.csgn_decrypt_sum_uniform
+        check(fn(n_bits, batch, t1, t2, _ptr(left), _ptr(right), _ptr(mask), _ptr(bits), _ptr(scratch),
+                 self.stream))
+        return bits[:batch]
+
     # -- encrypt ----------------------------------------------------------------------
     def encrypt_explicit(self, n_bits: int, d: int, plain: torch.Tensor, rnd: torch.Tensor,
                          chosen: torch.Tensor, last: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

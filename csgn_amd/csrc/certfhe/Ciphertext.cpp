@@ -283,6 +283,76 @@ Ciphertext &Ciphertext::operator*=(const Ciphertext &c)
     return *this;
 }
 
+// ------------------------------------------------------------------ wire format
+
+namespace {
+const char kWireMagic[4] = {'C', 'S', 'G', 'N'};
+
+void putU64(std::ostream &out, uint64_t v)
+{
+    unsigned char b[8];
+    for (int i = 0; i < 8; ++i)
+        b[i] = (unsigned char)(v >> (8 * i));
+    out.write(reinterpret_cast<const char *>(b), 8);
+}
+
+uint64_t getU64(std::istream &in)
+{
+    unsigned char b[8];
+    in.read(reinterpret_cast<char *>(b), 8);
+    if (!in)
+        throw std::runtime_error("certFHE::Ciphertext::deserialize: truncated stream");
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i)
+        v |= (uint64_t)b[i] << (8 * i);
+    return v;
+}
+} // namespace
+
+void Ciphertext::serialize(std::ostream &out) const
+{
+    const Context &ctx = requireContext(certFHEcontext);
+    out.write(kWireMagic, 4);
+    const unsigned char ver_flags[4] = {1, 0, (unsigned char)(custom_bitlen ? 1 : 0), 0};
+    out.write(reinterpret_cast<const char *>(ver_flags), 4);
+    putU64(out, ctx.getN());
+    putU64(out, ctx.getD());
+    putU64(out, len);
+    const uint64_t *v = getValues();
+    for (uint64_t i = 0; i < len; ++i)
+        putU64(out, v[i]);
+    if (custom_bitlen)
+        for (uint64_t i = 0; i < len; ++i)
+            putU64(out, host_bitlen[i]);
+    if (!out)
+        throw std::runtime_error("certFHE::Ciphertext::serialize: write failed");
+}
+
+Ciphertext Ciphertext::deserialize(std::istream &in)
+{
+    char magic[4];
+    unsigned char ver_flags[4];
+    in.read(magic, 4);
+    in.read(reinterpret_cast<char *>(ver_flags), 4);
+    if (!in || memcmp(magic, kWireMagic, 4) != 0)
+        throw std::runtime_error("certFHE::Ciphertext::deserialize: not a CSGN stream");
+    if (ver_flags[0] != 1 || ver_flags[1] != 0)
+        throw std::runtime_error("certFHE::Ciphertext::deserialize: unsupported version");
+    const uint64_t n = getU64(in), d = getU64(in), words = getU64(in);
+    if (n == 0 || d == 0 || words > (1ull << 40))
+        throw std::runtime_error("certFHE::Ciphertext::deserialize: implausible header");
+    std::vector<uint64_t> v(words), bl;
+    for (uint64_t i = 0; i < words; ++i)
+        v[i] = getU64(in);
+    if (ver_flags[2] & 1) {
+        bl.resize(words);
+        for (uint64_t i = 0; i < words; ++i)
+            bl[i] = getU64(in);
+    }
+    Context ctx(n, d);
+    return Ciphertext(v.data(), bl.empty() ? nullptr : bl.data(), words, ctx);
+}
+
 // ------------------------------------------------------------------ permutation
 
 void Ciphertext::applyPermutation_inplace(const Permutation &permutation)

@@ -388,6 +388,41 @@ int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
     return CSGN_OK;
 }
 
+size_t csgn_decrypt_combined_scratch_bytes(uint64_t batch, uint64_t t1, uint64_t t2)
+{
+    return csgn::decrypt_combined_scratch_bytes(batch, t1, t2);
+}
+
+int csgn_decrypt_product_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                                 const uint64_t *d_left, const uint64_t *d_right,
+                                 const uint64_t *d_mask, uint8_t *d_bits, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_mask && d_bits && d_scratch && (d_left || t1 == 0) && (d_right || t2 == 0),
+            "null device pointer");
+    HIP_TRY(csgn::decrypt_combined(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
+                                   (const u64 *)d_mask, true, d_bits, d_scratch, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                             const uint64_t *d_left, const uint64_t *d_right,
+                             const uint64_t *d_mask, uint8_t *d_bits, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_mask && d_bits && d_scratch && (d_left || t1 == 0) && (d_right || t2 == 0),
+            "null device pointer");
+    HIP_TRY(csgn::decrypt_combined(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
+                                   (const u64 *)d_mask, false, d_bits, d_scratch, S(stream)));
+    return CSGN_OK;
+}
+
 int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
                           const uint8_t *d_plain, const uint64_t *d_rnd,
                           const uint32_t *d_chosen, const uint8_t *d_last,

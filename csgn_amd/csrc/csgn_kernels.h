@@ -41,5 +41,8 @@ hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *ou
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 
 size_t decrypt_scratch_bytes(u64 batch, u64 total_terms);
+size_t decrypt_combined_scratch_bytes(u64 batch, u64 t1, u64 t2);
+hipError_t decrypt_combined(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R,
+                            const u64 *mask, bool is_product, uint8_t *bits, void *scratch, hipStream_t s);
 
 } // namespace csgn

@@ -1049,6 +1049,50 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     return hipGetLastError();
 }
 
+// dec(a*b) = dec(a) & dec(b) and dec(a+b) = dec(a) ^ dec(b): a product term L_i & R_j covers
+// the key mask iff both factors do, so the number of hitting product terms is
+// hits(L)*hits(R) and its parity the AND of the parities; concatenation adds the counts.
+// The 168 MB product of a 1024x1024 pair is therefore never materialised when only its
+// plaintext is wanted: 2 x 160 KB are read instead.
+__global__ void __launch_bounds__(256) k_combine_bits(const uint8_t *__restrict__ a,
+                                                      const uint8_t *__restrict__ b, u64 n, int is_product,
+                                                      uint8_t *__restrict__ out)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n)
+        out[i] = is_product ? (a[i] & b[i] & 1u) : ((a[i] ^ b[i]) & 1u);
+}
+
+size_t decrypt_combined_scratch_bytes(u64 batch, u64 t1, u64 t2)
+{
+    const size_t pad = 256;
+    return decrypt_scratch_bytes(batch, batch * t1) + decrypt_scratch_bytes(batch, batch * t2) +
+           2 * (((size_t)batch + pad - 1) / pad * pad) + 4 * pad;
+}
+
+hipError_t decrypt_combined(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R,
+                            const u64 *mask, bool is_product, uint8_t *bits, void *scratch, hipStream_t s)
+{
+    if (batch == 0)
+        return hipSuccess;
+    const size_t pad = 256;
+    auto up = [&](size_t x) { return (x + pad - 1) / pad * pad; };
+    unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
+    base = reinterpret_cast<unsigned char *>(up(reinterpret_cast<uintptr_t>(base)));
+    unsigned char *s1 = base;
+    unsigned char *s2 = s1 + up(decrypt_scratch_bytes(batch, batch * t1));
+    uint8_t *b1 = s2 + up(decrypt_scratch_bytes(batch, batch * t2));
+    uint8_t *b2 = b1 + up(batch);
+    hipError_t e = decrypt(n_bits, batch, t1, batch * t1, L, nullptr, mask, b1, s1, s);
+    if (e != hipSuccess)
+        return e;
+    e = decrypt(n_bits, batch, t2, batch * t2, R, nullptr, mask, b2, s2, s);
+    if (e != hipSuccess)
+        return e;
+    k_combine_bits<<<ceil_div_u64(batch, 256), 256, 0, s>>>(b1, b2, batch, is_product ? 1 : 0, bits);
+    return hipGetLastError();
+}
+
 hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
                    const u32 *chosen, const uint8_t *last, const u64 *key, const u64 *mask, u64 seed,
                    bool device_rng, u64 *out, hipStream_t s)

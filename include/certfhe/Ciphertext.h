@@ -78,6 +78,14 @@ class Ciphertext {
     uint64_t getTerms() const;               // len / dL
     const uint64_t *deviceValues() const;    // HBM pointer, valid while this object is unchanged
     bool hasCanonicalBitlen() const;
+
+    // Wire format "CSGN" v1 (the reference has no save/load, only the raw
+    // getValues()/4-arg-constructor round trip).  Little-endian:
+    //   char[4] "CSGN" | u16 version=1 | u16 flags (bit0: explicit Bitlen array follows)
+    //   u64 N | u64 D | u64 len (words) | len x u64 term words [| len x u64 Bitlen]
+    // The bitlen side-array is implied by (N, len) and omitted unless it is non-canonical.
+    void serialize(std::ostream &out) const;
+    static Ciphertext deserialize(std::istream &in);
 };
 
 } // namespace certFHE

@@ -158,6 +158,22 @@ int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
                         const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
                         uint8_t *d_bits, void *d_scratch, void *stream);
 
+/* Fused forms: the plaintext of a product / sum WITHOUT materialising it.
+ *     bit_b = Dec(L_b * R_b) = Dec(L_b) & Dec(R_b)        (product)
+ *     bit_b = Dec(L_b + R_b) = Dec(L_b) ^ Dec(R_b)        (sum)
+ * exact identities of the scheme: a product term L_i & R_j has all D secret positions set
+ * iff both factors do, so the count of such terms is hits(L)*hits(R); concatenation adds the
+ * counts (src/SecretKey.cpp:131-140 applied to src/Ciphertext.cpp:153-163 / :107-122).
+ * Reads 8*dL*(t1+t2) bytes per pair instead of writing 8*dL*t1*t2.  d_scratch must hold
+ * csgn_decrypt_combined_scratch_bytes(batch, t1, t2) bytes. */
+size_t csgn_decrypt_combined_scratch_bytes(uint64_t batch, uint64_t t1, uint64_t t2);
+int csgn_decrypt_product_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                                 const uint64_t *d_left, const uint64_t *d_right,
+                                 const uint64_t *d_mask, uint8_t *d_bits, void *d_scratch, void *stream);
+int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
+                             const uint64_t *d_left, const uint64_t *d_right,
+                             const uint64_t *d_mask, uint8_t *d_bits, void *d_scratch, void *stream);
+
 /* ------------------------------------------------------------------- encrypt ---- */
 
 /* Batched SecretKey::encrypt (bit vector src/SecretKey.cpp:35-80, MSB-first packing

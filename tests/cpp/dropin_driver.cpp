@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <sstream>
 #include <stdexcept>
 
@@ -349,6 +350,56 @@ static int cmd_api()
     return 0;
 }
 
+static int cmd_wire(int argc, char **argv)
+{
+    // wire <path>: deterministic ciphertexts -> product -> save; load back, compare, decrypt
+    if (argc < 3)
+        return 64;
+    Context ctx(1247, 16);
+    SecretKey sk(ctx);
+    uint64_t key[16];
+    for (int i = 0; i < 16; ++i)
+        key[i] = (uint64_t)(i * 71 + 5);
+    sk.setKey(key, 16);
+    srand(2024);
+    Plaintext one(1), zero(0);
+    Ciphertext a = sk.encrypt(one), b = sk.encrypt(zero), c = sk.encrypt(one);
+    Ciphertext prod = (a + b) * (c + a);           // 4 terms, plaintext (1^0)&(1^1) = 0
+    {
+        std::ofstream f(argv[2], std::ios::binary);
+        prod.serialize(f);
+        a.serialize(f);                            // two objects back to back in one stream
+    }
+    std::ifstream f(argv[2], std::ios::binary);
+    Ciphertext p2 = Ciphertext::deserialize(f);
+    Ciphertext a2 = Ciphertext::deserialize(f);
+    EXPECT(p2.getLen() == prod.getLen() && a2.getLen() == 20);
+    EXPECT(p2.getContext().getN() == 1247 && p2.getContext().getD() == 16);
+    for (uint64_t i = 0; i < prod.getLen(); ++i)
+        EXPECT(p2.getValues()[i] == prod.getValues()[i]);
+    EXPECT(sk.decrypt(p2).getValue() == 0 && sk.decrypt(a2).getValue() == 1);
+    dump("wire_prod", prod);
+    dump("wire_a", a);
+    // a custom Bitlen survives the round trip; garbage is refused
+    uint64_t w[2] = {1, 2}, bl[2] = {7, 9};
+    Context small(65, 4);
+    Ciphertext odd(w, bl, 2, small);
+    std::stringstream ss;
+    odd.serialize(ss);
+    Ciphertext odd2 = Ciphertext::deserialize(ss);
+    EXPECT(!odd2.hasCanonicalBitlen() && odd2.getBitlen()[0] == 7 && odd2.getBitlen()[1] == 9);
+    std::stringstream bad("not a ciphertext at all");
+    bool threw = false;
+    try {
+        Ciphertext::deserialize(bad);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    EXPECT(threw);
+    printf("wire ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
@@ -371,6 +422,8 @@ int main(int argc, char **argv)
             return cmd_bitlen();
         if (cmd == "api")
             return cmd_api();
+        if (cmd == "wire")
+            return cmd_wire(argc, argv);
         return 64;
     } catch (const std::exception &e) {
         fprintf(stderr, "certFHE error: %s\n", e.what());

@@ -137,3 +137,28 @@ def test_circuit_matches_oracle(driver, oracle, n, d):
     decs = [l.split() for l in p.stdout.splitlines() if l.startswith("stage_dec")]
     assert len(decs) == 6 and all(t[1] == t[3] for t in decs)
     assert int(decs[-1][5]) == x.size // oracle.default_len(n)
+
+
+@pytest.mark.gpu
+def test_wire_format_roundtrip(driver, oracle, tmp_path):
+    """Ciphertext::serialize / deserialize (SURVEY 8f-3): the file is the documented layout and
+    its words are what the oracle computes for the same seeded inputs."""
+    path = tmp_path / "ct.csgn"
+    out = run(driver, "wire", path).stdout
+    assert "wire ok" in out
+    raw = path.read_bytes()
+    assert raw[:4] == b"CSGN" and raw[4:8] == bytes([1, 0, 0, 0])
+    n, d, words = np.frombuffer(raw[8:32], dtype="<u8")
+    assert (n, d, words) == (1247, 16, 80)
+    prod = np.frombuffer(raw[32:32 + 8 * 80], dtype="<u8")
+    second = raw[32 + 8 * 80:]
+    assert second[:4] == b"CSGN" and len(second) == 32 + 8 * 20
+    a_words = np.frombuffer(second[32:], dtype="<u8")
+    key = np.array([i * 71 + 5 for i in range(16)], dtype=np.uint64)
+    fresh, _ = oracle.encrypt_seq(1247, key, [1, 0, 1], glibc_draws(2024, 3 * 1249))
+    a, b, c = fresh[:20], fresh[20:40], fresh[40:]
+    lhs, _ = oracle.add(a, b)
+    rhs, _ = oracle.add(c, a)
+    want, _ = oracle.mul(1247, lhs, rhs)
+    assert np.array_equal(prod, want) and np.array_equal(a_words, a)
+    assert np.array_equal(parse_cts(out, "wire_prod")[0], want)

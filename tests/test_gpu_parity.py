@@ -516,3 +516,111 @@ def test_decrypt_kernel_forms(hip, oracle, monkeypatch, n, d, loop):
         bits = hip.download(hip.decrypt_uniform(n, batch, terms, hip.upload(np.concatenate(parts)), dmask))
         for b in range(batch):
             assert bits[b] == oracle.decrypt_canonical(n, key, parts[b]) == ((5 * b + terms) % (terms + 1)) % 2
+
+
+def test_config5_depth16_circuit_batched(hip, oracle):
+    """BASELINE config 5 / SURVEY 8d: Context(4096,32), x0=Enc(b0); odd level: x += Enc(b);
+    even level: x *= (Enc(b)+Enc(b')) -> 766 terms after 16 levels; a random Permutation is
+    applied to every FRESH input and to the key first.  Run as a BATCH of independent circuits
+    through the uniform batch calls; every circuit's ciphertext is compared with the oracle at
+    the end and every level's decryption with the plaintext circuit evaluated in the clear."""
+    n, d, dl, B = 4096, 32, 64, 24
+    key = make_key(n, d, 21)
+    rng = np.random.default_rng(22)
+    perm = rng.permutation(n).astype(np.uint64)
+    pkey = oracle.permute_key(n, perm, key)
+    dmask = hip.upload(hip.key_mask(n, key))
+    dpmask = hip.upload(hip.key_mask(n, pkey))
+    per_circuit = 1 + 8 + 16                      # fresh inputs used by one circuit
+    plain = rng.integers(0, 2, size=(per_circuit, B)).astype(np.uint8)   # input-major layout
+    fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), hip.upload(key), dmask, seed=77)
+    fresh = hip.permute_uniform(n, per_circuit * B, 1, fresh, hip.upload(perm.astype(np.uint32)))
+    inp = lambda i: fresh[i * B * dl:(i + 1) * B * dl]          # input i of every circuit: B ciphertexts
+    x, xt = inp(0), 1
+    xb = plain[0].copy()
+    k = 1
+    for level in range(1, 17):
+        if level % 2:
+            x = hip.add_uniform(n, B, xt, 1, x, inp(k)); xb ^= plain[k]; xt += 1; k += 1
+        else:
+            rhs = hip.add_uniform(n, B, 1, 1, inp(k), inp(k + 1))
+            x = hip.mul_uniform(n, B, xt, 2, x, rhs); xb &= plain[k] ^ plain[k + 1]; xt *= 2; k += 2
+        got = hip.download(hip.decrypt_uniform(n, B, xt, x, dpmask))
+        assert np.array_equal(got, xb), level
+    assert xt == 766 and k == per_circuit
+    # full ciphertext parity for three of the circuits
+    host_fresh = hip.download(fresh).reshape(per_circuit, B, dl)
+    host_x = hip.download(x).reshape(B, xt * dl)
+    for c in (0, 7, B - 1):
+        hx, kk = host_fresh[0, c], 1
+        for level in range(1, 17):
+            if level % 2:
+                hx, _ = oracle.add(hx, host_fresh[kk, c]); kk += 1
+            else:
+                r, _ = oracle.add(host_fresh[kk, c], host_fresh[kk + 1, c])
+                hx, _ = oracle.mul(n, hx, r); kk += 2
+        assert np.array_equal(host_x[c], hx)
+        assert oracle.decrypt_canonical(n, pkey, hx) == xb[c]
+
+
+def test_largest_supported_term_and_rejection(hip, oracle):
+    """Terms of 16 KiB (N=131072) are the documented limit; one bit more is refused."""
+    from csgn_amd.capi import CsgnError
+    n = 131072
+    dl = oracle.default_len(n)
+    a = oracle.synth(1, n, 0, 3 * dl)
+    b = oracle.synth(2, n, 0, 5 * dl)
+    out = hip.download(hip.mul_uniform(n, 1, 3, 5, hip.upload(a), hip.upload(b)))
+    want, _ = oracle.mul(n, a, b)
+    assert np.array_equal(out, want)
+    key = make_key(n, 8, 3)
+    planted_ct = planted(oracle, n, key, 9, 4, 55)
+    bit = hip.download(hip.decrypt_uniform(n, 1, 9, hip.upload(planted_ct), hip.upload(hip.key_mask(n, key))))
+    assert bit[0] == 0 == oracle.decrypt_canonical(n, key, planted_ct)
+    perm = np.random.default_rng(4).permutation(n).astype(np.uint64)
+    got = hip.download(hip.permute_uniform(n, 1, 1, hip.upload(a[:dl]), hip.upload(perm.astype(np.uint32))))
+    assert np.array_equal(got, oracle.permute_ciphertext(n, perm, a[:dl]))
+    with pytest.raises(CsgnError):
+        hip.mul_uniform(n + 1, 1, 1, 1, hip.upload(a), hip.upload(b))
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (63, 4)])
+def test_fused_product_and_sum_decrypt(hip, oracle, n, d):
+    """Dec(L*R) and Dec(L+R) computed without materialising the result equal the decryption of
+    the materialised result (GPU) and of the oracle's result."""
+    key = make_key(n, d, 31)
+    dmask = hip.upload(hip.key_mask(n, key))
+    dl = oracle.default_len(n)
+    for (t1, t2) in [(1, 1), (3, 5), (64, 33), (300, 7)]:
+        batch = 12
+        Ls = [planted(oracle, n, key, t1, (b * 7 + 1) % (t1 + 1), 800 + b) for b in range(batch)]
+        Rs = [planted(oracle, n, key, t2, (b * 5 + 2) % (t2 + 1), 900 + b) for b in range(batch)]
+        dL_, dR_ = hip.upload(np.concatenate(Ls)), hip.upload(np.concatenate(Rs))
+        fused_mul = hip.download(hip.decrypt_combined_uniform(n, batch, t1, t2, dL_, dR_, dmask, True))
+        fused_add = hip.download(hip.decrypt_combined_uniform(n, batch, t1, t2, dL_, dR_, dmask, False))
+        prod = hip.mul_uniform(n, batch, t1, t2, dL_, dR_)
+        summ = hip.add_uniform(n, batch, t1, t2, dL_, dR_)
+        assert np.array_equal(fused_mul, hip.download(hip.decrypt_uniform(n, batch, t1 * t2, prod, dmask)))
+        assert np.array_equal(fused_add, hip.download(hip.decrypt_uniform(n, batch, t1 + t2, summ, dmask)))
+        for b in (0, 5, batch - 1):
+            pm, _ = oracle.mul(n, Ls[b], Rs[b])
+            pa, _ = oracle.add(Ls[b], Rs[b])
+            assert fused_mul[b] == oracle.decrypt_canonical(n, key, pm)
+            assert fused_add[b] == oracle.decrypt_canonical(n, key, pa)
+
+
+def test_fused_product_decrypt_full_size(hip, oracle):
+    """1024x1024 at N=1247: the fused form answers from 2x160 KB what the materialised
+    168 MB product decrypts to."""
+    n, d, t = 1247, 16, 1024
+    key = make_key(n, d, 33)
+    dmask = hip.upload(hip.key_mask(n, key))
+    batch = 6
+    Ls = [planted(oracle, n, key, t, 3 + b, 1000 + b) for b in range(batch)]
+    Rs = [planted(oracle, n, key, t, 5 + 2 * b + (b % 2), 1100 + b) for b in range(batch)]
+    dL_, dR_ = hip.upload(np.concatenate(Ls)), hip.upload(np.concatenate(Rs))
+    fused = hip.download(hip.decrypt_combined_uniform(n, batch, t, t, dL_, dR_, dmask, True))
+    prod = hip.mul_uniform(n, batch, t, t, dL_, dR_)
+    mat = hip.download(hip.decrypt_uniform(n, batch, t * t, prod, dmask))
+    assert np.array_equal(fused, mat)
+    assert list(fused) == [((3 + b) * (5 + 2 * b + (b % 2))) % 2 for b in range(batch)]
