@@ -88,7 +88,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _LIB_PATH
+    p = path or os.environ.get("CSGN_HIP_LIB") or _LIB_PATH   # env override: A/B of library builds
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: the HIP library has not been built (python -m csgn_amd.build). "

@@ -14,8 +14,9 @@ struct MulTuning {
     int m;
     int ti;
     int nt;
-    int flat;   // CSGN_MUL_FLAT: force the flat kernel with this many units per lane (0 = auto)
+    int flat;   // CSGN_MUL_FLAT: units per lane of the flat kernel (0 = default 1); -1 = use the LDS-tiled kernel
     int bs;     // CSGN_MUL_BS: override the tiled kernel's block size (0 = auto)
+    int xcd;    // CSGN_MUL_XCD: XCD-contiguous block order: 0 off, 1 flat kernel only (default), 2 both kernels
 };
 MulTuning mul_tuning();
 

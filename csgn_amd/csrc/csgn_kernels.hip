@@ -36,6 +36,17 @@ __device__ inline bool unit_covers(unit8 x, unit8 m) { return (x & m) == m; }
 
 inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; placement is
+// a speed matter only, never correctness).  Remapping the block id so that XCD x owns the
+// x-th contiguous eighth of the logical block range makes every XCD's L2 write back one
+// sequential address stream instead of every 8th 4 KiB chunk: +5 % on a pure fill
+// (tools/wbench.hip: 6.9 -> 7.3 TB/s).  Bijective for any grid size.
+__device__ inline u32 xcd_contiguous_block(u32 b, u32 nblocks)
+{
+    const u32 q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
+    return x * q + min(x, r) + (b >> 3);
+}
+
 // ---------------------------------------------------------------------------------------
 // 1x1 batch: out = a & b over a flat stream of units.
 // Replaces Ciphertext::defaultN_multiply (src/Ciphertext.cpp:124-131) for a whole batch of
@@ -59,25 +70,34 @@ __global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
 // (pair, left term i, right column c).  Operands are tiny and re-read through L1/L2.
 // Replaces the general path of Ciphertext::multiply (src/Ciphertext.cpp:146-163).
 // ---------------------------------------------------------------------------------------
-template <typename Unit, int MF>
+template <typename Unit, int MF, bool XCD>
 __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
                                                   Unit *__restrict__ out, u32 total_units, u32 t1,
                                                   u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU)
 {
-    // one launch covers < 2^32 output units, so every index below is 32-bit
+    // one launch covers < 2^32 output units, so every index below is 32-bit.  Loads are
+    // unconditional on clamped indices so that all 2*MF of them are in flight together.
     const u32 CU = t2 * U, LU = t1 * U, PU = t1 * CU;
+    const u32 bid = XCD ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u32 last = total_units - 1;
+    Unit l[MF], r[MF];
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-        const u32 g = blockIdx.x * (256u * MF) + (u32)m * 256u + threadIdx.x;
-        if (g < total_units) {
-            const u32 pair = csgn_fastdiv(g, dPU);
-            const u32 r = g - pair * PU;
-            const u32 i = csgn_fastdiv(r, dCU);
-            const u32 c = r - i * CU;
-            const u32 k = c - csgn_fastdiv(c, dU) * U;
-            out[g] = L[(u64)pair * LU + i * U + k] & R[(u64)pair * CU + c];
-        }
+        const u32 g = min(bid * (256u * MF) + (u32)m * 256u + threadIdx.x, last);
+        const u32 pair = csgn_fastdiv(g, dPU);
+        const u32 rr = g - pair * PU;
+        const u32 i = csgn_fastdiv(rr, dCU);
+        const u32 c = rr - i * CU;
+        const u32 k = c - csgn_fastdiv(c, dU) * U;
+        l[m] = L[(u64)pair * LU + i * U + k];
+        r[m] = R[(u64)pair * CU + c];
+    }
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u32 g = bid * (256u * MF) + (u32)m * 256u + threadIdx.x;
+        if (g <= last)
+            unit_store<Unit, true>(out + g, l[m] & r[m]);
     }
 }
 
@@ -103,6 +123,7 @@ struct MulArgs {
     const u64 *offR;
     const u64 *offOut;
     u32 t1, t2, U, TI, col_tiles, row_tiles;
+    u32 xcd_remap;
 };
 
 template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
@@ -113,8 +134,9 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
 
     const u32 BS = blockDim.x, tid = threadIdx.x, U = a.U;
     const u32 tiles = a.col_tiles * a.row_tiles;
-    const u32 pair = blockIdx.x / tiles;
-    const u32 tile = blockIdx.x - pair * tiles;
+    const u32 bid = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u32 pair = bid / tiles;
+    const u32 tile = bid - pair * tiles;
     const u32 row_tile = tile / a.col_tiles;
     const u32 col_tile = tile - row_tile * a.col_tiles;
 
@@ -141,12 +163,15 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
         return;                               // whole workgroup leaves together
     const u32 rows = min(a.TI, t1 - i0);
 
-    // stage the left tile: rows*U consecutive units, coalesced
+    // stage the left tile: rows*U consecutive units, coalesced (wave 0 only at the default tile)
     const Unit *Lp = reinterpret_cast<const Unit *>(a.L) + lbase + (u64)i0 * U;
     for (u32 u = tid; u < rows * U; u += BS)
         lds[u] = Lp[u];
 
-    // this lane's right-operand units stay in registers for the whole tile
+    // this lane's right-operand units stay in registers for the whole tile.  (Measured A/B on
+    // one device, bench.py batch 8192: issuing this load first and unconditionally, so that it
+    // overlaps the left-tile fetch, is 4-5 % SLOWER end to end, 39.1 k vs 41.5 k mult/s; the
+    // 8 resident workgroups per CU already hide the prologue latency.)
     const Unit *Rp = reinterpret_cast<const Unit *>(a.R) + rbase;
     Unit r[M];
     u32 k[M];
@@ -736,6 +761,9 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
         ti = a.t1;
     a.U = U;
     a.TI = ti;
+    // XCD-contiguous order helps the (linear) flat kernel but measured 7 % slower on the tiled
+    // kernel's comb-shaped store pattern, so it is opt-in here (CSGN_MUL_XCD=2)
+    a.xcd_remap = tune.xcd == 2 ? 1u : 0u;
     a.col_tiles = (cu + bs * m - 1) / (bs * m);
     a.row_tiles = (a.t1 + ti - 1) / ti;
     const u64 tiles = (u64)a.col_tiles * a.row_tiles;
@@ -791,7 +819,13 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         }
         return hipSuccess;
     }
-    if ((PU <= 8192 || tune.flat) && PU < (1ull << 31)) {
+    // Small products (and CSGN_MUL_FLAT=k sweeps): the flat kernel, which re-reads both
+    // operands through L1/L2 for every output unit.  It is the faster of the two ONLY while the
+    // operands of the pairs in flight stay cache-resident (7.3 vs 6.9 TB/s at 1024x1024 with a
+    // 40 MB operand set) and collapses to 4.6 TB/s when they stream from HBM (the bench's
+    // 21 GB), so larger products take the LDS-tiled kernel, which reads each right-operand
+    // unit once per TI rows and holds 7.0 TB/s either way.
+    if ((tune.flat > 0 || (tune.flat == 0 && PU <= 8192)) && PU < (1ull << 31)) {
         const int mf = tune.flat ? tune.flat : 1;
         const u64 pairs_per = (0xFFFFFFFFull / PU) ? (0xFFFFFFFFull / PU) : 1;   // < 2^32 units per launch
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
@@ -802,12 +836,20 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
             const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
             const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
             Unit *Oc = Ou + p0 * PU;
+#define CSGN_FLAT(MF)                                                                                  \
+    do {                                                                                               \
+        if (tune.xcd)                                                                                  \
+            k_mul_flat<Unit, MF, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU);  \
+        else                                                                                           \
+            k_mul_flat<Unit, MF, false><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); \
+    } while (0)
             switch (mf) {
-            case 1: k_mul_flat<Unit, 1><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
-            case 2: k_mul_flat<Unit, 2><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
-            case 4: k_mul_flat<Unit, 4><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
-            default: k_mul_flat<Unit, 8><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); break;
+            case 1: CSGN_FLAT(1); break;
+            case 2: CSGN_FLAT(2); break;
+            case 4: CSGN_FLAT(4); break;
+            default: CSGN_FLAT(8); break;
             }
+#undef CSGN_FLAT
             hipError_t e = hipGetLastError();
             if (e != hipSuccess)
                 return e;
@@ -841,9 +883,12 @@ MulTuning mul_tuning()
     if (t.ti < 1)
         t.ti = 1;
     t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
-    t.flat = env_int("CSGN_MUL_FLAT", 0);
-    if (t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
+    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = flat kernel, default unroll; -1 = LDS-tiled kernel
+    if (t.flat != -1 && t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
         t.flat = 0;
+    t.xcd = env_int("CSGN_MUL_XCD", 1);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both
+    if (t.xcd < 0 || t.xcd > 2)
+        t.xcd = 1;
     t.bs = env_int("CSGN_MUL_BS", 0);
     if (t.bs % 64 != 0 || t.bs < 64 || t.bs > 512)
         t.bs = 0;

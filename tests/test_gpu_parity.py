@@ -85,8 +85,40 @@ def test_mul_uniform_matches_oracle(hip, oracle, n, d, t1, t2, batch):
         assert np.array_equal(out[b * per:(b + 1) * per], want), (n, t1, t2, b)
 
 
+@pytest.mark.parametrize("flat,xcd", [(0, 1), (0, 0), (2, 1), (4, 0), (8, 1)])
+def test_mul_flat_variants_do_not_change_results(hip, oracle, monkeypatch, flat, xcd):
+    monkeypatch.setenv("CSGN_MUL_FLAT", str(flat))
+    monkeypatch.setenv("CSGN_MUL_XCD", str(xcd))
+    n, dl = 1247, 20
+    for (t1, t2, batch) in [(100, 77, 2), (64, 128, 3), (257, 33, 1), (3, 5, 7), (1, 9, 5)]:
+        L = oracle.synth(5, n, 0, batch * t1 * dl)
+        R = oracle.synth(6, n, 0, batch * t2 * dl)
+        out = hip.download(hip.mul_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R)))
+        per = t1 * t2 * dl
+        for b in range(batch):
+            want, _ = oracle.mul(n, L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+            assert np.array_equal(out[b * per:(b + 1) * per], want)
+
+
+@pytest.mark.parametrize("n,d", CONTEXTS)
+@pytest.mark.parametrize("t1,t2", [(1, 2), (3, 5), (33, 65), (5, 300), (129, 130)])
+def test_mul_tiled_kernel_matches_oracle(hip, oracle, monkeypatch, n, d, t1, t2):
+    """The LDS-tiled kernel (CSGN_MUL_FLAT=-1; also the ragged path) on every context."""
+    monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
+    dl = oracle.default_len(n)
+    batch = 2
+    L = oracle.synth(1000 + t1, n, 0, batch * t1 * dl)
+    R = oracle.synth(2000 + t2, n, 0, batch * t2 * dl)
+    out = hip.download(hip.mul_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R)))
+    per = t1 * t2 * dl
+    for b in range(batch):
+        want, _ = oracle.mul(n, L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+        assert np.array_equal(out[b * per:(b + 1) * per], want), (n, t1, t2, b)
+
+
 @pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
 def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
+    monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
     monkeypatch.setenv("CSGN_MUL_M", str(m))
     monkeypatch.setenv("CSGN_MUL_TI", str(ti))
     monkeypatch.setenv("CSGN_MUL_NT", str(nt))

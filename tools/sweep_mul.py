@@ -49,7 +49,8 @@ def timed(fn):
     return a.elapsed_time(b) / 1e3
 
 
-def run_mul(m, ti, nt, flat=0, bs=0):
+def run_mul(m, ti, nt, flat=0, bs=0, xcd=1):
+    os.environ["CSGN_MUL_XCD"] = str(xcd)
     os.environ["CSGN_MUL_M"], os.environ["CSGN_MUL_TI"], os.environ["CSGN_MUL_NT"] = str(m), str(ti), str(nt)
     os.environ["CSGN_MUL_FLAT"], os.environ["CSGN_MUL_BS"] = str(flat), str(bs)
     hip.mul_uniform(n, args.pairs, T, T, L, R, out=arena, out_slots=args.slots)
@@ -68,7 +69,7 @@ for r in range(args.rounds):
 
 for k, ts in ref.items():
     print(f"{k:>14}: median {arena_bytes / statistics.median(ts) / 1e9:8.1f} GB/s  best {arena_bytes / min(ts) / 1e9:8.1f} GB/s")
-print(f"{'M,TI,NT,FLAT,BS':>14}  median GB/s   best GB/s   mult/s(median)")
+print(f"{'M,TI,NT,FLAT,BS,XCD':>14}  median GB/s   best GB/s   mult/s(median)")
 for v, ts in sorted(res.items(), key=lambda kv: statistics.median(kv[1])):
     med, best = statistics.median(ts), min(ts)
     print(f"{str(v):>14}  {args.pairs * bytes_per_mul / med / 1e9:10.1f}  {args.pairs * bytes_per_mul / best / 1e9:10.1f}   {args.pairs / med:10.0f}")

@@ -71,6 +71,17 @@ __global__ void __launch_bounds__(512) fill_rows(unit16 *o, u32 cu, u32 rows_tot
     for (u64 i = threadIdx.x; i < n; i += BS) { if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
 }
 
+// E: one store per lane, block size BS, optional XCD-contiguous remap of the chunk order
+template <bool NT, int REMAP>
+__global__ void __launch_bounds__(1024) fill_one(unit16 *o, u64 n, unit16 v, u32 nblocks)
+{
+    u32 b = blockIdx.x;
+    if (REMAP == 1) { const u32 per = nblocks / 8; b = (b % 8) * per + b / 8; }        // each XCD sweeps its own eighth
+    if (REMAP == 2) { const u32 grp = b / 64, r = b % 64; b = grp * 64 + (r % 8) * 8 + r / 8; }  // 8x8 transpose inside 64-block groups
+    const u64 i = (u64)b * blockDim.x + threadIdx.x;
+    if (i < n) { if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v; }
+}
+
 template <typename F>
 double bench(const char *name, double bytes, int rounds, F launch)
 {
@@ -115,6 +126,16 @@ int main(int argc, char **argv)
     bench("fill_chunk K=16 NT", bytes, rounds, [&] { fill_chunk<16, true><<<(u32)((n + 4095) / 4096), 256>>>(o, n, v); });
     bench("fill_chunk K=64", bytes, rounds, [&] { fill_chunk<64, false><<<(u32)((n + 16383) / 16384), 256>>>(o, n, v); });
 
+    for (u32 bs : {256u, 512u, 1024u}) {
+        const u32 nb = (u32)(n / bs);
+        char nm[64];
+        snprintf(nm, 64, "fill_one bs=%u", bs); bench(nm, bytes, rounds, [&] { fill_one<false, 0><<<nb, bs>>>(o, n, v, nb); });
+        snprintf(nm, 64, "fill_one bs=%u NT", bs); bench(nm, bytes, rounds, [&] { fill_one<true, 0><<<nb, bs>>>(o, n, v, nb); });
+        snprintf(nm, 64, "fill_one bs=%u xcd-contig", bs); bench(nm, bytes, rounds, [&] { fill_one<false, 1><<<nb, bs>>>(o, n, v, nb); });
+        snprintf(nm, 64, "fill_one bs=%u NT xcd-contig", bs); bench(nm, bytes, rounds, [&] { fill_one<true, 1><<<nb, bs>>>(o, n, v, nb); });
+        snprintf(nm, 64, "fill_one bs=%u 8x8-transpose", bs); bench(nm, bytes, rounds, [&] { fill_one<false, 2><<<nb, bs>>>(o, n, v, nb); });
+    }
+    if (argc > 3 && argv[3][0] == 'e') { CK(hipFree(o)); return 0; }
     for (u32 bs : {64u, 128u, 256u, 320u, 512u}) {
         for (u32 ti : {1u, 2u, 4u, 8u}) {
             const u32 M = 1; u32 ct = (cu + bs * M - 1) / (bs * M), rt = (T + ti - 1) / ti;
