@@ -19,6 +19,8 @@ void Library::useDevice(int device) { detail::selectDevice(device); }
 
 int Library::currentDevice() { return detail::activeDevice(); }
 
+void Library::releaseDeviceCache() { detail::releaseBlockCache(); }
+
 bool Helper::exists(const uint64_t *v, const uint64_t len, const uint64_t value)
 {
     for (uint64_t i = 0; i < len; ++i)

@@ -2,6 +2,7 @@
 #include "runtime.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace certFHE {
 namespace detail {
@@ -9,6 +10,87 @@ namespace detail {
 namespace {
 thread_local int g_device = -1;       // -1: not initialised on this thread
 thread_local int g_requested = -1;    // Library::useDevice
+
+// Block cache.  hipMalloc/hipFree cost ~10 us each and hipFree synchronises the device, which
+// would dominate the value-semantic class API (every operator allocates a result, every
+// temporary frees one).  Freed blocks are kept per power-of-two size class and handed out
+// again; re-use is ordered by the single stream all class operations run on, so a block that
+// an in-flight kernel still reads is only overwritten by work queued behind that kernel.
+struct BlockCache {
+    static const int kClasses = 48;
+    static const size_t kMaxCachedBlock = (size_t)256 << 20;   // larger blocks go straight back
+    static const size_t kMaxCachedTotal = (size_t)4 << 30;
+    std::vector<void *> free_list[kClasses];
+    size_t cached_bytes;
+    BlockCache() : cached_bytes(0) {}
+    ~BlockCache() { release(); }
+    static int size_class(size_t bytes)
+    {
+        int c = 8;                                  // 256-byte minimum
+        while (((size_t)1 << c) < bytes)
+            ++c;
+        return c;
+    }
+    void *take(size_t bytes, size_t *capacity)
+    {
+        const int c = size_class(bytes);
+        *capacity = (size_t)1 << c;
+        if (c < kClasses && !free_list[c].empty()) {
+            void *p = free_list[c].back();
+            free_list[c].pop_back();
+            cached_bytes -= *capacity;
+            return p;
+        }
+        void *p = nullptr;
+        int rc = csgn_malloc(&p, *capacity);
+        if (rc != CSGN_OK && cached_bytes) {        // out of HBM: drop the cache and retry once
+            release();
+            rc = csgn_malloc(&p, *capacity);
+        }
+        check(rc, "csgn_malloc");
+        return p;
+    }
+    void give(void *p, size_t capacity)
+    {
+        static const bool disabled = getenv("CSGN_NO_BLOCK_CACHE") != nullptr;   // A/B switch
+        const int c = size_class(capacity);
+        if (!disabled && c < kClasses && capacity <= kMaxCachedBlock && cached_bytes + capacity <= kMaxCachedTotal) {
+            free_list[c].push_back(p);
+            cached_bytes += capacity;
+        } else {
+            csgn_free(p);
+        }
+    }
+    void release()
+    {
+        for (int c = 0; c < kClasses; ++c) {
+            for (size_t i = 0; i < free_list[c].size(); ++i)
+                csgn_free(free_list[c][i]);
+            free_list[c].clear();
+        }
+        cached_bytes = 0;
+    }
+};
+// The cache lives on the heap behind a thread_local guard: objects with static storage can
+// outlive the guard at process exit, and then simply free their block directly.
+thread_local BlockCache *g_cache_ptr = nullptr;
+struct CacheGuard {
+    ~CacheGuard()
+    {
+        delete g_cache_ptr;
+        g_cache_ptr = nullptr;
+        dead = true;
+    }
+    bool dead = false;
+};
+thread_local CacheGuard g_cache_guard;
+
+BlockCache *cache()
+{
+    if (!g_cache_ptr && !g_cache_guard.dead)
+        g_cache_ptr = new BlockCache();
+    return g_cache_ptr;
+}
 }
 
 void check(int rc, const char *what)
@@ -59,8 +141,12 @@ void ensureDevice()
 
 DevicePayload::~DevicePayload()
 {
-    if (ptr)
-        csgn_free(ptr);   // nothing useful to do with a failure in a destructor
+    if (!ptr)
+        return;
+    if (BlockCache *c = cache())
+        c->give(ptr, capacity);
+    else
+        csgn_free(ptr);
 }
 
 std::shared_ptr<DevicePayload> allocBytes(size_t bytes)
@@ -68,9 +154,15 @@ std::shared_ptr<DevicePayload> allocBytes(size_t bytes)
     ensureDevice();
     std::shared_ptr<DevicePayload> p = std::make_shared<DevicePayload>();
     if (bytes)
-        check(csgn_malloc(&p->ptr, bytes), "csgn_malloc");
+        p->ptr = cache()->take(bytes, &p->capacity);
     p->words = bytes / 8;
     return p;
+}
+
+void releaseBlockCache()
+{
+    if (g_cache_ptr)
+        g_cache_ptr->release();
 }
 
 std::shared_ptr<DevicePayload> allocWords(uint64_t words) { return allocBytes((size_t)words * 8); }

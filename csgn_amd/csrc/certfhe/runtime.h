@@ -18,7 +18,8 @@ namespace detail {
 struct DevicePayload {
     void *ptr;
     uint64_t words;
-    DevicePayload() : ptr(nullptr), words(0) {}
+    size_t capacity;      // bytes actually reserved (a size class of the block cache)
+    DevicePayload() : ptr(nullptr), words(0), capacity(0) {}
     ~DevicePayload();
     DevicePayload(const DevicePayload &) = delete;
     DevicePayload &operator=(const DevicePayload &) = delete;
@@ -39,6 +40,8 @@ std::shared_ptr<DevicePayload> allocWords(uint64_t words);
 std::shared_ptr<DevicePayload> uploadWords(const uint64_t *host, uint64_t words);
 void downloadBytes(void *host, const void *dev, size_t bytes);
 void syncDevice();
+// Returns every cached HBM block of the calling thread to the driver.
+void releaseBlockCache();
 
 inline void *stream() { return nullptr; }   // the classes run on the default stream
 

@@ -20,6 +20,9 @@ class Library {
     // Throws std::runtime_error when no gfx950 device is usable: there is no CPU fallback.
     static void useDevice(int device);
     static int currentDevice();
+    // Freed ciphertext buffers are cached per size class for re-use (hipMalloc/hipFree are
+    // slow and hipFree synchronises); this hands the cached HBM back to the driver.
+    static void releaseDeviceCache();
 };
 
 class Helper {

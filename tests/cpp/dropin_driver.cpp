@@ -400,6 +400,40 @@ static int cmd_wire(int argc, char **argv)
     return 0;
 }
 
+static int cmd_latency(int iters)
+{
+    // steady-state cost of single operations through the value-semantic class API
+    Library::initializeLibrary();
+    Context ctx(1247, 16);
+    SecretKey sk(ctx);
+    Plaintext one(1), zero(0);
+    Ciphertext a = sk.encrypt(one), b = sk.encrypt(zero);
+    Ciphertext big = a + b;
+    for (int i = 0; i < 6; ++i)
+        big = big * (a + b);                        // 128 terms
+    struct Case { const char *name; int kind; } cases[] = {
+        {"mul 1x1", 0}, {"add 1+1", 1}, {"decrypt 1 term", 2}, {"encrypt", 3},
+        {"mul 128x2", 4}, {"decrypt 128 terms", 5}};
+    for (const Case &c : cases) {
+        Timer t(c.name);
+        int acc = 0;
+        t.start();
+        for (int i = 0; i < iters; ++i) {
+            switch (c.kind) {
+            case 0: { Ciphertext r = a * b; acc += (int)r.getLen(); break; }
+            case 1: { Ciphertext r = a + b; acc += (int)r.getLen(); break; }
+            case 2: acc += sk.decrypt(a).getValue(); break;
+            case 3: { Ciphertext r = sk.encrypt(one); acc += (int)r.getLen(); break; }
+            case 4: { Ciphertext r = big * (a + b); acc += (int)r.getLen(); break; }
+            default: acc += sk.decrypt(big).getValue(); break;
+            }
+        }
+        double ms = t.stop();
+        printf("latency %-18s %8.2f us/op (acc %d)\n", c.name, ms * 1000.0 / iters, acc);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) {
@@ -424,6 +458,8 @@ int main(int argc, char **argv)
             return cmd_api();
         if (cmd == "wire")
             return cmd_wire(argc, argv);
+        if (cmd == "latency")
+            return cmd_latency(argc > 2 ? atoi(argv[2]) : 2000);
         return 64;
     } catch (const std::exception &e) {
         fprintf(stderr, "certFHE error: %s\n", e.what());
