@@ -1,0 +1,156 @@
+// Batch.cpp -- uniform device-resident batches over the C ABI (extension, see Batch.h).
+#include "Batch.h"
+
+#include "runtime.h"
+
+namespace certFHE {
+
+using detail::DevicePayload;
+
+namespace {
+void requireSameShape(const Context &a, const Context &b, uint64_t ca, uint64_t cb)
+{
+    if (a.getN() != b.getN() || ca != cb)
+        throw std::invalid_argument("certFHE::CiphertextBatch: operands differ in N or element count");
+}
+} // namespace
+
+CiphertextBatch::CiphertextBatch(const Context &c, uint64_t count, uint64_t terms)
+    : count_(count), terms_(terms), ctx(c)
+{
+    payload = detail::allocWords(count * terms * c.getDefaultN());
+}
+
+const uint64_t *CiphertextBatch::deviceValues() const { return payload ? payload->data() : nullptr; }
+
+CiphertextBatch CiphertextBatch::encrypt(const SecretKey &key, const std::vector<unsigned char> &bits,
+                                         uint64_t seed)
+{
+    if (!key.certFHEContext)
+        throw std::logic_error("certFHE::CiphertextBatch::encrypt: key has no Context");
+    const Context &c = *key.certFHEContext;
+    key.ensureMask();
+    const uint64_t d = (uint64_t)key.length, count = bits.size();
+    CiphertextBatch out(c, count, 1);
+    if (count == 0)
+        return out;
+    // staging: [key indices (d words)][plaintext bytes]
+    std::vector<uint64_t> stage(d + (count + 7) / 8, 0);
+    for (uint64_t i = 0; i < d; ++i)
+        stage[i] = key.s[i];
+    memcpy(stage.data() + d, bits.data(), count);
+    std::shared_ptr<DevicePayload> dstage = detail::uploadWords(stage.data(), stage.size());
+    detail::check(csgn_encrypt_device_rng(c.getN(), d, count,
+                                          reinterpret_cast<const uint8_t *>(dstage->data() + d),
+                                          dstage->data(), key.device_mask->data(), seed,
+                                          out.payload->data(), detail::stream()),
+                  "csgn_encrypt_device_rng");
+    detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");
+    return out;
+}
+
+CiphertextBatch CiphertextBatch::pack(const std::vector<Ciphertext> &items)
+{
+    if (items.empty())
+        throw std::invalid_argument("certFHE::CiphertextBatch::pack: empty list");
+    const Context c = items[0].getContext();
+    const uint64_t dl = c.getDefaultN(), terms = items[0].getTerms();
+    CiphertextBatch out(c, items.size(), terms);
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (items[i].getTerms() != terms || items[i].getLen() != terms * dl || !items[i].hasCanonicalBitlen())
+            throw std::invalid_argument("certFHE::CiphertextBatch::pack: elements must share one shape");
+        detail::check(csgn_memcpy_d2d(out.payload->data() + i * terms * dl, items[i].deviceValues(),
+                                      (size_t)terms * dl * 8, detail::stream()),
+                      "csgn_memcpy_d2d");
+    }
+    return out;
+}
+
+CiphertextBatch CiphertextBatch::operator*(const CiphertextBatch &rhs) const
+{
+    requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    CiphertextBatch out(ctx, count_, terms_ * rhs.terms_);
+    detail::check(csgn_mul_uniform(ctx.getN(), count_, terms_, rhs.terms_, deviceValues(),
+                                   rhs.deviceValues(), out.payload->data(), 0, detail::stream()),
+                  "csgn_mul_uniform");
+    return out;
+}
+
+CiphertextBatch CiphertextBatch::operator+(const CiphertextBatch &rhs) const
+{
+    requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    CiphertextBatch out(ctx, count_, terms_ + rhs.terms_);
+    detail::check(csgn_add_uniform(ctx.getN(), count_, terms_, rhs.terms_, deviceValues(),
+                                   rhs.deviceValues(), out.payload->data(), detail::stream()),
+                  "csgn_add_uniform");
+    return out;
+}
+
+std::vector<unsigned char> CiphertextBatch::decrypt(const SecretKey &key) const
+{
+    std::vector<unsigned char> bits(count_, 0);
+    if (count_ == 0)
+        return bits;
+    key.ensureMask();
+    const size_t scratch = (csgn_decrypt_scratch_bytes(count_, count_ * terms_) + 255) & ~(size_t)255;
+    std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch + count_);
+    uint8_t *d_bits = static_cast<uint8_t *>(work->ptr) + scratch;
+    detail::check(csgn_decrypt_uniform(ctx.getN(), count_, terms_, deviceValues(), key.device_mask->data(),
+                                       d_bits, work->ptr, detail::stream()),
+                  "csgn_decrypt_uniform");
+    detail::downloadBytes(bits.data(), d_bits, count_);
+    return bits;
+}
+
+static std::vector<unsigned char> fusedDecrypt(const CiphertextBatch &a, const CiphertextBatch &b,
+                                               const uint64_t *mask, bool product)
+{
+    std::vector<unsigned char> bits(a.size(), 0);
+    if (a.size() == 0)
+        return bits;
+    const size_t scratch =
+        (csgn_decrypt_combined_scratch_bytes(a.size(), a.terms(), b.terms()) + 255) & ~(size_t)255;
+    std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch + a.size());
+    uint8_t *d_bits = static_cast<uint8_t *>(work->ptr) + scratch;
+    const uint64_t n = a.context().getN();
+    detail::check(product ? csgn_decrypt_product_uniform(n, a.size(), a.terms(), b.terms(), a.deviceValues(),
+                                                         b.deviceValues(), mask, d_bits, work->ptr,
+                                                         detail::stream())
+                          : csgn_decrypt_sum_uniform(n, a.size(), a.terms(), b.terms(), a.deviceValues(),
+                                                     b.deviceValues(), mask, d_bits, work->ptr,
+                                                     detail::stream()),
+                  "csgn_decrypt_{product,sum}_uniform");
+    detail::downloadBytes(bits.data(), d_bits, a.size());
+    return bits;
+}
+
+std::vector<unsigned char> CiphertextBatch::decryptProduct(const CiphertextBatch &rhs,
+                                                           const SecretKey &key) const
+{
+    requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    key.ensureMask();
+    return fusedDecrypt(*this, rhs, key.device_mask->data(), true);
+}
+
+std::vector<unsigned char> CiphertextBatch::decryptSum(const CiphertextBatch &rhs, const SecretKey &key) const
+{
+    requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    key.ensureMask();
+    return fusedDecrypt(*this, rhs, key.device_mask->data(), false);
+}
+
+Ciphertext CiphertextBatch::at(uint64_t i) const
+{
+    if (i >= count_)
+        throw std::out_of_range("certFHE::CiphertextBatch::at");
+    const uint64_t words = terms_ * ctx.getDefaultN();
+    std::shared_ptr<DevicePayload> p = detail::allocWords(words);
+    detail::check(csgn_memcpy_d2d(p->data(), deviceValues() + i * words, (size_t)words * 8, detail::stream()),
+                  "csgn_memcpy_d2d");
+    Ciphertext c;
+    c.certFHEcontext = new Context(ctx);
+    c.publish(p, words);
+    return c;
+}
+
+} // namespace certFHE

@@ -30,6 +30,7 @@ struct DevicePayload;   // device buffer + word count (csgn_amd/csrc/certfhe/run
 }
 
 class SecretKey;
+class CiphertextBatch;
 
 class Ciphertext {
     std::shared_ptr<detail::DevicePayload> payload; // immutable once published
@@ -46,6 +47,7 @@ class Ciphertext {
     static Ciphertext combine(const Ciphertext &a, const Ciphertext &b, bool product);
 
     friend class SecretKey;
+    friend class CiphertextBatch;      // extension (Batch.h)
 
   public:
     Ciphertext();

@@ -22,6 +22,8 @@ using namespace std;
 
 namespace certFHE {
 
+class CiphertextBatch;
+
 class SecretKey {
     uint64_t *s;      // D secret positions in [0, N), in generation order
     long length;
@@ -32,6 +34,7 @@ class SecretKey {
 
     void invalidateMask();
     void ensureMask() const;
+    friend class CiphertextBatch;      // extension (Batch.h): reads the device-resident key mask
 
   public:
     SecretKey() = delete;

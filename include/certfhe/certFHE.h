@@ -10,5 +10,6 @@
 #include "Plaintext.h"
 #include "SecretKey.h"
 #include "Timer.h"
+#include "Batch.h"   // extension: device-resident uniform batches
 
 #endif

@@ -162,3 +162,11 @@ def test_wire_format_roundtrip(driver, oracle, tmp_path):
     want, _ = oracle.mul(1247, lhs, rhs)
     assert np.array_equal(prod, want) and np.array_equal(a_words, a)
     assert np.array_equal(parse_cts(out, "wire_prod")[0], want)
+
+
+@pytest.mark.gpu
+def test_batch_extension(driver):
+    """certFHE::CiphertextBatch: 4096 depth-6 circuits in lock step vs the clear evaluation,
+    the fused decryptProduct, and the per-object API."""
+    assert "batch ok count=4096" in run(driver, "batch", 4096).stdout
+    assert "batch ok count=7" in run(driver, "batch", 7).stdout
