@@ -74,14 +74,24 @@ template <typename Unit, int MF, bool XCD>
 __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
                                                   Unit *__restrict__ out, u32 total_units, u32 t1,
-                                                  u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU)
+                                                  u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU,
+                                                  u32 pf_rows, u32 total_rows)
 {
-    // one launch covers < 2^32 output units, so every index below is 32-bit.  Loads are
+    // One launch covers < 2^32 output units, so every index below is 32-bit.  Loads are
     // unconditional on clamped indices so that all 2*MF of them are in flight together.
+    //
+    // Left-term prefetch: every output row needs a NEW 16*U-byte left term, and with operands
+    // streaming from HBM each of the row's workgroups would sit out a full HBM miss on it
+    // (measured: 4.6 TB/s instead of 7.4).  The lanes that own the first U units of a row
+    // therefore also touch the left term of the row `pf_rows` further down the launch (left
+    // operands of consecutive pairs are contiguous, so this runs across pair boundaries); by
+    // the time that row is dispatched its term sits in L2 / Infinity Cache.  The value is only
+    // kept alive, never used.
     const u32 CU = t2 * U, LU = t1 * U, PU = t1 * CU;
     const u32 bid = XCD ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const u32 last = total_units - 1;
-    Unit l[MF], r[MF];
+    Unit l[MF], r[MF], pf_val;
+    bool pf_on = false;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const u32 g = min(bid * (256u * MF) + (u32)m * 256u + threadIdx.x, last);
@@ -92,6 +102,13 @@ __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
         const u32 k = c - csgn_fastdiv(c, dU) * U;
         l[m] = L[(u64)pair * LU + i * U + k];
         r[m] = R[(u64)pair * CU + c];
+        if (m == 0 && pf_rows) {
+            const u32 grow = pair * t1 + i + pf_rows;           // global row of this launch
+            if (c < U && grow < total_rows) {
+                pf_val = L[(u64)grow * U + c];
+                pf_on = true;
+            }
+        }
     }
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -99,6 +116,8 @@ __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
         if (g <= last)
             unit_store<Unit, true>(out + g, l[m] & r[m]);
     }
+    if (pf_on)
+        asm volatile("" ::"v"(pf_val));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -827,21 +846,30 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
     // unit once per TI rows and holds 7.0 TB/s either way.
     if ((tune.flat > 0 || (tune.flat == 0 && PU <= 8192)) && PU < (1ull << 31)) {
         const int mf = tune.flat ? tune.flat : 1;
+        // left-term prefetch distance: ~6 MB of output ahead per XCD stream (8x that when the
+        // workgroups of a row are spread over all XCDs), only when a row fills a workgroup
+        u32 pfr = 0;
+        if ((u64)t2 * U >= 256u) {
+            const u64 ahead = (u64)env_int("CSGN_MUL_PF_KB", tune.xcd ? 6144 : 49152) << 10;
+            const u64 row_bytes = (u64)t2 * U * sizeof(Unit);
+            pfr = (u32)((ahead + row_bytes - 1) / row_bytes);
+        }
         const u64 pairs_per = (0xFFFFFFFFull / PU) ? (0xFFFFFFFFull / PU) : 1;   // < 2^32 units per launch
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
                       dU = csgn_fastdiv_make(U);
         for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
             const u64 np = (pairs - p0 < pairs_per) ? pairs - p0 : pairs_per;
             const u32 tot = (u32)(np * PU);
+            const u32 trows = (u32)(np * t1);
             const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
             const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
             Unit *Oc = Ou + p0 * PU;
 #define CSGN_FLAT(MF)                                                                                  \
     do {                                                                                               \
         if (tune.xcd)                                                                                  \
-            k_mul_flat<Unit, MF, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU);  \
+            k_mul_flat<Unit, MF, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows);  \
         else                                                                                           \
-            k_mul_flat<Unit, MF, false><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU); \
+            k_mul_flat<Unit, MF, false><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows); \
     } while (0)
             switch (mf) {
             case 1: CSGN_FLAT(1); break;

@@ -49,7 +49,11 @@ def timed(fn):
     return a.elapsed_time(b) / 1e3
 
 
-def run_mul(m, ti, nt, flat=0, bs=0, xcd=1):
+def run_mul(m, ti, nt, flat=0, bs=0, xcd=1, pfkb=-1):
+    if pfkb >= 0:
+        os.environ["CSGN_MUL_PF_KB"] = str(pfkb)
+    else:
+        os.environ.pop("CSGN_MUL_PF_KB", None)
     os.environ["CSGN_MUL_XCD"] = str(xcd)
     os.environ["CSGN_MUL_M"], os.environ["CSGN_MUL_TI"], os.environ["CSGN_MUL_NT"] = str(m), str(ti), str(nt)
     os.environ["CSGN_MUL_FLAT"], os.environ["CSGN_MUL_BS"] = str(flat), str(bs)
