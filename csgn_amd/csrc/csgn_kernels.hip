@@ -380,7 +380,9 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
 {
     __shared__ u64 ok_bits[K * 4 + 1];
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const u64 g0 = (u64)blockIdx.x * (256u * K) + tid;
+    // XCD-contiguous block order: +4.5 % on a pure read stream (tools/rbench.hip)
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g0 = (u64)bid * (256u * K) + tid;
 
     // Loads are unconditional (addresses clamped into range) so that all K of them, and the K
     // mask units, are in flight together: a load under a divergent `if` makes hipcc wait
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
         if (lane == 0) {
             const u32 first = t;                  // first term of this wave's group
             const u32 nbits = min(64u, TB - first);
-            unsigned char *dst = hits + (u64)blockIdx.x * (TB >> 3) + (first >> 3);
+            unsigned char *dst = hits + (u64)bid * (TB >> 3) + (first >> 3);
             if (nbits == 64u)
                 *reinterpret_cast<u64 *>(dst) = hb;
             else if (nbits == 32u)

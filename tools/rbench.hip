@@ -59,6 +59,31 @@ __global__ void __launch_bounds__(256) copy_chunk(const unit16 *a, unit16 *o, u6
     for (int k = 0; k < K; ++k) { u64 i = base + (u64)k * 256; if (i < n) { if (NT) __builtin_nontemporal_store(x[k], o + i); else o[i] = x[k]; } }
 }
 
+__device__ inline u32 xcd_contig(u32 b, u32 n) { const u32 q = n >> 3, r = n & 7u, x = b & 7u; return x * q + min(x, r) + (b >> 3); }
+
+template <bool XCD>
+__global__ void __launch_bounds__(256) read_one(const unit16 *in, u64 n, u32 *sink)
+{
+    const u32 b = XCD ? xcd_contig(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u64 i = (u64)b * 256 + threadIdx.x;
+    u32 acc = i < n ? fold(in[i]) : 0;
+    if (acc == 0x12345678u) sink[threadIdx.x] = acc;
+}
+template <bool XCD, bool NT>
+__global__ void __launch_bounds__(256) and_one(const unit16 *a, const unit16 *b, unit16 *o, u64 n)
+{
+    const u32 blk = XCD ? xcd_contig(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u64 i = (u64)blk * 256 + threadIdx.x;
+    if (i < n) { unit16 r = a[i] & b[i]; if (NT) __builtin_nontemporal_store(r, o + i); else o[i] = r; }
+}
+template <bool XCD, bool NT>
+__global__ void __launch_bounds__(256) copy_one(const unit16 *a, unit16 *o, u64 n)
+{
+    const u32 blk = XCD ? xcd_contig(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u64 i = (u64)blk * 256 + threadIdx.x;
+    if (i < n) { unit16 r = a[i]; if (NT) __builtin_nontemporal_store(r, o + i); else o[i] = r; }
+}
+
 template <typename F>
 void bench(const char *name, double bytes, int rounds, F launch)
 {
@@ -86,6 +111,17 @@ int main(int argc, char **argv)
     CK(hipMemset(a, 0x11, n * 16)); CK(hipMemset(b, 0x33, n * 16));
     const double bytes = (double)n * 16;
     printf("buffers of %.2f GiB\n", gib);
+    {
+        const u32 nb = (u32)((n + 255) / 256);
+        bench("read_one", bytes, rounds, [&] { read_one<false><<<nb, 256>>>(a, n, sink); });
+        bench("read_one xcd-contig", bytes, rounds, [&] { read_one<true><<<nb, 256>>>(a, n, sink); });
+        bench("and_one NT", 3 * bytes, rounds, [&] { and_one<false, true><<<nb, 256>>>(a, b, o, n); });
+        bench("and_one NT xcd-contig", 3 * bytes, rounds, [&] { and_one<true, true><<<nb, 256>>>(a, b, o, n); });
+        bench("copy_one NT", 2 * bytes, rounds, [&] { copy_one<false, true><<<nb, 256>>>(a, o, n); });
+        bench("copy_one NT xcd-contig", 2 * bytes, rounds, [&] { copy_one<true, true><<<nb, 256>>>(a, o, n); });
+        bench("copy_one xcd-contig", 2 * bytes, rounds, [&] { copy_one<true, false><<<nb, 256>>>(a, o, n); });
+    }
+    if (argc > 3) return 0;
 #define RC(K) bench("read_chunk K=" #K, bytes, rounds, [&] { read_chunk<K><<<(u32)((n + 256 * K - 1) / (256 * K)), 256>>>(a, n, sink); })
     RC(1); RC(2); RC(4); RC(8); RC(10); RC(16); RC(32);
     for (int g : {2048, 8192, 32768}) { char nm[64]; snprintf(nm, 64, "read_stride grid=%d", g); bench(nm, bytes, rounds, [&] { read_stride<<<g, 256>>>(a, n, sink); }); }
