@@ -656,3 +656,55 @@ def test_fused_product_decrypt_full_size(hip, oracle):
     mat = hip.download(hip.decrypt_uniform(n, batch, t * t, prod, dmask))
     assert np.array_equal(fused, mat)
     assert list(fused) == [((3 + b) * (5 + 2 * b + (b % 2))) % 2 for b in range(batch)]
+
+
+def test_concurrent_host_threads_on_separate_streams(hip, oracle):
+    """SURVEY 8b threading row: the shim is callable from several host threads at once, each on
+    its own stream (ctypes drops the GIL during the calls); results stay bit-exact."""
+    import threading
+    import torch
+    n, dl = 1247, 20
+    key = make_key(n, 16, 41)
+    dmask = hip.upload(hip.key_mask(n, key))
+    errors = []
+
+    def worker(idx):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(25):
+                    t1, t2 = 3 + (it + idx) % 5, 2 + (it * 7 + idx) % 9
+                    a = oracle.synth(1000 * idx + it, n, 0, t1 * dl)
+                    b = oracle.synth(2000 * idx + it, n, 0, t2 * dl)
+                    da, db = hip.upload(a), hip.upload(b)
+                    prod = hip.mul_uniform(n, 1, t1, t2, da, db)
+                    summ = hip.add_uniform(n, 1, t1, t2, da, db)
+                    bit = hip.decrypt_uniform(n, 1, t1 * t2, prod, dmask)
+                    want_p, _ = oracle.mul(n, a, b)
+                    want_s, _ = oracle.add(a, b)
+                    stream.synchronize()
+                    assert np.array_equal(hip.download(prod), want_p)
+                    assert np.array_equal(hip.download(summ), want_s)
+                    assert hip.download(bit)[0] == oracle.decrypt_canonical(n, key, want_p)
+        except Exception as e:          # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_mul_fresh_batch_one_million(hip, oracle):
+    """BASELINE config 4 per-GPU shape and beyond: 1,048,576 independent 1x1 products."""
+    n, batch, dl = 1247, 1 << 20, 20
+    L = hip.synth_fill(71, n, 0, batch * dl)
+    R = hip.synth_fill(72, n, 0, batch * dl)
+    out = hip.mul_uniform(n, batch, 1, 1, L, R)
+    hl, hr = oracle.synth(71, n, 0, batch * dl), oracle.synth(72, n, 0, batch * dl)
+    assert hip.digest(out) == oracle.digest(hl & hr)
+    got = hip.download(out[-20:])
+    want, _ = oracle.mul(n, hl[-20:], hr[-20:])
+    assert np.array_equal(got, want)
