@@ -155,6 +155,22 @@ class HipPath:
                  self.stream))
         return bits[:batch]
 
+    def compact_ragged(self, n_bits: int, words: torch.Tensor, off: torch.Tensor,
+                       total_terms: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Extension: mod-2 compaction (identical terms cancel in pairs).  Returns (terms, CSR offsets)."""
+        batch = off.numel() - 1
+        dl = self.default_len(n_bits)
+        if total_terms is None:
+            total_terms = int(self.download(off[-1:])[0])
+        out = self.empty_words(max(total_terms * dl, 1))
+        off_out = self.empty_words(batch + 1)
+        scratch = torch.empty(int(self.lib.csgn_compact_scratch_bytes(total_terms)), dtype=torch.uint8,
+                              device=self.device)
+        check(self.lib.csgn_compact_ragged(n_bits, batch, total_terms, _ptr(words), _ptr(off), _ptr(out),
+                                           _ptr(off_out), _ptr(scratch), self.stream))
+        kept = int(self.download(off_out[-1:])[0])
+        return out[: kept * dl], off_out
+
     # -- encrypt ----------------------------------------------------------------------
     def encrypt_explicit(self, n_bits: int, d: int, plain: torch.Tensor, rnd: torch.Tensor,
                          chosen: torch.Tensor, last: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

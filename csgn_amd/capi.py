@@ -59,6 +59,8 @@ SIGNATURES = {
     "csgn_decrypt_combined_scratch_bytes": (C.c_size_t, [u64, u64, u64]),
     "csgn_decrypt_product_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_decrypt_sum_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_compact_scratch_bytes": (C.c_size_t, [u64]),
+    "csgn_compact_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_explicit": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_device_rng": (C.c_int, [u64, u64, u64, vp, vp, vp, u64, vp, vp]),
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),

@@ -423,6 +423,26 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
     return CSGN_OK;
 }
 
+size_t csgn_compact_scratch_bytes(uint64_t total_terms) { return csgn::compact_scratch_bytes(total_terms); }
+
+int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+                        const uint64_t *d_terms, const uint64_t *d_off,
+                        uint64_t *d_out, uint64_t *d_off_out, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_off && d_off_out && d_scratch && ((d_terms && d_out) || total_terms == 0),
+            "null device pointer");
+    hipError_t e = csgn::compact(n_bits, batch, total_terms, (const u64 *)d_terms, (const u64 *)d_off,
+                                 (u64 *)d_out, (u64 *)d_off_out, d_scratch, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "compaction handles fewer than 2^31 ciphertexts and terms per call");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
 int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
                           const uint8_t *d_plain, const uint64_t *d_rnd,
                           const uint32_t *d_chosen, const uint8_t *d_last,

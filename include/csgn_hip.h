@@ -174,6 +174,19 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
                              const uint64_t *d_left, const uint64_t *d_right,
                              const uint64_t *d_mask, uint8_t *d_bits, void *d_scratch, void *stream);
 
+/* EXTENSION, not reference behaviour: mod-2 compaction of term lists.  The
+ * reference's add never reduces (src/Ciphertext.cpp:107-122); because decryption XORs over
+ * terms (src/SecretKey.cpp:139), identical terms cancel in pairs, so every ciphertext may be
+ * replaced by its distinct odd-multiplicity terms without changing Dec under ANY key.  Output
+ * keeps one copy of each such term at the position order of first occurrence; d_off_out
+ * receives the compacted CSR offsets (d_off_out[batch] = terms kept).  d_out needs room for
+ * total_terms*dL words, d_scratch for csgn_compact_scratch_bytes(total_terms) bytes.  Never
+ * called on a parity path. */
+size_t csgn_compact_scratch_bytes(uint64_t total_terms);
+int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+                        const uint64_t *d_terms, const uint64_t *d_off,
+                        uint64_t *d_out, uint64_t *d_off_out, void *d_scratch, void *stream);
+
 /* ------------------------------------------------------------------- encrypt ---- */
 
 /* Batched SecretKey::encrypt (bit vector src/SecretKey.cpp:35-80, MSB-first packing

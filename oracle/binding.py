@@ -119,6 +119,8 @@ class Oracle:
         L.csgn_oracle_permute_ciphertext.argtypes = [u64, u64p, u64p, u64, u64p, u64p]
         L.csgn_oracle_permute_key.restype = u64
         L.csgn_oracle_permute_key.argtypes = [u64, u64p, u64p, u64, u64p]
+        L.csgn_oracle_compact.restype = u64
+        L.csgn_oracle_compact.argtypes = [u64, u64p, u64, u64p]
         L.csgn_oracle_synth_word.restype = u64
         L.csgn_oracle_synth_word.argtypes = [u64, u64]
         L.csgn_oracle_synth_fill.restype = None
@@ -247,6 +249,15 @@ class Oracle:
         out = np.zeros(key.size, dtype=np.uint64)
         cnt = int(self.lib.csgn_oracle_permute_key(n_bits, _p64(perm), _p64(key), key.size, _p64(out)))
         return out[:cnt]
+
+    # -- extension checker ----------------------------------------------------------
+    def compact(self, n_bits: int, v) -> np.ndarray:
+        """Mod-2 compaction (extension, not reference behaviour)."""
+        v = as_u64(v)
+        dl = self.default_len(n_bits)
+        out = np.zeros(max(v.size, 1), dtype=np.uint64)
+        kept = int(self.lib.csgn_oracle_compact(dl, _p64(v), v.size // dl, _p64(out)))
+        return out[: kept * dl].copy()
 
     # -- harness helpers ------------------------------------------------------------
     def synth(self, seed: int, n_bits: int, first_word: int, n_words: int) -> np.ndarray:

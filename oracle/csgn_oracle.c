@@ -426,6 +426,48 @@ uint64_t csgn_oracle_permute_key(uint64_t n_bits, const uint64_t *perm,
     return count;
 }
 
+/* ------------------------------------------------ extension checker: compact ---- */
+
+static uint64_t g_cmp_dl;
+static const uint64_t *g_cmp_base;
+
+static int cmp_term_index(const void *pa, const void *pb)
+{
+    const uint64_t a = *(const uint64_t *)pa, b = *(const uint64_t *)pb;
+    int c = memcmp(g_cmp_base + a * g_cmp_dl, g_cmp_base + b * g_cmp_dl, g_cmp_dl * sizeof(uint64_t));
+    if (c)
+        return c;
+    return (a > b) - (a < b);            /* equal terms: ascending index */
+}
+
+uint64_t csgn_oracle_compact(uint64_t dl, const uint64_t *v, uint64_t terms, uint64_t *out)
+{
+    if (terms == 0 || dl == 0)
+        return 0;
+    uint64_t *idx = (uint64_t *)malloc(terms * sizeof(uint64_t));
+    uint8_t *keep = (uint8_t *)calloc(terms, 1);
+    for (uint64_t i = 0; i < terms; ++i)
+        idx[i] = i;
+    g_cmp_dl = dl;
+    g_cmp_base = v;
+    qsort(idx, terms, sizeof(uint64_t), cmp_term_index);
+    for (uint64_t s = 0; s < terms;) {
+        uint64_t e = s + 1;
+        while (e < terms && memcmp(v + idx[s] * dl, v + idx[e] * dl, dl * sizeof(uint64_t)) == 0)
+            ++e;
+        if ((e - s) & 1u)
+            keep[idx[s]] = 1;            /* first occurrence of an odd-multiplicity term */
+        s = e;
+    }
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < terms; ++i)
+        if (keep[i])
+            memcpy(out + (kept++) * dl, v + i * dl, dl * sizeof(uint64_t));
+    free(idx);
+    free(keep);
+    return kept;
+}
+
 /* ---------------------------------------------------------- harness helpers ---- */
 
 uint64_t csgn_oracle_synth_word(uint64_t seed, uint64_t idx)

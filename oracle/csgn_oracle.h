@@ -98,6 +98,13 @@ uint64_t csgn_oracle_permute_ciphertext(uint64_t n_bits, const uint64_t *perm,
 uint64_t csgn_oracle_permute_key(uint64_t n_bits, const uint64_t *perm,
                                  const uint64_t *key, uint64_t d, uint64_t *new_key);
 
+/* ---- EXTENSION checker (not reference behaviour) ------------------------
+ * Mod-2 compaction of a term list: a term that occurs an even number of times vanishes, one
+ * that occurs an odd number of times is kept once, at the position of its first occurrence.
+ * Decryption is unchanged for every key (XOR over terms).  Returns the number of terms kept;
+ * out must hold terms*dL words. */
+uint64_t csgn_oracle_compact(uint64_t dl, const uint64_t *v, uint64_t terms, uint64_t *out);
+
 /* ---- harness helpers shared with the HIP side (definitions, not reference code) ---
  * Synthetic operand words: word idx of a flat term buffer is
  * splitmix64(seed + GOLDEN*(idx+1)); the last word of every term keeps only its top

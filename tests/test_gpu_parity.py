@@ -708,3 +708,52 @@ def test_mul_fresh_batch_one_million(hip, oracle):
     got = hip.download(out[-20:])
     want, _ = oracle.mul(n, hl[-20:], hr[-20:])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (63, 4)])
+def test_compaction_extension(hip, oracle, n, d):
+    """EXTENSION, not reference behaviour: mod-2 compaction.  Checked against the
+    extension's own CPU checker (exact term list) and, more importantly, for the property that
+    makes it legal: Dec is unchanged under ANY key."""
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n)
+    # ragged batch with planted duplicates: pools of distinct terms drawn with repetition
+    cts = []
+    for b, (pool, draws) in enumerate([(1, 2), (1, 3), (5, 40), (300, 1000), (0, 0), (64, 64), (7, 1)]):
+        if draws == 0:
+            cts.append(np.zeros(0, dtype=np.uint64))
+            continue
+        base = oracle.synth(500 + b, n, 0, pool * dl).reshape(pool, dl)
+        idx = rng.integers(0, pool, size=draws)
+        cts.append(np.ascontiguousarray(base[idx].reshape(-1)))
+    off = csr([c.size // dl for c in cts])
+    flat = np.concatenate(cts)
+    out, off_out = hip.compact_ragged(n, hip.upload(flat), hip.upload(off))
+    out, off_out = hip.download(out), hip.download(off_out)
+    keys = [make_key(n, d, 90 + i) for i in range(3)]
+    for b, ct in enumerate(cts):
+        got = out[int(off_out[b]) * dl:int(off_out[b + 1]) * dl]
+        want = oracle.compact(n, ct)
+        assert np.array_equal(got, want), b
+        rows = got.reshape(-1, dl)
+        assert len({r.tobytes() for r in rows}) == rows.shape[0]          # all distinct
+        for key in keys:
+            assert oracle.decrypt_canonical(n, key, got) == oracle.decrypt_canonical(n, key, ct)
+    assert int(off_out[1]) - int(off_out[0]) == 0      # x + x cancels completely
+    assert int(off_out[2]) - int(off_out[1]) == 1      # x + x + x leaves x
+
+
+def test_compaction_of_squared_sum(hip, oracle):
+    """(a+b)*(a+b) = a*a + a*b + b*a + b*b: the two cross terms are bit-identical (AND commutes)
+    and cancel; the GPU decryption of the compacted ciphertext still equals Dec(a+b)."""
+    n, d, dl = 1247, 16, 20
+    key = make_key(n, d, 7)
+    dmask = hip.upload(hip.key_mask(n, key))
+    plain = np.array([1, 0], dtype=np.uint8)
+    fresh = hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=3)
+    s = hip.add_uniform(n, 1, 1, 1, fresh[:dl], fresh[dl:])
+    sq = hip.mul_uniform(n, 1, 2, 2, s, s)
+    out, off_out = hip.compact_ragged(n, sq, hip.upload(csr([4])))
+    assert hip.download(off_out).tolist() == [0, 2]
+    bit = hip.download(hip.decrypt_uniform(n, 1, 2, out, dmask))[0]
+    assert bit == hip.download(hip.decrypt_uniform(n, 1, 4, sq, dmask))[0] == 1
