@@ -613,6 +613,168 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
 // holds its source bit, one AND with its bit mask, the compare that forms the ballot, and
 // two v_writelane that drop the ballot into lane w -- all reads of a term are issued
 // before the first ballot so LDS latency overlaps.
+// encrypt, fast form: the same K-aligned-segments structure as k_term_hits_seg.  One lane per
+// 16-byte (or 8-byte) unit, K passes, TB whole ciphertexts per workgroup, everything a lane
+// needs stays in registers; the only cross-lane fact -- "do all OTHER secret positions of my
+// ciphertext hold 1?" (src/SecretKey.cpp:60-76) -- is decided from two __ballot bit strings in
+// LDS exactly like a decrypt verdict.  No staging of the words through LDS, 16-byte stores.
+template <int VEC>
+struct UnitWords {
+    u64 w[VEC];
+};
+__device__ inline UnitWords<2> unit_to_words(unit16 v)
+{
+    UnitWords<2> r;
+    r.w[0] = ((u64)v.y << 32) | v.x;
+    r.w[1] = ((u64)v.w << 32) | v.z;
+    return r;
+}
+__device__ inline UnitWords<1> unit_to_words(unit8 v)
+{
+    UnitWords<1> r;
+    r.w[0] = v;
+    return r;
+}
+__device__ inline void words_to_unit(const UnitWords<2> &r, unit16 &v)
+{
+    v.x = (u32)r.w[0];
+    v.y = (u32)(r.w[0] >> 32);
+    v.z = (u32)r.w[1];
+    v.w = (u32)(r.w[1] >> 32);
+}
+__device__ inline void words_to_unit(const UnitWords<1> &r, unit8 &v) { v = r.w[0]; }
+
+template <typename Unit, int K, bool DEVRNG>
+__global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, FastDiv dU, u64 D, u64 batch,
+                                                     u32 TB, const uint8_t *__restrict__ plain,
+                                                     const Unit *__restrict__ rnd,
+                                                     const u32 *__restrict__ chosen,
+                                                     const uint8_t *__restrict__ last,
+                                                     const u64 *__restrict__ key,
+                                                     const Unit *__restrict__ mask, u64 seed,
+                                                     Unit *__restrict__ out)
+{
+    constexpr int VEC = sizeof(Unit) / 8;
+    __shared__ u32 s_pos[256];                  // chosen position of ciphertext t, ~0u = none (plaintext 1)
+    __shared__ unsigned char s_spare[256], s_plain[256], s_clear[256];
+    __shared__ u64 others_bits[K * 4 + 1], fail_bits[K * 4 + 1];
+
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const u64 c0 = (u64)blockIdx.x * TB;                       // first ciphertext of this workgroup
+    const u32 nct = (u32)min((u64)TB, batch - c0);
+    const u32 rem = (u32)(n_bits & 63);
+    const u64 tail = rem ? ~0ull << (64 - rem) : ~0ull;
+
+    if (tid < TB) {
+        u32 pos = 0xFFFFFFFFu;
+        unsigned char sp = 0, pl = 1;
+        if (tid < nct) {
+            const u64 c = c0 + tid;
+            pl = plain[c] & 1u;
+            if (!pl) {
+                if (DEVRNG) {
+                    pos = (u32)key[csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1)) % D];
+                    sp = (unsigned char)((csgn_splitmix64((seed ^ 0x8CB92BA72F3D8DD7ull) + CSGN_GOLDEN * (c + 1)) >> 32) & 1u);
+                } else {
+                    pos = chosen[c];
+                    sp = last[c] & 1u;
+                }
+                if (pos >= n_bits)
+                    pos = 0xFFFFFFFFu;                         // invalid input: leave the words alone
+            }
+        }
+        s_pos[tid] = pos;
+        s_spare[tid] = sp;
+        s_plain[tid] = pl;
+    }
+    if (tid == 0) {
+        others_bits[K * 4] = 0;
+        fail_bits[K * 4] = 0;
+    }
+    __syncthreads();
+
+    const u64 last_unit = batch * (u64)U - 1;
+    UnitWords<VEC> w[K], m[K];
+    u32 tk[K];                                                // (term << 16) | unit-in-term
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u32 local = (u32)j * 256u + tid;
+        const u32 t = csgn_fastdiv(local, dU), k = local - t * U;
+        tk[j] = (t << 16) | k;
+        m[j] = unit_to_words(mask[k]);
+        const u64 g = min(c0 * U + local, last_unit);          // global unit index (clamped)
+        if (DEVRNG) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                w[j].w[q] = csgn_splitmix64(seed + CSGN_GOLDEN * (g * VEC + q + 1));
+        } else {
+            w[j] = unit_to_words(rnd[g]);
+        }
+        if (k == U - 1)
+            w[j].w[VEC - 1] &= tail;                           // padding bits of the last word stay 0
+    }
+    // per unit: does it hold secret positions other than the chosen one, and are they all 1?
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u32 t = tk[j] >> 16, k = tk[j] & 0xFFFFu;
+        const u32 pos = s_pos[t];
+        bool others = false, fail = false;
+        if (t < nct && pos != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                u64 mm = m[j].w[q];
+                if ((pos >> 6) == k * VEC + (u32)q)
+                    mm &= ~(1ull << (63u - (pos & 63u)));
+                others = others || (mm != 0);
+                fail = fail || ((w[j].w[q] & mm) != mm);
+            }
+        }
+        const u64 bo = __ballot(others), bf = __ballot(fail);
+        if (lane == 0) {
+            others_bits[j * 4 + wave] = bo;
+            fail_bits[j * 4 + wave] = bf;
+        }
+    }
+    __syncthreads();
+    if (tid < TB) {
+        const u32 start = tid * U, wd = start >> 6, sh = start & 63u;
+        u64 vo = others_bits[wd] >> sh, vf = fail_bits[wd] >> sh;
+        if (sh) {
+            vo |= others_bits[wd + 1] << (64u - sh);
+            vf |= fail_bits[wd + 1] << (64u - sh);
+        }
+        const u64 need = (U >= 64u) ? ~0ull : ((1ull << U) - 1ull);
+        // src/SecretKey.cpp:73-76: clear the chosen slot iff other secret slots exist and are all 1
+        s_clear[tid] = ((vo & need) != 0 && (vf & need) == 0) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u32 t = tk[j] >> 16, k = tk[j] & 0xFFFFu;
+        if (t < nct) {
+            if (s_plain[t]) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q)
+                    w[j].w[q] |= m[j].w[q];                    // src/SecretKey.cpp:44-45
+            } else {
+                const u32 pos = s_pos[t];
+                if (pos != 0xFFFFFFFFu && (pos >> 6) / VEC == k) {
+                    const u32 q = (pos >> 6) - k * VEC;
+                    const u64 bit = 1ull << (63u - (pos & 63u));
+                    const u64 newbit = s_clear[t] ? 0ull : (s_spare[t] ? bit : 0ull);
+#pragma unroll
+                    for (int qq = 0; qq < VEC; ++qq)
+                        if ((u32)qq == q)
+                            w[j].w[qq] = (w[j].w[qq] & ~bit) | newbit;
+                }
+            }
+            Unit v;
+            words_to_unit(w[j], v);
+            unit_store<Unit, true>(out + c0 * U + (u32)j * 256u + tid, v);
+        }
+    }
+}
+
 // v_writelane_b32: drop a wave-uniform 64-bit value into ONE lane of a VGPR pair (hipcc 7.2
 // exposes no builtin for it).  `lane` must be a compile-time constant.  The s_nop is the
 // gfx940+ "VALU writes SGPR -> VALU reads that SGPR" hazard (2 wait states): the ballot is
@@ -1376,6 +1538,56 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0)
         return hipSuccess;
+    // fast form: K aligned 4 KiB segments = TB whole ciphertexts per workgroup, one lane per unit
+    {
+        const bool wide = (dL % 2 == 0) && aligned16(out) && aligned16(mask) && (device_rng || aligned16(rnd));
+        const u32 U = (u32)(wide ? dL / 2 : dL);
+        int k_seg = 0;
+        if (U <= 64u)
+            for (int k = 1; k <= 8; ++k)
+                if ((256u * k) % U == 0 && (256u * k) / U <= 256u) {
+                    k_seg = k;
+                    break;
+                }
+        if (k_seg && env_int("CSGN_ENC_LDS", 0) == 0) {
+            const u32 tb = 256u * k_seg / U;
+            const u64 nblk = (batch + tb - 1) / tb;
+            if (nblk > (1ull << 31) - 1)
+                return hipErrorInvalidValue;
+            const FastDiv dU = csgn_fastdiv_make(U);
+#define CSGN_ENC_SEG(UNIT, K)                                                                           \
+    do {                                                                                                \
+        if (device_rng)                                                                                 \
+            k_encrypt_seg<UNIT, K, true><<<(u32)nblk, 256, 0, s>>>(                                      \
+                n_bits, (u32)dL, U, dU, d, batch, tb, plain, reinterpret_cast<const UNIT *>(rnd), chosen, \
+                last, key, reinterpret_cast<const UNIT *>(mask), seed, reinterpret_cast<UNIT *>(out));   \
+        else                                                                                            \
+            k_encrypt_seg<UNIT, K, false><<<(u32)nblk, 256, 0, s>>>(                                     \
+                n_bits, (u32)dL, U, dU, d, batch, tb, plain, reinterpret_cast<const UNIT *>(rnd), chosen, \
+                last, key, reinterpret_cast<const UNIT *>(mask), seed, reinterpret_cast<UNIT *>(out));   \
+    } while (0)
+#define CSGN_ENC_SEG_K(UNIT)                                       \
+    switch (k_seg) {                                               \
+    case 1: CSGN_ENC_SEG(UNIT, 1); break;                          \
+    case 2: CSGN_ENC_SEG(UNIT, 2); break;                          \
+    case 3: CSGN_ENC_SEG(UNIT, 3); break;                          \
+    case 4: CSGN_ENC_SEG(UNIT, 4); break;                          \
+    case 5: CSGN_ENC_SEG(UNIT, 5); break;                          \
+    case 6: CSGN_ENC_SEG(UNIT, 6); break;                          \
+    case 7: CSGN_ENC_SEG(UNIT, 7); break;                          \
+    default: CSGN_ENC_SEG(UNIT, 8); break;                         \
+    }
+            if (wide) {
+                CSGN_ENC_SEG_K(unit16)
+            } else {
+                CSGN_ENC_SEG_K(unit8)
+            }
+#undef CSGN_ENC_SEG_K
+#undef CSGN_ENC_SEG
+            return hipGetLastError();
+        }
+    }
+    // general form (term sizes that do not pack): ciphertexts staged in LDS
     u32 cb = 64;
     while (cb > 1 && (u64)cb * dL * 8 > 32768)
         cb /= 2;

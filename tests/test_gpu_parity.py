@@ -757,3 +757,19 @@ def test_compaction_of_squared_sum(hip, oracle):
     assert hip.download(off_out).tolist() == [0, 2]
     bit = hip.download(hip.decrypt_uniform(n, 1, 2, out, dmask))[0]
     assert bit == hip.download(hip.decrypt_uniform(n, 1, 4, sq, dmask))[0] == 1
+
+
+@pytest.mark.parametrize("lds", [0, 1])
+def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, monkeypatch, lds):
+    """Both encrypt kernels (register/ballot segments; LDS-staged general form) against the
+    genuine reference's fresh ciphertexts, plus agreement of the two device-RNG streams."""
+    monkeypatch.setenv("CSGN_ENC_LDS", str(lds))
+    test_encrypt_explicit_reproduces_reference_ciphertexts(hip, oracle, kat)
+    n, d = 1247, 16
+    key = make_key(n, d, 6)
+    dmask = hip.upload(hip.key_mask(n, key))
+    plain = np.random.default_rng(1).integers(0, 2, size=5000).astype(np.uint8)
+    mine = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
+    monkeypatch.setenv("CSGN_ENC_LDS", str(1 - lds))
+    other = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
+    assert np.array_equal(mine, other)

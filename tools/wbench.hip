@@ -71,6 +71,24 @@ __global__ void __launch_bounds__(512) fill_rows(unit16 *o, u32 cu, u32 rows_tot
     for (u64 i = threadIdx.x; i < n; i += BS) { if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
 }
 
+// F: 4 rows x 4 KiB tile per 256-thread block, but wave w owns ROW w and writes its 4 KiB as four
+// consecutive 1 KiB stores (instead of every wave writing 1 KiB of each row)
+template <bool NT>
+__global__ void __launch_bounds__(256) fill_tile_wave_rows(unit16 *o, u32 cu, u32 rows_total, u32 col_tiles, u32 row_tiles, unit16 v)
+{
+    const u32 tiles = col_tiles * row_tiles;
+    const u32 pair = blockIdx.x / tiles;
+    const u32 tile = blockIdx.x - pair * tiles;
+    const u32 row_tile = tile / col_tiles, col_tile = tile - row_tile * col_tiles;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 row = row_tile * 4 + wave;
+    if (row >= rows_total) return;
+    unit16 *p = o + (u64)pair * rows_total * cu + (u64)row * cu + col_tile * 256 + lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (col_tile * 256 + k * 64 + lane < cu) { if (NT) __builtin_nontemporal_store(v, p + k * 64); else p[k * 64] = v; }
+}
+
 // E: one store per lane, block size BS, optional XCD-contiguous remap of the chunk order
 template <bool NT, int REMAP>
 __global__ void __launch_bounds__(1024) fill_one(unit16 *o, u64 n, unit16 v, u32 nblocks)
@@ -126,6 +144,13 @@ int main(int argc, char **argv)
     bench("fill_chunk K=16 NT", bytes, rounds, [&] { fill_chunk<16, true><<<(u32)((n + 4095) / 4096), 256>>>(o, n, v); });
     bench("fill_chunk K=64", bytes, rounds, [&] { fill_chunk<64, false><<<(u32)((n + 16383) / 16384), 256>>>(o, n, v); });
 
+    {
+        u32 ct = (cu + 255) / 256, rt = (T + 3) / 4;
+        bench("fill_tiled bs=256 M=1 TI=4 (lane cols)", bytes, rounds, [&] { fill_tiled<1, false><<<slots * ct * rt, 256>>>(o, cu, T, 4, ct, rt, v); });
+        bench("fill_tiled bs=256 M=1 TI=4 NT", bytes, rounds, [&] { fill_tiled<1, true><<<slots * ct * rt, 256>>>(o, cu, T, 4, ct, rt, v); });
+        bench("fill_tile_wave_rows", bytes, rounds, [&] { fill_tile_wave_rows<false><<<slots * ct * rt, 256>>>(o, cu, T, ct, rt, v); });
+        bench("fill_tile_wave_rows NT", bytes, rounds, [&] { fill_tile_wave_rows<true><<<slots * ct * rt, 256>>>(o, cu, T, ct, rt, v); });
+    }
     for (u32 bs : {256u, 512u, 1024u}) {
         const u32 nb = (u32)(n / bs);
         char nm[64];
