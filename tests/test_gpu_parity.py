@@ -773,3 +773,44 @@ def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, monkeypatch,
     monkeypatch.setenv("CSGN_ENC_LDS", str(1 - lds))
     other = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
     assert np.array_equal(mine, other)
+
+
+def test_config3_depth10_chain_then_1024x1024(hip, oracle):
+    """BASELINE config 3: a depth-10 multiply chain x <- x * (Enc(b) + Enc(b')) grows a fresh
+    ciphertext to 2^10 = 1024 terms; two such chains are then multiplied (1024 x 1024 terms).
+    Run as a batch on the GPU; every stage checked against the plaintext circuit, the final
+    operands and the 1M-term product against the oracle."""
+    n, d, dl, B = 1247, 16, 20, 3
+    key = make_key(n, d, 51)
+    dmask = hip.upload(hip.key_mask(n, key))
+    rng = np.random.default_rng(52)
+
+    def chain(seed):
+        per = 1 + 20
+        plain = rng.integers(0, 2, size=(per, B)).astype(np.uint8)
+        fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), hip.upload(key), dmask, seed=seed)
+        inp = lambda i: fresh[i * B * dl:(i + 1) * B * dl]
+        x, xt, xb = inp(0), 1, plain[0].copy()
+        for level in range(10):
+            rhs = hip.add_uniform(n, B, 1, 1, inp(1 + 2 * level), inp(2 + 2 * level))
+            x = hip.mul_uniform(n, B, xt, 2, x, rhs)
+            xt *= 2
+            xb &= plain[1 + 2 * level] ^ plain[2 + 2 * level]
+            assert np.array_equal(hip.download(hip.decrypt_uniform(n, B, xt, x, dmask)), xb), level
+        # oracle replay of circuit 0
+        hf = hip.download(fresh).reshape(per, B, dl)
+        hx = hf[0, 0]
+        for level in range(10):
+            r, _ = oracle.add(hf[1 + 2 * level, 0], hf[2 + 2 * level, 0])
+            hx, _ = oracle.mul(n, hx, r)
+        assert xt == 1024 and np.array_equal(hip.download(x[:1024 * dl]), hx)
+        return x, xb, hx
+
+    xa, ba, ha = chain(101)
+    xc, bc, hc = chain(202)
+    prod = hip.mul_uniform(n, B, 1024, 1024, xa, xc)
+    bits = hip.download(hip.decrypt_uniform(n, B, 1024 * 1024, prod, dmask))
+    assert np.array_equal(bits, ba & bc)
+    assert np.array_equal(bits, hip.download(hip.decrypt_combined_uniform(n, B, 1024, 1024, xa, xc, dmask, True)))
+    want, _ = oracle.mul(n, ha, hc)
+    assert hip.digest(prod[:1024 * 1024 * dl]) == oracle.digest(want)
