@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=1024, help="terms per operand")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU baseline batch-parallel on every host core "
+                         "(extra 'cpu_baseline_all_cores' object; BASELINE.md section 4, mode 2)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the term-count all-gather even with one rank "
@@ -90,6 +93,46 @@ def cpu_baseline(terms: int, budget_s: float):
     }
 
 
+def _cpu_worker(args):
+    terms, iters = args
+    from oracle import binding
+    orc = binding.Oracle()
+    dl = orc.default_len(N_BITS)
+    a = orc.synth(SEED + 1, N_BITS, 0, terms * dl)
+    b = orc.synth(SEED + 2, N_BITS, 0, terms * dl)
+    ref = binding.load_ref()
+    t0 = time.perf_counter()
+    if ref is not None:
+        ref.time_mul(N_BITS, D_KEY, a, b, iters)
+    else:
+        for _ in range(iters):
+            orc.mul_reference_cost(N_BITS, a, b)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(terms: int, per_core_rate: float, budget_s: float):
+    """The same single-threaded product, one independent stream of pairs per host core
+    (the reference has no threading of its own; this is the batch-parallel upper bound).
+    Workers are plain child processes of this script (`--cpu-worker`), no GPU, no torch."""
+    import subprocess
+    from oracle import binding
+    cores = len(os.sched_getaffinity(0))
+    iters = max(1, int(per_core_rate * budget_s * 0.5))      # memory-bound: expect < linear scaling
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(terms), str(iters)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(cores)]
+    ok = all(p.wait(timeout=600) == 0 for p in procs)
+    wall = time.perf_counter() - t0
+    return {
+        "value": cores * iters / wall if ok else None,
+        "unit": "mult/s",
+        "cores": cores,
+        "kind": "reference" if binding.load_ref() is not None else "port",
+        "sample": f"{cores} processes x {iters} x ({terms}x{terms}-term c*c) in {wall:.2f}s wall "
+                  f"(process start-up included)",
+    }
+
+
 def measured_traffic(kernel: str, terms: int, pairs_per_launch: float):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile
     (profiles/traffic_current.json, produced by tools/prof_pmc.sh + tools/pmc_summary.py).
@@ -107,6 +150,9 @@ def measured_traffic(kernel: str, terms: int, pairs_per_launch: float):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":      # child of cpu_baseline_all_cores
+        _cpu_worker((int(sys.argv[2]), int(sys.argv[3])))
+        return
     args = parse_args()
     import numpy as np
     import torch
@@ -253,6 +299,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.cpu_seconds)
+            if args.cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
+                    T, out["cpu_baseline"]["value"], args.cpu_seconds)
         print(json.dumps(out))
 
     if use_dist:
