@@ -376,7 +376,8 @@ template <typename Unit, int K>
 __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ terms,
                                                        const Unit *__restrict__ mask,
                                                        u64 total_units, u32 U, FastDiv dU, u32 TB,
-                                                       unsigned char *__restrict__ hits)
+                                                       unsigned char *__restrict__ hits,
+                                                       uint8_t *__restrict__ direct_bits)
 {
     __shared__ u64 ok_bits[K * 4 + 1];
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -417,6 +418,12 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
         if (sh)
             v |= ok_bits[w + 1] << (64u - sh);
         const bool hit = (v & need) == need;
+        if (direct_bits) {                        // single-term ciphertexts: the verdict IS the plaintext
+            const u64 term = (u64)bid * TB + t;
+            if (term * U < total_units)
+                direct_bits[term] = hit ? 1 : 0;
+            continue;
+        }
         const u64 hb = __ballot(hit);             // lanes past TB are not in this iteration
         if (lane == 0) {
             const u32 first = t;                  // first term of this wave's group
@@ -1233,14 +1240,17 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
                 return hipErrorInvalidValue;
             unsigned char *hb = reinterpret_cast<unsigned char *>(scratch);
             const u64 tu = total_terms * U;
+            // fresh (single-term) ciphertexts in a uniform batch: pass 1 writes the plaintext
+            // bytes itself and pass 2 is skipped
+            uint8_t *direct = (!off && terms_uniform == 1) ? bits : nullptr;
 #define CSGN_HITS_SEG(K)                                                                              \
     do {                                                                                              \
         if (wide)                                                                                     \
             k_term_hits_seg<unit16, K><<<(u32)nblk, 256, 0, s>>>(                                     \
                 reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask), tu, U, \
-                dU, tb, hb);                                                                          \
+                dU, tb, hb, direct);                                                                  \
         else                                                                                          \
-            k_term_hits_seg<unit8, K><<<(u32)nblk, 256, 0, s>>>(terms, mask, tu, U, dU, tb, hb);      \
+            k_term_hits_seg<unit8, K><<<(u32)nblk, 256, 0, s>>>(terms, mask, tu, U, dU, tb, hb, direct); \
     } while (0)
             switch (k_seg) {
             case 1: CSGN_HITS_SEG(1); break;
@@ -1253,6 +1263,8 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
             default: CSGN_HITS_SEG(8); break;
             }
 #undef CSGN_HITS_SEG
+            if (direct)
+                return hipGetLastError();
         } else if (wide)
             k_term_hits<unit16><<<blocks, 256, (size_t)U * 16 + 1024, s>>>(
                 reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask),
