@@ -89,6 +89,25 @@ __global__ void __launch_bounds__(256) fill_tile_wave_rows(unit16 *o, u32 cu, u3
         if (col_tile * 256 + k * 64 + lane < cu) { if (NT) __builtin_nontemporal_store(v, p + k * 64); else p[k * 64] = v; }
 }
 
+// G: persistent grid-stride writers, but each wave keeps at most W+1 stores in flight
+template <int W, bool XCD>
+__global__ void __launch_bounds__(256) fill_stride_throttled(unit16 *o, u64 n, unit16 v)
+{
+    u32 b = blockIdx.x;
+    if (XCD) { const u32 q = gridDim.x >> 3, r = gridDim.x & 7u, x = b & 7u; b = x * q + min(x, r) + (b >> 3); }
+    // XCD variant: block b of XCD x sweeps the x-th eighth of the buffer with stride = blocks per XCD
+    const u64 per = XCD ? (n / 8) : n;
+    const u64 base = XCD ? (u64)(blockIdx.x & 7u) * per : 0;
+    const u64 nb = XCD ? (gridDim.x >> 3) : gridDim.x;
+    const u64 me = XCD ? (blockIdx.x >> 3) : blockIdx.x;
+    for (u64 i = me * 256 + threadIdx.x; i < per; i += nb * 256) {
+        o[base + i] = v;
+        if (W == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (W == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (W == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
+}
+
 // E: one store per lane, block size BS, optional XCD-contiguous remap of the chunk order
 template <bool NT, int REMAP>
 __global__ void __launch_bounds__(1024) fill_one(unit16 *o, u64 n, unit16 v, u32 nblocks)
@@ -150,6 +169,14 @@ int main(int argc, char **argv)
         bench("fill_tiled bs=256 M=1 TI=4 NT", bytes, rounds, [&] { fill_tiled<1, true><<<slots * ct * rt, 256>>>(o, cu, T, 4, ct, rt, v); });
         bench("fill_tile_wave_rows", bytes, rounds, [&] { fill_tile_wave_rows<false><<<slots * ct * rt, 256>>>(o, cu, T, ct, rt, v); });
         bench("fill_tile_wave_rows NT", bytes, rounds, [&] { fill_tile_wave_rows<true><<<slots * ct * rt, 256>>>(o, cu, T, ct, rt, v); });
+    }
+    for (int g : {2048, 4096, 8192}) {
+        char nm[64];
+        snprintf(nm, 64, "fill_stride_thr W=0 grid=%d", g); bench(nm, bytes, rounds, [&] { fill_stride_throttled<0, false><<<g, 256>>>(o, n, v); });
+        snprintf(nm, 64, "fill_stride_thr W=1 grid=%d", g); bench(nm, bytes, rounds, [&] { fill_stride_throttled<1, false><<<g, 256>>>(o, n, v); });
+        snprintf(nm, 64, "fill_stride_thr W=3 grid=%d", g); bench(nm, bytes, rounds, [&] { fill_stride_throttled<3, false><<<g, 256>>>(o, n, v); });
+        snprintf(nm, 64, "fill_stride_thr W=0 xcd grid=%d", g); bench(nm, bytes, rounds, [&] { fill_stride_throttled<0, true><<<g, 256>>>(o, n, v); });
+        snprintf(nm, 64, "fill_stride_thr W=1 xcd grid=%d", g); bench(nm, bytes, rounds, [&] { fill_stride_throttled<1, true><<<g, 256>>>(o, n, v); });
     }
     for (u32 bs : {256u, 512u, 1024u}) {
         const u32 nb = (u32)(n / bs);
