@@ -814,3 +814,61 @@ def test_config3_depth10_chain_then_1024x1024(hip, oracle):
     assert np.array_equal(bits, hip.download(hip.decrypt_combined_uniform(n, B, 1024, 1024, xa, xc, dmask, True)))
     want, _ = oracle.mul(n, ha, hc)
     assert hip.digest(prod[:1024 * 1024 * dl]) == oracle.digest(want)
+
+
+@pytest.mark.parametrize("n,d,seed", [(1247, 16, 1), (4096, 32, 2), (65, 4, 3), (63, 4, 4)])
+def test_fuzz_random_operation_sequences(hip, oracle, n, d, seed):
+    """Seeded random walk over the whole C ABI: a pool of device-resident ciphertexts and its
+    host twin (oracle) are driven through 150 random mul / add / permute / compact / decrypt
+    steps; words and plaintext bits must agree after every step."""
+    rng = np.random.default_rng(seed)
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 60 + seed)
+    dmask = hip.upload(hip.key_mask(n, key))
+    perm = rng.permutation(n).astype(np.uint64)
+    dperm = hip.upload(perm.astype(np.uint32))
+    pkey = oracle.permute_key(n, perm, key)
+    dpmask = hip.upload(hip.key_mask(n, pkey))
+    plain = rng.integers(0, 2, size=8).astype(np.uint8)
+    fresh = hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=seed)
+    pool = [(fresh[i * dl:(i + 1) * dl], hip.download(fresh[i * dl:(i + 1) * dl]).copy(), int(plain[i])) for i in range(8)]
+    for step in range(150):
+        op = rng.choice(["mul", "add", "add", "permute", "compact", "decrypt"])
+        i, j = rng.integers(0, len(pool), size=2)
+        (da, ha, ba), (db, hb, bb) = pool[i], pool[j]
+        ta, tb = ha.size // dl, hb.size // dl
+        if op == "mul" and ta * tb <= 4096 and ta and tb:
+            dev = hip.mul_uniform(n, 1, ta, tb, da, db)
+            host, _ = oracle.mul(n, ha, hb)
+            pool.append((dev, host, ba & bb))
+        elif op == "add" and ta + tb <= 4096:
+            dev = hip.add_uniform(n, 1, ta, tb, da, db)
+            host, _ = oracle.add(ha, hb)
+            pool.append((dev, host, ba ^ bb))
+        elif op == "permute" and ta >= 1:
+            dev = hip.permute_uniform(n, 1, ta, da, dperm)            # reference semantics: first term only
+            host = oracle.permute_ciphertext(n, perm, ha)
+            assert np.array_equal(hip.download(dev), host)
+            got = hip.download(hip.decrypt_uniform(n, 1, 1, dev, dpmask))[0]
+            assert got == oracle.decrypt_canonical(n, pkey, host)
+            continue
+        elif op == "compact" and ta >= 1:
+            dev, off_out = hip.compact_ragged(n, da, hip.upload(csr([ta])))
+            host = oracle.compact(n, ha)
+            assert np.array_equal(hip.download(dev), host)
+            if host.size:
+                pool.append((dev, host, ba))
+        else:
+            if ta:
+                assert hip.download(hip.decrypt_uniform(n, 1, ta, da, dmask))[0] == oracle.decrypt_canonical(n, key, ha)
+            continue
+        dev, host, bit = pool[-1]
+        assert np.array_equal(hip.download(dev), host), (step, op)
+        t = host.size // dl
+        if t:
+            got = hip.download(hip.decrypt_uniform(n, 1, t, dev, dmask))[0]
+            assert got == oracle.decrypt_canonical(n, key, host)
+            if d > 1:
+                assert got == bit, (step, op)
+        if len(pool) > 40:
+            pool = pool[:8] + pool[-16:]
