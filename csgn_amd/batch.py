@@ -93,7 +93,7 @@ class HipPath:
         total, max_t1, max_t2 = int(plan[0]), int(plan[1]), int(plan[2])
         out = self.empty_words(max(total * dl, 1))
         check(self.lib.csgn_mul_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
-                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_t1, max_t2,
+                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_t1, max_t2, total,
                                        self.stream))
         return out[: total * dl], off_out
 
@@ -108,18 +108,16 @@ class HipPath:
 
     def add_ragged(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor,
                    right: torch.Tensor, off_right: torch.Tensor,
-                   max_terms_out: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   total_terms_out: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         batch = off_left.numel() - 1
         dl = self.default_len(n_bits)
-        ol, orr = self.download(off_left), self.download(off_right)
-        total = int(ol[-1] + orr[-1])
-        if max_terms_out is None:
-            max_terms_out = int(((ol[1:] - ol[:-1]) + (orr[1:] - orr[:-1])).max()) if batch else 0
+        if total_terms_out is None:
+            total_terms_out = int(self.download(off_left[-1:])[0]) + int(self.download(off_right[-1:])[0])
+        total = total_terms_out
         out = self.empty_words(max(total * dl, 1))
         off_out = self.empty_words(batch + 1)
         check(self.lib.csgn_add_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
-                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_terms_out,
-                                       self.stream))
+                                       _ptr(off_right), _ptr(out), _ptr(off_out), total, self.stream))
         return out[: total * dl], off_out
 
     # -- decrypt ----------------------------------------------------------------------

@@ -50,7 +50,7 @@ SIGNATURES = {
     "csgn_key_mask": (C.c_int, [u64, vp, u64, vp]),
     "csgn_mul_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, u64, vp]),
     "csgn_mul_ragged_plan": (C.c_int, [u64, vp, vp, vp, C.POINTER(u64 * 4), vp]),
-    "csgn_mul_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, u64, vp]),
+    "csgn_mul_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, u64, u64, vp]),
     "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
     "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
     "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64, u64]),

@@ -282,7 +282,7 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
 {
     REQUIRE(d_off_left && d_off_right && d_off_out && h_plan, "null pointer");
     u64 *d_plan = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_plan, 4 * sizeof(u64)));
+    HIP_TRY(hipMalloc((void **)&d_plan, csgn::mul_ragged_plan_scratch_words(batch) * sizeof(u64)));
     hipError_t e = csgn::mul_ragged_plan(batch, (const u64 *)d_off_left, (const u64 *)d_off_right,
                                          (u64 *)d_off_out, d_plan, S(stream));
     if (e == hipSuccess)
@@ -299,11 +299,11 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
                     uint64_t *d_out, const uint64_t *d_off_out,
-                    uint64_t max_t1, uint64_t max_t2, void *stream)
+                    uint64_t max_t1, uint64_t max_t2, uint64_t total_out_terms, void *stream)
 {
     if (int rc = check_n(n_bits))
         return rc;
-    if (batch == 0 || max_t1 == 0 || max_t2 == 0)
+    if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
         return CSGN_OK;
     REQUIRE(d_left && d_right && d_out && d_off_left && d_off_right && d_off_out, "null device pointer");
     const uint64_t dl = csgn_default_len(n_bits);
@@ -312,9 +312,9 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     (unsigned long long)max_t1, (unsigned long long)max_t2);
     hipError_t e = csgn::mul_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
                                     (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
-                                    (const u64 *)d_off_out, max_t1, max_t2, S(stream));
+                                    (const u64 *)d_off_out, max_t1, max_t2, total_out_terms, S(stream));
     if (e == hipErrorInvalidValue)
-        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch needs more than 2^30 workgroups; split it");
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch too large for one call (2^32 pairs / one pair's tile grid)");
     HIP_TRY(e);
     return CSGN_OK;
 }
@@ -339,17 +339,17 @@ int csgn_add_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
 int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
-                    uint64_t *d_out, uint64_t *d_off_out, uint64_t max_terms_out, void *stream)
+                    uint64_t *d_out, uint64_t *d_off_out, uint64_t total_terms_out, void *stream)
 {
     if (int rc = check_n(n_bits))
         return rc;
     REQUIRE(d_off_left && d_off_right && d_off_out, "null offset pointer");
-    REQUIRE(max_terms_out == 0 || batch == 0 || (d_left && d_right && d_out), "null device pointer");
+    REQUIRE(total_terms_out == 0 || batch == 0 || (d_left && d_right && d_out), "null device pointer");
     hipError_t e = csgn::add_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
                                     (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
-                                    (u64 *)d_off_out, max_terms_out, S(stream));
+                                    (u64 *)d_off_out, total_terms_out, S(stream));
     if (e == hipErrorInvalidValue)
-        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch needs more than 2^30 workgroups; split it");
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch of 2^32 or more pairs; split it");
     HIP_TRY(e);
     return CSGN_OK;
 }

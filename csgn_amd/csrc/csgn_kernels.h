@@ -22,15 +22,16 @@ MulTuning mul_tuning();
 
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s);
-hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_plan4,
+u64 mul_ragged_plan_scratch_words(u64 batch);
+hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      hipStream_t s);
+                      u64 total_out_terms, hipStream_t s);
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        hipStream_t s);
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
-                      const u64 *offR, u64 *out, u64 *offOut, u64 max_terms_out, hipStream_t s);
+                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s);
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
                    const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s);
 size_t compact_scratch_bytes(u64 total_terms);

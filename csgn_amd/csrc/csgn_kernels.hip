@@ -36,6 +36,12 @@ __device__ inline bool unit_covers(unit8 x, unit8 m) { return (x & m) == m; }
 
 inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
+// HIP refuses a launch whose gridDim.x * blockDim.x reaches 2^32 (hipErrorInvalidConfiguration),
+// so the number of workgroups per launch is bounded by the block size, not by 2^31.
+constexpr u64 kMaxBlocks256 = ((1ull << 32) - 1) / 256;    // 256-thread workgroups
+constexpr u64 kMaxBlocks512 = ((1ull << 32) - 1) / 512;    // the tiled kernel's upper block size
+constexpr u64 kMaxBlocks1024 = ((1ull << 32) - 1) / 1024;
+
 // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; placement is
 // a speed matter only, never correctness).  Remapping the block id so that XCD x owns the
 // x-th contiguous eighth of the logical block range makes every XCD's L2 write back one
@@ -143,6 +149,7 @@ struct MulArgs {
     const u64 *offOut;
     u32 t1, t2, U, TI, col_tiles, row_tiles;
     u32 xcd_remap;
+    u32 pair_base;      // ragged launches cut into chunks: first pair of this launch
 };
 
 template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
@@ -154,8 +161,9 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
     const u32 BS = blockDim.x, tid = threadIdx.x, U = a.U;
     const u32 tiles = a.col_tiles * a.row_tiles;
     const u32 bid = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    const u32 pair = bid / tiles;
-    const u32 tile = bid - pair * tiles;
+    const u32 pair_local = bid / tiles;
+    const u32 tile = bid - pair_local * tiles;
+    const u32 pair = a.pair_base + pair_local;
     const u32 row_tile = tile / a.col_tiles;
     const u32 col_tile = tile - row_tile * a.col_tiles;
 
@@ -224,52 +232,181 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
     }
 }
 
-// Exclusive scan of t1_b*t2_b -> product term offsets; also max shapes.  One workgroup:
-// planning is O(batch) on 16 bytes per pair and is not on the bandwidth-critical path.
-__global__ void __launch_bounds__(1024) k_mul_plan(u64 batch, const u64 *__restrict__ offL,
-                                                   const u64 *__restrict__ offR,
-                                                   u64 *__restrict__ offOut, u64 *__restrict__ plan4)
+// ---------------------------------------------------------------------------------------
+// Ragged batches (CSR offsets), skew-proof form.  The grid covers the FLATTENED output
+// (one 16-byte unit per lane, 4 KiB per workgroup, address order), so its size is the real
+// output, not batch x the largest shape.  A lane finds the pair that owns its output term by
+// binary search over the product offsets: first the workgroup's starting pair (identical
+// addresses in every lane, so the loads broadcast), then a short per-lane search inside the
+// few pairs one workgroup can span.
+// ---------------------------------------------------------------------------------------
+// largest p in [lo, hi) with off[p] <= term   (requires off[lo] <= term)
+__device__ inline u32 csr_find(const u64 *__restrict__ off, u32 lo, u32 hi, u64 term)
 {
-    __shared__ u64 part[1024];
-    __shared__ u64 mx[3][1024];
-    const u32 tid = threadIdx.x;
-    const u64 chunk = (batch + 1023) / 1024;
-    const u64 b0 = min(batch, (u64)tid * chunk), b1 = min(batch, b0 + chunk);
-    u64 sum = 0, m1 = 0, m2 = 0, mp = 0;
-    for (u64 b = b0; b < b1; ++b) {
-        const u64 t1 = offL[b + 1] - offL[b], t2 = offR[b + 1] - offR[b];
-        sum += t1 * t2;
-        m1 = max(m1, t1);
-        m2 = max(m2, t2);
-        mp = max(mp, t1 * t2);
+    while (hi - lo > 1) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= term)
+            lo = mid;
+        else
+            hi = mid;
     }
-    part[tid] = sum;
-    mx[0][tid] = m1;
-    mx[1][tid] = m2;
-    mx[2][tid] = mp;
+    return lo;
+}
+
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
+                                                         const u64 *__restrict__ offL,
+                                                         const Unit *__restrict__ R,
+                                                         const u64 *__restrict__ offR,
+                                                         Unit *__restrict__ out,
+                                                         const u64 *__restrict__ offOut, u32 batch,
+                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU)
+{
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g0 = unit_base + (u64)bid * 256u;
+    if (g0 >= total_units)
+        return;
+    const u64 term0 = g0 / U;                                   // wave-uniform
+    const u32 p0 = csr_find(offOut, 0u, batch, term0);          // uniform search: loads broadcast
+    const u64 g = g0 + threadIdx.x;
+    if (g >= total_units)
+        return;
+    // this lane's term: g0 = term0*U + r0, so (r0 + tid) / U is a 32-bit division
+    const u32 r = (u32)(g0 - term0 * U) + threadIdx.x;
+    const u32 dt = csgn_fastdiv(r, dU);
+    const u64 term = term0 + dt;
+    const u32 k = r - dt * U;
+    const u32 p = csr_find(offOut, p0, batch, term);           // empty pairs make the span unbounded
+    const u64 l0 = offL[p], r0 = offR[p];
+    const u32 t2 = (u32)(offR[p + 1] - r0);
+    const u32 q = (u32)(term - offOut[p]);                      // product term index inside the pair
+    const u32 i = q / t2, j = q - i * t2;
+    unit_store<Unit, true>(out + g, L[(l0 + i) * U + k] & R[(r0 + j) * U + k]);
+}
+
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict__ L,
+                                                         const u64 *__restrict__ offL,
+                                                         const Unit *__restrict__ R,
+                                                         const u64 *__restrict__ offR,
+                                                         Unit *__restrict__ out,
+                                                         const u64 *__restrict__ offOut, u32 batch,
+                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU)
+{
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g0 = unit_base + (u64)bid * 256u;
+    if (g0 >= total_units)
+        return;
+    const u64 term0 = g0 / U;
+    const u32 p0 = csr_find(offOut, 0u, batch, term0);
+    const u64 g = g0 + threadIdx.x;
+    if (g >= total_units)
+        return;
+    const u32 r = (u32)(g0 - term0 * U) + threadIdx.x;
+    const u32 dt = csgn_fastdiv(r, dU);
+    const u64 term = term0 + dt;
+    const u32 k = r - dt * U;
+    const u32 p = csr_find(offOut, p0, batch, term);
+    const u64 l0 = offL[p], r0 = offR[p];
+    const u64 t1 = offL[p + 1] - l0;
+    const u64 q = term - offOut[p];                             // offOut[p] = l0 + r0
+    const Unit v = (q < t1) ? L[(l0 + q) * U + k] : R[(r0 + (q - t1)) * U + k];
+    unit_store<Unit, true>(out + g, v);
+}
+
+// Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
+// launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
+// and the fix-up -- 1M pairs plan in tens of microseconds.
+__global__ void __launch_bounds__(256) k_plan_chunks(u64 batch, const u64 *__restrict__ offL,
+                                                     const u64 *__restrict__ offR,
+                                                     u64 *__restrict__ offOut, u64 *__restrict__ partial,
+                                                     u64 *__restrict__ plan4)
+{
+    __shared__ u64 sums[256];
+    const u32 tid = threadIdx.x;
+    const u64 b0 = (u64)blockIdx.x * 1024u + (u64)tid * 4u;
+    u64 c[4], m1 = 0, m2 = 0, mp = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = 0;
+        if (b0 + j < batch) {
+            const u64 t1 = offL[b0 + j + 1] - offL[b0 + j], t2 = offR[b0 + j + 1] - offR[b0 + j];
+            c[j] = t1 * t2;
+            m1 = max(m1, t1);
+            m2 = max(m2, t2);
+            mp = max(mp, c[j]);
+        }
+        mine += c[j];
+    }
+    sums[tid] = mine;
     __syncthreads();
     if (tid == 0) {
-        u64 run = 0, a1 = 0, a2 = 0, ap = 0;
+        u64 run = 0;
+        for (u32 t = 0; t < 256; ++t) {
+            const u64 v = sums[t];
+            sums[t] = run;
+            run += v;
+        }
+        partial[blockIdx.x] = run;
+    }
+    __syncthreads();
+    u64 run = sums[tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b0 + j < batch)
+            offOut[b0 + j] = run;                      // chunk-local; k_plan_fix adds the chunk base
+        run += c[j];
+    }
+    // wave-level maxima, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        m1 = max(m1, (u64)__shfl_down(m1, off, 64));
+        m2 = max(m2, (u64)__shfl_down(m2, off, 64));
+        mp = max(mp, (u64)__shfl_down(mp, off, 64));
+    }
+    if ((tid & (kWave - 1)) == 0) {
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1), m1);
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 2), m2);
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 3), mp);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 batch, u64 *__restrict__ partial,
+                                                             u64 *__restrict__ offOut, u64 *__restrict__ plan4)
+{
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 chunk = (nchunks + 1023) / 1024;
+    const u64 c0 = min(nchunks, (u64)tid * chunk), c1 = min(nchunks, c0 + chunk);
+    u64 sum = 0;
+    for (u64 c = c0; c < c1; ++c)
+        sum += partial[c];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
         for (u32 t = 0; t < 1024; ++t) {
             const u64 v = part[t];
             part[t] = run;
             run += v;
-            a1 = max(a1, mx[0][t]);
-            a2 = max(a2, mx[1][t]);
-            ap = max(ap, mx[2][t]);
         }
         offOut[batch] = run;
         plan4[0] = run;
-        plan4[1] = a1;
-        plan4[2] = a2;
-        plan4[3] = ap;
     }
     __syncthreads();
     u64 run = part[tid];
-    for (u64 b = b0; b < b1; ++b) {
-        offOut[b] = run;
-        run += (offL[b + 1] - offL[b]) * (offR[b + 1] - offR[b]);
+    for (u64 c = c0; c < c1; ++c) {
+        const u64 v = partial[c];
+        partial[c] = run;
+        run += v;
     }
+}
+
+__global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
+                                                  u64 *__restrict__ offOut)
+{
+    const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (b < batch)
+        offOut[b] += partial[b >> 10];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -289,29 +426,6 @@ __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
         const u32 r = g - pair * OU;
         const Unit v = (r < LU) ? L[(u64)pair * LU + r] : R[(u64)pair * RU + (r - LU)];
         unit_store<Unit, NT>(out + g, v);
-    }
-}
-
-// Ragged add: workgroup (pair, tile) copies one tile of the pair's output.
-template <typename Unit, int MF>
-__global__ void __launch_bounds__(256) k_add_ragged(const Unit *__restrict__ L,
-                                                    const u64 *__restrict__ offL,
-                                                    const Unit *__restrict__ R,
-                                                    const u64 *__restrict__ offR,
-                                                    Unit *__restrict__ out, u32 U, u32 tiles)
-{
-    const u32 pair = blockIdx.x / tiles;
-    const u32 tile = blockIdx.x - pair * tiles;
-    const u64 l0 = offL[pair], r0 = offR[pair];
-    const u64 LU = (offL[pair + 1] - l0) * U, RU = (offR[pair + 1] - r0) * U;
-    const Unit *Lp = L + l0 * U;
-    const Unit *Rp = R + r0 * U;
-    Unit *Op = out + (l0 + r0) * U;
-#pragma unroll
-    for (int m = 0; m < MF; ++m) {
-        const u64 u = (u64)tile * (256u * MF) + (u32)m * 256u + threadIdx.x;
-        if (u < LU + RU)
-            Op[u] = (u < LU) ? Lp[u] : Rp[u - LU];
     }
 }
 
@@ -958,13 +1072,14 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
     a.row_tiles = (a.t1 + ti - 1) / ti;
     const u64 tiles = (u64)a.col_tiles * a.row_tiles;
     const size_t lds = (size_t)ti * U * sizeof(Unit);
-    // keep blockIdx.x / the u32 pair index in range: at most 2^30 workgroups per launch
-    const u64 max_pairs = ((1ull << 30) / tiles) ? ((1ull << 30) / tiles) : 1;
-    if (RAGGED && pairs > max_pairs)
+    // at most kMaxBlocks512 workgroups per launch (gridDim.x * blockDim.x < 2^32)
+    if (tiles > kMaxBlocks512 || pairs >= (1ull << 32))
         return hipErrorInvalidValue;
+    const u64 max_pairs = kMaxBlocks512 / tiles;
     for (u64 p0 = 0; p0 < pairs; p0 += max_pairs) {
         const u64 np = (pairs - p0 < max_pairs) ? pairs - p0 : max_pairs;
         MulArgs b = a;
+        b.pair_base = RAGGED ? (u32)p0 : 0u;
         if (!RAGGED) {
             b.L = reinterpret_cast<const Unit *>(a.L) + p0 * a.t1 * U;
             b.R = reinterpret_cast<const Unit *>(a.R) + p0 * a.t2 * U;
@@ -999,7 +1114,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
     const MulTuning tune = mul_tuning();
     if (t1 == 1 && t2 == 1) {
         // at most 2^31-1 workgroups of 256 units per launch
-        const u64 per_launch = ((1ull << 31) - 1) * 256u;
+        const u64 per_launch = kMaxBlocks256 * 256u;
         for (u64 u0 = 0; u0 < total; u0 += per_launch) {
             const u64 nu = (total - u0 < per_launch) ? total - u0 : per_launch;
             k_and_stream<Unit, true><<<ceil_div_u64(nu, 256u), 256, 0, s>>>(Lu + u0, Ru + u0, Ou + u0, nu);
@@ -1025,7 +1140,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
             const u64 row_bytes = (u64)t2 * U * sizeof(Unit);
             pfr = (u32)((ahead + row_bytes - 1) / row_bytes);
         }
-        const u64 pairs_per = (0xFFFFFFFFull / PU) ? (0xFFFFFFFFull / PU) : 1;   // < 2^32 units per launch
+        const u64 pairs_per = (0xFFFFFF00ull / PU) ? (0xFFFFFF00ull / PU) : 1;   // units (= threads) per launch < 2^32
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
                       dU = csgn_fastdiv_make(U);
         for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
@@ -1115,32 +1230,72 @@ hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     return hipSuccess;
 }
 
-hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_plan4,
+u64 mul_ragged_plan_scratch_words(u64 batch) { return 4 + (batch + 1023) / 1024 + 1; }
+
+hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s)
 {
-    k_mul_plan<<<1, 1024, 0, s>>>(batch, offL, offR, offOut, d_plan4);
+    // d_work: [plan4 (total, max t1, max t2, max t1*t2)][one partial per 1024-pair chunk]
+    u64 *plan4 = d_work, *partial = d_work + 4;
+    const u64 nchunks = (batch + 1023) / 1024;
+    hipError_t e = hipMemsetAsync(d_work, 0, mul_ragged_plan_scratch_words(batch) * 8, s);
+    if (e != hipSuccess)
+        return e;
+    if (nchunks > kMaxBlocks256)
+        return hipErrorInvalidValue;
+    if (batch)
+        k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
+    k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
+    if (batch)
+        k_plan_fix<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, partial, offOut);
     return hipGetLastError();
 }
 
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      hipStream_t s)
+                      u64 total_out_terms, hipStream_t s)
 {
     const u64 dL = (n_bits + 63) / 64;
-    if (batch == 0 || max_t1 == 0 || max_t2 == 0)
+    if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
         return hipSuccess;
+    if (batch >= (1ull << 32))
+        return hipErrorInvalidValue;
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
-    MulArgs a = {};
-    a.L = L;
-    a.R = R;
-    a.out = out;
-    a.offL = offL;
-    a.offR = offR;
-    a.offOut = offOut;
-    a.t1 = (u32)max_t1;
-    a.t2 = (u32)max_t2;
-    return wide ? launch_tiled<unit16, true>(a, batch, U, s) : launch_tiled<unit8, true>(a, batch, U, s);
+    // Nearly uniform batches of large products keep the LDS-tiled kernel (one grid sized for the
+    // largest shape); anything skewed or small goes through the flat ragged kernel, whose grid
+    // is the real output.
+    const bool tiled = env_int("CSGN_RAGGED_FLAT", 0) == 0 && max_t1 * max_t2 * U > 8192 &&
+                       batch * max_t1 * max_t2 <= 2 * total_out_terms;
+    if (tiled) {
+        MulArgs a = {};
+        a.L = L;
+        a.R = R;
+        a.out = out;
+        a.offL = offL;
+        a.offR = offR;
+        a.offOut = offOut;
+        a.t1 = (u32)max_t1;
+        a.t2 = (u32)max_t2;
+        return wide ? launch_tiled<unit16, true>(a, batch, U, s) : launch_tiled<unit8, true>(a, batch, U, s);
+    }
+    const u64 total_units = total_out_terms * U;
+    const FastDiv dU = csgn_fastdiv_make(U);
+    for (u64 u0 = 0; u0 < total_units; u0 += kMaxBlocks256 * 256u) {
+        const u64 nu = (total_units - u0 < kMaxBlocks256 * 256u) ? total_units - u0 : kMaxBlocks256 * 256u;
+        const u32 blocks = ceil_div_u64(nu, 256u);
+        if (wide)
+            k_mul_ragged_flat<unit16><<<blocks, 256, 0, s>>>(
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, total_units, U, dU);
+        else
+            k_mul_ragged_flat<unit8><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, u0,
+                                                            total_units, U, dU);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
@@ -1152,7 +1307,7 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
     const u64 OU = (t1 + t2) * U;
-    const u64 pairs_per = (0xFFFFFFFFull / OU) ? (0xFFFFFFFFull / OU) : 1;       // < 2^32 units per launch
+    const u64 pairs_per = (0xFFFFFF00ull / OU) ? (0xFFFFFF00ull / OU) : 1;       // units (= threads) per launch < 2^32
     const FastDiv d = csgn_fastdiv_make((u32)OU);
     for (u64 p0 = 0; p0 < batch; p0 += pairs_per) {
         const u64 np = (batch - p0 < pairs_per) ? batch - p0 : pairs_per;
@@ -1175,27 +1330,33 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
 }
 
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
-                      const u64 *offR, u64 *out, u64 *offOut, u64 max_terms_out, hipStream_t s)
+                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s)
 {
     const u64 dL = (n_bits + 63) / 64;
+    if (batch >= (1ull << 32))
+        return hipErrorInvalidValue;
     k_off_sum<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch + 1, offL, offR, offOut);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || batch == 0 || max_terms_out == 0)
+    if (e != hipSuccess || batch == 0 || total_terms_out == 0)
         return e;
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
-    constexpr int MF = 4;
-    const u64 tiles = (max_terms_out * U + 256u * MF - 1) / (256u * MF);
-    if (batch * tiles > (1ull << 30))
-        return hipErrorInvalidValue;
-    const u32 blocks = (u32)(batch * tiles);
-    if (wide)
-        k_add_ragged<unit16, MF><<<blocks, 256, 0, s>>>(reinterpret_cast<const unit16 *>(L), offL,
-                                                        reinterpret_cast<const unit16 *>(R), offR,
-                                                        reinterpret_cast<unit16 *>(out), U, (u32)tiles);
-    else
-        k_add_ragged<unit8, MF><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, U, (u32)tiles);
-    return hipGetLastError();
+    const u64 total_units = total_terms_out * U;
+    const FastDiv dU = csgn_fastdiv_make(U);
+    for (u64 u0 = 0; u0 < total_units; u0 += kMaxBlocks256 * 256u) {
+        const u64 nu = (total_units - u0 < kMaxBlocks256 * 256u) ? total_units - u0 : kMaxBlocks256 * 256u;
+        const u32 blocks = ceil_div_u64(nu, 256u);
+        if (wide)
+            k_add_ragged_flat<unit16><<<blocks, 256, 0, s>>>(
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, total_units, U, dU);
+        else
+            k_add_ragged_flat<unit8><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, u0,
+                                                            total_units, U, dU);
+        if ((e = hipGetLastError()) != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
 }
 
 static size_t decrypt_bitmap_bytes(u64 total_terms)
@@ -1220,7 +1381,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         const bool wide = (dL % 2 == 0) && aligned16(terms) && aligned16(mask);
         const u32 U = (u32)(wide ? dL / 2 : dL);
         const u64 blocks64 = (total_terms + 255) / 256;
-        if (blocks64 > (1ull << 31) - 1)
+        if (blocks64 > kMaxBlocks256)
             return hipErrorInvalidValue;
         const u32 blocks = (u32)blocks64;
         const FastDiv dU = csgn_fastdiv_make(U);
@@ -1236,7 +1397,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         if (k_seg && env_int("CSGN_DEC_LOOP", 0) == 0) {
             const u32 tb = 256u * k_seg / U;
             const u64 nblk = (total_terms + tb - 1) / tb;
-            if (nblk > (1ull << 31) - 1)
+            if (nblk > kMaxBlocks256)
                 return hipErrorInvalidValue;
             unsigned char *hb = reinterpret_cast<unsigned char *>(scratch);
             const u64 tu = total_terms * U;
@@ -1279,7 +1440,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     const u64 avg = total_terms / batch;
     if (avg <= 4096) {
         k_hits_parity<1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
-    } else if (!off && batch * ((terms_uniform + 65535) / 65536) < (1ull << 31)) {
+    } else if (!off && batch * ((terms_uniform + 65535) / 65536) <= kMaxBlocks256) {
         // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
         u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
                                                decrypt_bitmap_bytes(total_terms));
@@ -1291,7 +1452,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         k_partial_to_bits<<<ceil_div_u64(batch, 256), 256, 0, s>>>(partial, batch, bits);
     } else {
         const u64 blocks64 = (batch * 64 + 255) / 256;
-        if (blocks64 > (1ull << 31) - 1)
+        if (blocks64 > kMaxBlocks256)
             return hipErrorInvalidValue;
         k_hits_parity<64><<<(u32)blocks64, 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
     }
@@ -1502,7 +1663,7 @@ hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, con
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0)
         return hipSuccess;
-    if (batch >= (1ull << 31) || total_terms >= (1ull << 31))
+    if (batch >= (1ull << 31) || total_terms > kMaxBlocks256 * 256u - 256u)
         return hipErrorInvalidValue;
     auto up = [](uintptr_t x) { return (x + 255) & ~(uintptr_t)255; };
     unsigned char *p = reinterpret_cast<unsigned char *>(up(reinterpret_cast<uintptr_t>(scratch)));
@@ -1536,7 +1697,7 @@ hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, con
     if (total_terms) {
         const u64 words = total_terms * dL;
         const u64 blocks64 = (words + 255) / 256;
-        if (blocks64 > (1ull << 31) - 1)
+        if (blocks64 > kMaxBlocks256)
             return hipErrorInvalidValue;
         k_compact_scatter<<<(u32)blocks64, 256, 0, s>>>(terms, words, (u32)dL, v, out);
     }
@@ -1564,7 +1725,7 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
         if (k_seg && env_int("CSGN_ENC_LDS", 0) == 0) {
             const u32 tb = 256u * k_seg / U;
             const u64 nblk = (batch + tb - 1) / tb;
-            if (nblk > (1ull << 31) - 1)
+            if (nblk > kMaxBlocks256)
                 return hipErrorInvalidValue;
             const FastDiv dU = csgn_fastdiv_make(U);
 #define CSGN_ENC_SEG(UNIT, K)                                                                           \
@@ -1605,7 +1766,7 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
         cb /= 2;
     const size_t lds = ((size_t)cb * dL + dL) * 8;
     const u64 blocks64 = (batch + cb - 1) / cb;
-    if (blocks64 > (1ull << 31) - 1)
+    if (blocks64 > kMaxBlocks256)
         return hipErrorInvalidValue;
     const FastDiv ddL = csgn_fastdiv_make((u32)dL);
     if (device_rng)
@@ -1630,7 +1791,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     while (tb > 4 && (u64)tb * dL * 8 > 32768)
         tb /= 2;
     const u64 blocks64 = (out_terms + tb - 1) / tb;
-    if (blocks64 > (1ull << 31) - 1)
+    if (blocks64 > kMaxBlocks256)
         return hipErrorInvalidValue;
     const FastDiv ddL = csgn_fastdiv_make((u32)dL);
     const u32 have = terms_in != 0 ? 1u : 0u;

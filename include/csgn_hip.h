@@ -121,12 +121,15 @@ int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
  * term counts the multi-GPU driver gathers (count_b = off[b+1]-off[b]). */
 int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
                          uint64_t *d_off_out, uint64_t h_plan[4], void *stream);
-/* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets. */
+/* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets; pass the plan's
+ * max_t1 = h_plan[1], max_t2 = h_plan[2], total_out_terms = h_plan[0].  Nearly uniform batches
+ * of large products run the LDS-tiled kernel; skewed or small ones a flat kernel whose grid is
+ * the real output (each lane finds its pair by binary search over d_off_out). */
 int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
                     uint64_t *d_out, const uint64_t *d_off_out,
-                    uint64_t max_t1, uint64_t max_t2, void *stream);
+                    uint64_t max_t1, uint64_t max_t2, uint64_t total_out_terms, void *stream);
 
 /* ----------------------------------------------------------------------- add ---- */
 
@@ -135,12 +138,13 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
 int csgn_add_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
                      const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out,
                      void *stream);
-/* Ragged: d_off_out[b] = d_off_left[b] + d_off_right[b] is written by the call. */
+/* Ragged: d_off_out[b] = d_off_left[b] + d_off_right[b] is written by the call;
+ * total_terms_out = d_off_left[batch] + d_off_right[batch] (the caller sized d_out with it). */
 int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
                     uint64_t *d_out, uint64_t *d_off_out,
-                    uint64_t max_terms_out, void *stream);
+                    uint64_t total_terms_out, void *stream);
 
 /* ------------------------------------------------------------------- decrypt ---- */
 

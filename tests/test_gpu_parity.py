@@ -872,3 +872,57 @@ def test_fuzz_random_operation_sequences(hip, oracle, n, d, seed):
                 assert got == bit, (step, op)
         if len(pool) > 40:
             pool = pool[:8] + pool[-16:]
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (63, 4), (4096, 32)])
+@pytest.mark.parametrize("force_flat", [0, 1])
+def test_ragged_skewed_batches(hip, oracle, monkeypatch, n, d, force_flat):
+    """Skewed CSR batches (one large pair among many tiny and empty ones, runs of empty pairs
+    longer than a workgroup) through both ragged multiply kernels and the ragged add."""
+    monkeypatch.setenv("CSGN_RAGGED_FLAT", str(force_flat))
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n + force_flat)
+    t1s = [1, 0, 0, 90, 1] + [0] * 300 + [2, 3] + [1] * 40 + [0, 7]
+    t2s = [1, 5, 0, 70, 1] + [0] * 300 + [3, 2] + [1] * 40 + [9, 0]
+    offL, offR = csr(t1s), csr(t2s)
+    L = oracle.synth(61, n, 0, int(offL[-1]) * dl)
+    R = oracle.synth(62, n, 0, int(offR[-1]) * dl)
+    dLw, dRw, dOL, dOR = hip.upload(L), hip.upload(R), hip.upload(offL), hip.upload(offR)
+    out, off_out = hip.mul_ragged(n, dLw, dOL, dRw, dOR)
+    out, off_out = hip.download(out), hip.download(off_out)
+    assert np.array_equal(off_out, csr([a * b for a, b in zip(t1s, t2s)]))
+    sout, soff = hip.add_ragged(n, dLw, dOL, dRw, dOR)
+    sout, soff = hip.download(sout), hip.download(soff)
+    assert np.array_equal(soff, offL + offR)
+    for b, (t1, t2) in enumerate(zip(t1s, t2s)):
+        lh = L[int(offL[b]) * dl:int(offL[b + 1]) * dl]
+        rh = R[int(offR[b]) * dl:int(offR[b + 1]) * dl]
+        got = out[int(off_out[b]) * dl:int(off_out[b + 1]) * dl]
+        if t1 and t2:
+            want, _ = oracle.mul(n, lh, rh)
+            assert np.array_equal(got, want), b
+        else:
+            assert got.size == 0
+        want_s, _ = oracle.add(lh, rh)
+        assert np.array_equal(sout[int(soff[b]) * dl:int(soff[b + 1]) * dl], want_s), b
+
+
+@pytest.mark.parametrize("batch", [1, 2, 1023, 1024, 1025, 5000, 200000])
+def test_mul_ragged_plan_offsets(hip, batch):
+    """The chunked plan scan (1024-pair chunks, partial scan, fix-up) against numpy for batch
+    sizes around the chunk boundaries, with zeros mixed in."""
+    import ctypes as C
+    rng = np.random.default_rng(batch)
+    t1 = rng.integers(0, 7, size=batch).astype(np.uint64)
+    t2 = rng.integers(0, 5, size=batch).astype(np.uint64)
+    offL, offR = csr(t1), csr(t2)
+    off_out = hip.empty_words(batch + 1)
+    plan = (C.c_uint64 * 4)()
+    from csgn_amd.capi import check
+    d_off_l, d_off_r = hip.upload(offL), hip.upload(offR)        # keep the tensors alive across the call
+    check(hip.lib.csgn_mul_ragged_plan(batch, d_off_l.data_ptr(), d_off_r.data_ptr(),
+                                       off_out.data_ptr(), C.byref(plan), hip.stream))
+    want = csr(t1 * t2)
+    assert np.array_equal(hip.download(off_out), want)
+    assert int(plan[0]) == int(want[-1])
+    assert (int(plan[1]), int(plan[2]), int(plan[3])) == (int(t1.max()), int(t2.max()), int((t1 * t2).max()))

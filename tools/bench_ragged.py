@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Ragged (CSR) multiply / add / decrypt throughput on skewed batches (dev tool)."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from csgn_amd.batch import HipPath
+hip = HipPath(0)
+def timed(fn, rounds=7):
+    fn(); torch.cuda.synchronize(); ts=[]
+    for _ in range(rounds):
+        a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b)/1e3)
+    return statistics.median(ts)
+def csr(c):
+    o=np.zeros(len(c)+1,dtype=np.uint64); o[1:]=np.cumsum(np.asarray(c,dtype=np.uint64)); return o
+n=1247; dl=20
+rng=np.random.default_rng(0)
+for name,t1s,t2s in [
+    ("uniform 64x64 x4096", [64]*4096, [64]*4096),
+    ("lognormal mean~32 x16384", np.clip(rng.lognormal(3,1,16384),1,2000).astype(int), np.clip(rng.lognormal(3,1,16384),1,2000).astype(int)),
+    ("one 1024x1024 + 65535 1x1", [1024]+[1]*65535, [1024]+[1]*65535),
+    ("fresh 1x1 x1M (ragged path)", [1]*(1<<20), [1]*(1<<20)),
+]:
+    offL,offR=csr(t1s),csr(t2s)
+    L=hip.synth_fill(1,n,0,int(offL[-1])*dl); R=hip.synth_fill(2,n,0,int(offR[-1])*dl)
+    dL_,dR_=hip.upload(offL),hip.upload(offR)
+    outw=int(np.sum(np.asarray(t1s,dtype=np.int64)*np.asarray(t2s,dtype=np.int64)))*dl
+    alg=8*(int(offL[-1])*dl+int(offR[-1])*dl+outw)
+    t=timed(lambda: hip.mul_ragged(n,L,dL_,R,dR_))
+    print(f"mul_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak), out {outw*8/1e6:.0f} MB", flush=True)
+    alg=2*8*dl*(int(offL[-1])+int(offR[-1]))
+    tot=int(offL[-1]+offR[-1]); t=timed(lambda: hip.add_ragged(n,L,dL_,R,dR_, total_terms_out=tot))
+    print(f"add_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak)", flush=True)
+    del L,R
