@@ -558,7 +558,12 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
 // decrypt, pass 2: XOR over the terms of each ciphertext = parity of the popcount of its
 // bit range (src/SecretKey.cpp:139, `_dec = (dec + _dec) % 2`).  G lanes per ciphertext:
 // 1 for small term counts, a whole wave (with a __ballot/__popcll fold) for large ones.
-template <int G>
+// MODE 0: every ciphertext; 1: only those of at most kLongTerms terms; 2: only the longer ones
+// (ragged batches run a lane-per-ciphertext pass for the short ones and a wave-per-ciphertext
+// pass for the long ones, so one huge ciphertext among many small ones costs neither).
+constexpr u64 kLongTerms = 4096;
+
+template <int G, int MODE>
 __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hits,
                                                      const u64 *__restrict__ off, u64 T, u64 batch,
                                                      uint8_t *__restrict__ bits)
@@ -570,6 +575,10 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
         return;
     const u64 s = off ? off[b] : b * T;
     const u64 e = off ? off[b + 1] : s + T;
+    if (MODE == 1 && e - s > kLongTerms)
+        return;
+    if (MODE == 2 && e - s <= kLongTerms)
+        return;                                     // whole wave leaves (G == 64: one ciphertext per wave)
     u32 par = 0;
     if (e > s) {
         const u64 w0 = s >> 6, w1 = (e - 1) >> 6;
@@ -1437,10 +1446,16 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         if (e != hipSuccess)
             return e;
     }
-    const u64 avg = total_terms / batch;
-    if (avg <= 4096) {
-        k_hits_parity<1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
-    } else if (!off && batch * ((terms_uniform + 65535) / 65536) <= kMaxBlocks256) {
+    if (off) {
+        // ragged: short ciphertexts one lane each, long ones one wave each
+        if (batch * 64 > kMaxBlocks256 * 256u)
+            return hipErrorInvalidValue;
+        k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits);
+        if (total_terms > kLongTerms)
+            k_hits_parity<64, 2><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, off, 0, batch, bits);
+    } else if (terms_uniform <= kLongTerms) {
+        k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits);
+    } else if (batch * ((terms_uniform + 65535) / 65536) <= kMaxBlocks256) {
         // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
         u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
                                                decrypt_bitmap_bytes(total_terms));
@@ -1451,10 +1466,9 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         k_hits_parity_chunked<<<(u32)(batch * chunks), 256, 0, s>>>(hits, terms_uniform, chunks, partial);
         k_partial_to_bits<<<ceil_div_u64(batch, 256), 256, 0, s>>>(partial, batch, bits);
     } else {
-        const u64 blocks64 = (batch * 64 + 255) / 256;
-        if (blocks64 > kMaxBlocks256)
+        if (batch * 64 > kMaxBlocks256 * 256u)
             return hipErrorInvalidValue;
-        k_hits_parity<64><<<(u32)blocks64, 256, 0, s>>>(hits, off, terms_uniform, batch, bits);
+        k_hits_parity<64, 0><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits);
     }
     return hipGetLastError();
 }

@@ -926,3 +926,18 @@ def test_mul_ragged_plan_offsets(hip, batch):
     assert np.array_equal(hip.download(off_out), want)
     assert int(plan[0]) == int(want[-1])
     assert (int(plan[1]), int(plan[2]), int(plan[3])) == (int(t1.max()), int(t2.max()), int((t1 * t2).max()))
+
+
+def test_decrypt_ragged_skewed(hip, oracle):
+    """Ragged decrypt where one ciphertext is far longer than the rest (lane-per-ciphertext pass
+    for the short ones, wave-per-ciphertext pass for the long ones), with empty ones mixed in."""
+    n, d = 1247, 16
+    key = make_key(n, d, 77)
+    dmask = hip.upload(hip.key_mask(n, key))
+    counts = [3, 0, 100000, 1, 4096, 4097, 0, 0, 7, 70000, 2]
+    parts = [planted(oracle, n, key, t, (t * 7 + i) % (t + 1), 300 + i) if t else np.zeros(0, np.uint64)
+             for i, t in enumerate(counts)]
+    bits = hip.download(hip.decrypt_ragged(n, hip.upload(np.concatenate(parts)), hip.upload(csr(counts)), dmask))
+    for i, t in enumerate(counts):
+        want = oracle.decrypt_canonical(n, key, parts[i]) if t else 0
+        assert bits[i] == want == (((t * 7 + i) % (t + 1)) % 2 if t else 0), i
