@@ -143,7 +143,9 @@ DevicePayload::~DevicePayload()
 {
     if (!ptr)
         return;
-    if (BlockCache *c = cache())
+    // only the cache of a thread bound to the SAME device may recycle the block
+    BlockCache *c = (device == g_device) ? cache() : nullptr;
+    if (c)
         c->give(ptr, capacity);
     else
         csgn_free(ptr);
@@ -153,6 +155,7 @@ std::shared_ptr<DevicePayload> allocBytes(size_t bytes)
 {
     ensureDevice();
     std::shared_ptr<DevicePayload> p = std::make_shared<DevicePayload>();
+    p->device = g_device;
     if (bytes)
         p->ptr = cache()->take(bytes, &p->capacity);
     p->words = bytes / 8;

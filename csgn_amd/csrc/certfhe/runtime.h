@@ -19,7 +19,8 @@ struct DevicePayload {
     void *ptr;
     uint64_t words;
     size_t capacity;      // bytes actually reserved (a size class of the block cache)
-    DevicePayload() : ptr(nullptr), words(0), capacity(0) {}
+    int device;           // GPU the block lives on
+    DevicePayload() : ptr(nullptr), words(0), capacity(0), device(-1) {}
     ~DevicePayload();
     DevicePayload(const DevicePayload &) = delete;
     DevicePayload &operator=(const DevicePayload &) = delete;
