@@ -170,3 +170,57 @@ def test_batch_extension(driver):
     the fused decryptProduct, and the per-object API."""
     assert "batch ok count=4096" in run(driver, "batch", 4096).stdout
     assert "batch ok count=7" in run(driver, "batch", 7).stdout
+
+
+def test_libcertfhe_exports_the_reference_class_surface(driver):
+    """libcertFHE.so defines every public member of the reference's classes that user code can
+    call (src/Ciphertext.h:65-143, src/SecretKey.h:67-143, src/Context.h:28-69,
+    src/Permutation.h:27-89, src/Helpers.h:21,38,43, src/Timer.h)."""
+    out = subprocess.run(["nm", "-DC", "--defined-only", os.path.join(LIBDIR, "libcertFHE.so")],
+                         capture_output=True, text=True, check=True).stdout
+    expected = [
+        "certFHE::Context::Context(unsigned long, unsigned long)", "certFHE::Context::getN() const",
+        "certFHE::Context::getD() const", "certFHE::Context::getS() const",
+        "certFHE::Context::getDefaultN() const", "certFHE::Context::setN(unsigned long)",
+        "certFHE::Context::setD(unsigned long)",
+        "certFHE::Ciphertext::Ciphertext()",
+        "certFHE::Ciphertext::Ciphertext(unsigned long const*, unsigned long const*, unsigned long, certFHE::Context const&)",
+        "certFHE::Ciphertext::Ciphertext(certFHE::Ciphertext const&)",
+        "certFHE::Ciphertext::operator+(certFHE::Ciphertext const&) const",
+        "certFHE::Ciphertext::operator+=(certFHE::Ciphertext const&)",
+        "certFHE::Ciphertext::operator*(certFHE::Ciphertext const&) const",
+        "certFHE::Ciphertext::operator*=(certFHE::Ciphertext const&)",
+        "certFHE::Ciphertext::operator=(certFHE::Ciphertext const&)",
+        "certFHE::Ciphertext::setValues(unsigned long const*, unsigned long)",
+        "certFHE::Ciphertext::setBitlen(unsigned long const*, unsigned long)",
+        "certFHE::Ciphertext::setContext(certFHE::Context const&)",
+        "certFHE::Ciphertext::getLen() const", "certFHE::Ciphertext::getContext() const",
+        "certFHE::Ciphertext::getValues() const", "certFHE::Ciphertext::getBitlen() const",
+        "certFHE::Ciphertext::applyPermutation_inplace(certFHE::Permutation const&)",
+        "certFHE::Ciphertext::applyPermutation(certFHE::Permutation const&)",
+        "certFHE::Ciphertext::size()",
+        "certFHE::SecretKey::SecretKey(certFHE::Context const&)",
+        "certFHE::SecretKey::SecretKey(certFHE::SecretKey const&)",
+        "certFHE::SecretKey::encrypt(certFHE::Plaintext&)", "certFHE::SecretKey::decrypt(certFHE::Ciphertext&)",
+        "certFHE::SecretKey::applyPermutation_inplace(certFHE::Permutation const&)",
+        "certFHE::SecretKey::applyPermutation(certFHE::Permutation const&)",
+        "certFHE::SecretKey::operator=(certFHE::SecretKey const&)",
+        "certFHE::SecretKey::getLength() const", "certFHE::SecretKey::getKey() const",
+        "certFHE::SecretKey::setKey(unsigned long*, unsigned long)", "certFHE::SecretKey::size()",
+        "certFHE::Permutation::Permutation()", "certFHE::Permutation::Permutation(unsigned long const*, unsigned long)",
+        "certFHE::Permutation::Permutation(certFHE::Context const&)", "certFHE::Permutation::Permutation(unsigned long)",
+        "certFHE::Permutation::getInverse()", "certFHE::Permutation::operator+(certFHE::Permutation const&) const",
+        "certFHE::Permutation::operator+=(certFHE::Permutation const&)",
+        "certFHE::Permutation::getLength() const", "certFHE::Permutation::getPermutation() const",
+        "certFHE::Permutation::setPermutation(unsigned long*, unsigned long)", "certFHE::Permutation::setLength(unsigned long)",
+        "certFHE::Library::initializeLibrary()", "certFHE::Helper::exists(unsigned long const*, unsigned long, unsigned long)",
+        "certFHE::Helper::deletePointer(void*, bool)",
+        "certFHE::Timer::start()", "certFHE::Timer::stop()", "certFHE::Timer::stopAndPrint()", "certFHE::Timer::getValue()",
+        "certFHE::operator<<(std::ostream&, certFHE::Ciphertext const&)",
+        "certFHE::operator<<(std::ostream&, certFHE::SecretKey const&)",
+        "certFHE::operator<<(std::ostream&, certFHE::Context const&)",
+        "certFHE::operator<<(std::ostream&, certFHE::Plaintext const&)",
+        "certFHE::operator<<(std::ostream&, certFHE::Permutation const&)",
+    ]
+    missing = [e for e in expected if e not in out]
+    assert not missing, missing
