@@ -60,6 +60,12 @@ def build_ref() -> Optional[str]:
     return REF_SO if os.path.exists(REF_SO) else None
 
 
+def build_demos() -> None:
+    """The reference's own demo programs linked against the drop-in library (needs
+    csgn_amd/lib/libcertFHE.so; dev container only, prebuilt binaries travel to the GPU box)."""
+    subprocess.check_call(["make", "-C", HERE, "demos"], stdout=subprocess.DEVNULL)
+
+
 def glibc_draws(seed: int, count: int) -> np.ndarray:
     """`count` successive rand() results after srand(seed), from this box's libc."""
     libc = C.CDLL("libc.so.6")
