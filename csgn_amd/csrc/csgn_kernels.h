@@ -11,7 +11,7 @@ namespace csgn {
 // CSGN_MUL_M (column units per lane), CSGN_MUL_TI (left terms per tile),
 // CSGN_MUL_NT (1 = non-temporal stores).
 struct MulTuning {
-    int m;
+    int m;      // CSGN_MUL_M: column units per lane, 0 = auto
     int ti;
     int nt;
     int flat;   // CSGN_MUL_FLAT: units per lane of the flat kernel (0 = default 1); -1 = use the LDS-tiled kernel

@@ -1056,13 +1056,16 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
     // With M > 1 a block size that U divides lets every column of a lane share one LDS read
     // (SAMEK); with the default M == 1 there is a single column per lane and 256 threads
     // (4 KiB-aligned row segments) measured fastest.
+    // auto: 256 threads x 4 KiB row segments -- one 16-byte unit per lane, or two 8-byte units
+    // when dL is odd (measured at N=1300: 5.3 -> 6.4 TB/s, the 2 KiB segments of M=1 lose)
+    const int m_req = tune.m ? tune.m : (sizeof(Unit) == 8 ? 2 : 1);
     u32 bs = tune.bs ? (u32)tune.bs : (tune.m > 1 ? samek_block(U) : 256u);
     if (bs == 0)
         bs = 256;
     const bool samek = bs % U == 0;
     const u32 cu = a.t2 * U;
     // do not give a lane more columns than the row has
-    int m = tune.m;
+    int m = m_req;
     while (m > 1 && (u64)bs * (m / 2) >= cu)
         m /= 2;
     // left tile: TI terms, capped so the LDS image stays <= 32 KB
@@ -1199,9 +1202,9 @@ MulTuning mul_tuning()
     // (4 KiB row segments), one column unit per lane, 4 left terms per tile, non-temporal
     // stores.  Short-lived workgroups keep the chip-wide write front dense in address space,
     // which is what HBM rewards; TI=64 tiles lose ~20 % to the scattered store pattern.
-    t.m = env_int("CSGN_MUL_M", 1);
+    t.m = env_int("CSGN_MUL_M", 0);          // 0 = auto: 1 column unit per lane (2 for 8-byte units)
     if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
-        t.m = 1;
+        t.m = 0;
     t.ti = env_int("CSGN_MUL_TI", 4);
     if (t.ti < 1)
         t.ti = 1;
