@@ -42,7 +42,7 @@ SEED = 0x43534743
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=65536, help="pairs per GPU per step")
     ap.add_argument("--slots", type=int, default=128, help="result buffers in the output arena")
