@@ -100,3 +100,22 @@ def test_fails_loudly_without_gpu(lib):
     buf = np.zeros(64, dtype=np.uint64)
     rc = lib.csgn_mul_uniform(1247, 1, 1, 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, 0, None)
     assert rc < 0, "compute call must not succeed without a GPU"
+
+
+def test_integration_md_binding_stub_compiles(tmp_path):
+    """The reference-side binding shown in INTEGRATION.md (section B) is real code: extract it
+    and compile it against include/csgn_hip.h and the Context class."""
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "namespace hipbind" in b]
+    assert len(stub) == 1
+    src = tmp_path / "binding_stub.cpp"
+    src.write_text('#include <vector>\n#include "Context.h"\n' + stub[0] +
+                   "\nint main() { certFHE::Context c(1247, 16); uint64_t n = 0; (void)c; (void)n;"
+                   " (void)&certFHE::hipbind::multiply; (void)&certFHE::hipbind::add;"
+                   " (void)&certFHE::hipbind::decrypt; return 0; }\n")
+    p = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "include", "certfhe"), str(src)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
