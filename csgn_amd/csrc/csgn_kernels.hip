@@ -133,12 +133,13 @@ __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
 // For a fixed left term i the output row is the WHOLE right operand masked by one
 // broadcast term, so the product is a pure streaming write (reads are < 0.3 % of the
 // bytes at 1024x1024).  A workgroup owns TI left terms x (BS*M) right-operand units:
-//   - the TI left terms sit in LDS (TI*U units, 10 KB at N=1247, TI=64);
+//   - the TI left terms sit in LDS (TI*U units: 640 B at N=1247 with the default TI=4);
 //   - each lane keeps its M right units in registers for the whole tile;
 //   - per row, a lane reads the one left unit it needs (index c mod U) with ds_read_b128
 //     and issues M global_store_dwordx4; a wave instruction writes 1 KiB contiguous.
-// When U divides the block size every one of a lane's M columns needs the same left unit
-// (SAMEK), so there is one LDS read per row instead of M.
+// Defaults (mul_tuning): 256 threads, M = 1 for 16-byte units (2 for 8-byte units), TI = 4.
+// SAMEK only matters for M > 1: when U divides the block size every one of a lane's M columns
+// needs the same left unit, so there is one LDS read per row instead of M.
 // ---------------------------------------------------------------------------------------
 struct MulArgs {
     const void *L;
@@ -1201,7 +1202,7 @@ MulTuning mul_tuning()
     // Defaults from the MI355X sweeps recorded in DESIGN.md / profiles/: 256-thread workgroups
     // (4 KiB row segments), one column unit per lane, 4 left terms per tile, non-temporal
     // stores.  Short-lived workgroups keep the chip-wide write front dense in address space,
-    // which is what HBM rewards; TI=64 tiles lose ~20 % to the scattered store pattern.
+    // which is what HBM rewards; long-lived tiles (TI=64) lose ~20 % to the scattered store pattern.
     t.m = env_int("CSGN_MUL_M", 0);          // 0 = auto: 1 column unit per lane (2 for 8-byte units)
     if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
         t.m = 0;
@@ -1209,7 +1210,7 @@ MulTuning mul_tuning()
     if (t.ti < 1)
         t.ti = 1;
     t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
-    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = flat kernel, default unroll; -1 = LDS-tiled kernel
+    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = auto (flat when a pair has <= 8192 output units, else LDS-tiled); >0 = flat with that unroll; -1 = always tiled
     if (t.flat != -1 && t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
         t.flat = 0;
     t.xcd = env_int("CSGN_MUL_XCD", 1);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both

@@ -59,6 +59,21 @@ uint64_t ref_context_s(uint64_t n, uint64_t d)
 void ref_keygen(uint64_t n, uint64_t d, uint64_t *key_out, int64_t *t_before, int64_t *t_after)
 {
     Context ctx(n, d);
+    /* The reference's sampler tests membership against the WHOLE new uint64_t[d] array, whose
+     * tail is still uninitialised (SecretKey.cpp:318-327 + Helpers.cpp:18-24): stale heap words
+     * that happen to be < n reject draws at random.  Hand the allocator a few recycled chunks
+     * of that size filled with values no draw can equal, so the run is reproducible. */
+    {
+        uint64_t *pad[8];
+        for (int i = 0; i < 8; ++i) {
+            pad[i] = new uint64_t[d];
+            volatile uint64_t *q = pad[i]; /* keep the fill: it is dead to the optimiser */
+            for (uint64_t j = 0; j < d; ++j)
+                q[j] = ~0ull;
+        }
+        for (int i = 0; i < 8; ++i)
+            delete[] pad[i];
+    }
     *t_before = (int64_t)time(NULL);
     SecretKey sk(ctx);
     *t_after = (int64_t)time(NULL);
