@@ -310,6 +310,8 @@ class Ref:
         L.ref_time_mul.argtypes = [u64, u64, u64p, u64, u64p, u64, u64, u64p]
         L.ref_time_decrypt.restype = C.c_double
         L.ref_time_decrypt.argtypes = [u64, u64, u64p, u64p, u64, u64, u64p]
+        L.ref_text.restype = u64
+        L.ref_text.argtypes = [C.c_int, u64, u64, u64p, u64p, u64, C.c_char_p, u64]
 
     def default_len(self, n: int, d: int) -> int:
         return int(self.lib.ref_default_len(n, d))
@@ -400,6 +402,48 @@ class Ref:
         key, v = as_u64(key), as_u64(v)
         sink = u64(0)
         return float(self.lib.ref_time_decrypt(n, d, _p64(key), _p64(v), v.size, iters, C.byref(sink)))
+
+    TEXT_KINDS = {"ciphertext": 0, "key": 1, "context": 2, "plaintext": 3, "permutation": 4}
+
+    def text(self, kind: str, n: int, d: int, a=None, b=None, length: int = 0) -> str:
+        """operator<< output of one object (see ref_text in ref_driver.cpp)."""
+        a = as_u64(a) if a is not None else np.zeros(1, dtype=np.uint64)
+        b = as_u64(b) if b is not None else np.zeros(1, dtype=np.uint64)
+        k = self.TEXT_KINDS[kind]
+        need = int(self.lib.ref_text(k, n, d, _p64(a), _p64(b), length, None, 0))
+        buf = C.create_string_buffer(need + 1)
+        self.lib.ref_text(k, n, d, _p64(a), _p64(b), length, buf, need)
+        return buf.raw[:need].decode("ascii")
+
+
+# ---- text forms (operator<<): restated here because they are pure formatting -------------
+def text_ciphertext(v, bitlen) -> str:
+    """src/Ciphertext.cpp:185-202: per word, its top bitlen[word] bits MSB-first; one newline."""
+    v, bitlen = as_u64(v), as_u64(bitlen)
+    return "".join(format(int(w), "064b")[: int(b)] for w, b in zip(v, bitlen)) + "\n"
+
+
+def text_key(key) -> str:
+    """src/SecretKey.cpp:22-29: indices in stored order, each followed by a blank."""
+    return "".join("%d " % int(k) for k in as_u64(key)) + "\n"
+
+
+def text_context(n: int, d: int) -> str:
+    """src/Context.cpp:40-47 (S = N/(2D), src/Context.cpp:20-29)."""
+    return "N= %d\nD= %d\nS= %d\n" % (n, d, n // (2 * d))
+
+
+def text_plaintext(bit: int) -> str:
+    """src/Plaintext.cpp:10-19."""
+    return "%d\n" % (bit & 1)
+
+
+def text_permutation(perm) -> str:
+    """src/Permutation.cpp:33-46: two-row notation."""
+    perm = as_u64(perm)
+    top = "".join("%d " % i for i in range(perm.size))
+    bot = "".join("%d " % int(x) for x in perm)
+    return "(%s)\n(%s)\n" % (top, bot)
 
 
 def load_ref() -> Optional[Ref]:

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sstream>
+#include <string>
 
 #include "certFHE.h"
 
@@ -267,6 +269,36 @@ double ref_time_decrypt(uint64_t n, uint64_t d, const uint64_t *key,
         *sink = acc;
     delete[] bl;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+/* Text form (operator<<) of one object.  kind: 0 Ciphertext (a=v, b=bitlen, len words),
+ * 1 SecretKey (a=key, len=d), 2 Context, 3 Plaintext (len = the bit), 4 Permutation (a=perm,
+ * len=size).  Copies at most cap bytes into buf and returns the full length. */
+uint64_t ref_text(int kind, uint64_t n, uint64_t d, const uint64_t *a, const uint64_t *b,
+                  uint64_t len, char *buf, uint64_t cap)
+{
+    std::ostringstream os;
+    Context ctx(n, d);
+    if (kind == 0) {
+        Ciphertext c(a, b, len, ctx);
+        os << c;
+    } else if (kind == 1) {
+        SecretKey sk(ctx);
+        sk.setKey(const_cast<uint64_t *>(a), len);
+        os << sk;
+    } else if (kind == 2) {
+        os << ctx;
+    } else if (kind == 3) {
+        Plaintext p((int)len);
+        os << p;
+    } else if (kind == 4) {
+        Permutation p(a, len);
+        os << p;
+    }
+    const std::string t = os.str();
+    if (buf && cap)
+        std::memcpy(buf, t.data(), t.size() < cap ? t.size() : cap);
+    return t.size();
 }
 
 } // extern "C"

@@ -162,6 +162,19 @@ def main():
         added=hexs(added), multiplied=hexs(mult),
         dec_added=ref.decrypt(n, d, key, added, abl), dec_multiplied=ref.decrypt(n, d, key, mult, mbl))
 
+    # (ix) text forms (operator<<) of every class, small context so the strings stay short ----
+    n, d, seed = 130, 5, 77
+    key = make_key(n, d, seed)
+    cts, _ = ref.encrypt_seq(n, d, key, seed, [1, 0])
+    perm = ref.perm_random(n, seed)
+    out["text"] = dict(
+        n=n, d=d, seed=seed, key=ints(key), ct=hexs(cts), perm=ints(perm),
+        ciphertext=ref.text("ciphertext", n, d, cts, canonical_bitlen(n, 2), cts.size),
+        key_text=ref.text("key", n, d, key, None, d),
+        context=ref.text("context", n, d),
+        plaintext=[ref.text("plaintext", n, d, length=0), ref.text("plaintext", n, d, length=1)],
+        permutation=ref.text("permutation", n, d, perm, None, n))
+
     path = os.path.join(HERE, "csgn_kat.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -61,4 +61,5 @@ from tests.test_oracle_vs_ref import (  # noqa: E402,F401
     test_mul_matches_reference,
     test_permutation_generation_inverse_compose,
     test_permute_ciphertext_and_key,
+    test_text_forms_match_reference,
 )

@@ -9,7 +9,8 @@ import os
 import numpy as np
 import pytest
 
-from oracle.binding import canonical_bitlen, glibc_draws
+from oracle.binding import (canonical_bitlen, glibc_draws, text_ciphertext, text_context, text_key,
+                            text_permutation, text_plaintext)
 
 KAT_PATH = os.path.join(os.path.dirname(__file__), "golden", "csgn_kat.json")
 
@@ -129,6 +130,22 @@ def test_golden_basic_operations(oracle, kat):
     assert np.array_equal(added, words(c["added"])) and np.array_equal(mult, words(c["multiplied"]))
     assert oracle.decrypt(n, key, added) == c["dec_added"] == 1
     assert oracle.decrypt(n, key, mult) == c["dec_multiplied"] == 0
+
+
+def test_golden_text_forms(oracle, kat):
+    """operator<< strings of every class, as printed by the genuine reference."""
+    c = kat["text"]
+    n, d = c["n"], c["d"]
+    key = np.array(c["key"], dtype=np.uint64)
+    cts, _ = oracle.encrypt_seq(n, key, [1, 0], glibc_draws(c["seed"], 2 * (n + 2)))
+    assert np.array_equal(cts, words(c["ct"]))
+    assert text_ciphertext(cts, canonical_bitlen(n, 2)) == c["ciphertext"]
+    assert text_key(key) == c["key_text"]
+    assert text_context(n, d) == c["context"]
+    assert [text_plaintext(0), text_plaintext(1)] == c["plaintext"]
+    perm, _ = oracle.perm_random(n, glibc_draws(c["seed"], 64 * n + 1000))
+    assert perm.tolist() == c["perm"]
+    assert text_permutation(perm) == c["permutation"]
 
 
 def test_oracle_homomorphic_properties(oracle):

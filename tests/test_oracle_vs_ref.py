@@ -11,7 +11,8 @@ import time
 import numpy as np
 import pytest
 
-from oracle.binding import canonical_bitlen, glibc_draws
+from oracle.binding import (canonical_bitlen, glibc_draws, text_ciphertext, text_context, text_key,
+                            text_permutation, text_plaintext)
 
 CONTEXTS = [(1247, 16), (4096, 32), (63, 4), (64, 4), (65, 4), (128, 8), (130, 5), (100, 1)]
 
@@ -218,3 +219,25 @@ def test_large_products_digest(oracle, ref):
         got, _ = oracle.mul(n, a, b)
         assert np.array_equal(got, want)
         assert oracle.digest(got) == oracle.digest(want)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (65, 4), (63, 4)])
+def test_text_forms_match_reference(oracle, ref, n, d):
+    """operator<< of every class (text dump parity)."""
+    key = make_key(n, d, 9)
+    cts, bl = ref.encrypt_seq(n, d, key, 9, [1, 0, 1])
+    dl = oracle.default_len(n)
+    want = ref.text("ciphertext", n, d, cts, canonical_bitlen(n, 3), cts.size)
+    assert want == text_ciphertext(cts, canonical_bitlen(n, 3))
+    assert len(want) == 3 * n + 1
+    # a product keeps the left operand's Bitlen; the dump follows Bitlen word by word
+    prod, pbl = ref.mul(n, d, cts[:2 * dl], canonical_bitlen(n, 2), cts[dl:], canonical_bitlen(n, 2))
+    assert ref.text("ciphertext", n, d, prod, pbl, prod.size) == text_ciphertext(prod, pbl)
+    odd_bl = (np.arange(dl, dtype=np.uint64) % 64) + 1
+    assert ref.text("ciphertext", n, d, cts[:dl], odd_bl, dl) == text_ciphertext(cts[:dl], odd_bl)
+    assert ref.text("key", n, d, key, None, d) == text_key(key)
+    assert ref.text("context", n, d) == text_context(n, d)
+    assert ref.text("plaintext", n, d, length=1) == text_plaintext(1) == "1\n"
+    assert ref.text("plaintext", n, d, length=0) == text_plaintext(0) == "0\n"
+    perm = ref.perm_random(n, 4)
+    assert ref.text("permutation", n, d, perm, None, n) == text_permutation(perm)
