@@ -976,6 +976,283 @@ __global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, FastDiv ddL
 }
 
 // ---------------------------------------------------------------------------------------
+// Permutation, bit-plane form.  One wave owns 64 terms and the permutation is the same for all of
+// them, so it turns the 64 x N bit matrix on its side: a 64x64 bit transpose inside the wave
+// (6 exchange stages: v_permlane32_swap / v_permlane16_swap for the two coarse ones, DPP lane
+// exchange + v_alignbit + v_bfi for the four inside a 16-bit field) leaves "bit j of 64 terms"
+// in one 64-bit word.  Moving bit j to bit j' is then a plain 8-byte LDS move, and a second
+// transpose turns the planes back into terms.
+// ~1.2 lane-operations per bit instead of ~6 for the ballot form above.
+// ---------------------------------------------------------------------------------------
+template <int K>
+__device__ inline u32 lane_xor(u32 v)
+{
+    // all on the VALU (DPP): an LDS-crossbar swizzle costs a round trip the two waves a SIMD
+    // holds here cannot hide
+    if (K == 8)
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xF, 0xF, true);
+    if (K == 4) {
+        // lanes with bit 2 clear read lane+4 (row_shl:4, banks 0 and 2), the others lane-4
+        int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+        return (u32)__builtin_amdgcn_update_dpp(t, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+    }
+    if (K == 2)
+        return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true);
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+}
+
+// per-lane constants of the four in-word stages (K = 8, 4, 2, 1)
+struct TrLane {
+    u32 rot[4];     // rotate-right amount that lines the partner's half up with mine
+    u32 keep[4];    // bits of my own word that stay
+};
+
+__device__ inline TrLane tr_lane(u32 lane)
+{
+    const u32 M[4] = {0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+    TrLane c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 k = 8u >> i;
+        const bool upper = (lane & k) != 0;
+        c.rot[i] = upper ? k : 32u - k;
+        c.keep[i] = upper ? ~M[i] : M[i];
+    }
+    return c;
+}
+
+// One in-word stage on R independent registers, written operation by operation (all lane
+// exchanges, then all rotates, then all merges) and pinned with sched_barrier: a dependent VALU
+// result is not available to the next instruction of the same wave without a stall, and only one
+// or two waves share a SIMD here, so the independent registers have to interleave.
+template <int I, int R>
+__device__ inline void tr_stage_n(u32 (&h)[R], const TrLane &c)
+{
+    u32 y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        y[r] = lane_xor<(8 >> I)>(h[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        y[r] = __builtin_amdgcn_alignbit(y[r], y[r], c.rot[I]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r)   // (h & keep) | (y & ~keep); hipcc otherwise emits and/and/or
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h[r]) : "v"(c.keep[I]), "v"(h[r]), "v"(y[r]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// On return bit c of lane b's word is bit b of lane c's input (LSB = bit 0); h[2q], h[2q+1] are
+// the low and high halves of word q.  Stages 32 and 16 are pure data movement between registers
+// and lane groups:
+//   32: lanes 0..31 hand their high words to lanes 32..63 and take those lanes' low words
+//       (v_permlane32_swap);
+//   16: the same between 16-bit halves and 16-lane rows -- gather the low halves of (lo,hi) in
+//       one register and the high halves in another (v_perm_b32), v_permlane16_swap, scatter back.
+template <int Q>
+__device__ inline void wave_transpose64_n(u32 (&h)[2 * Q], const TrLane &c)
+{
+    u32 a[Q], b[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        auto s32 = __builtin_amdgcn_permlane32_swap(h[2 * q], h[2 * q + 1], false, false);
+        a[q] = s32[0];
+        b[q] = s32[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        h[2 * q] = __builtin_amdgcn_perm(b[q], a[q], 0x05040100u);       // low halves
+        h[2 * q + 1] = __builtin_amdgcn_perm(b[q], a[q], 0x07060302u);   // high halves
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        auto s16 = __builtin_amdgcn_permlane16_swap(h[2 * q], h[2 * q + 1], false, false);
+        a[q] = s16[0];
+        b[q] = s16[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        h[2 * q] = __builtin_amdgcn_perm(b[q], a[q], 0x05040100u);
+        h[2 * q + 1] = __builtin_amdgcn_perm(b[q], a[q], 0x07060302u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tr_stage_n<0, 2 * Q>(h, c);
+    tr_stage_n<1, 2 * Q>(h, c);
+    tr_stage_n<2, 2 * Q>(h, c);
+    tr_stage_n<3, 2 * Q>(h, c);
+}
+
+constexpr int kPermUnroll = 5;
+
+// Workgroup = ONE wave = 64 terms at a time, persistent over groups of 64 terms.  LDS: rows[64][SA]
+// (SA = dL | 1 words, conflict-free column reads), planes[n_bits + 1] (the last entry stays 0: "no
+// source"), psrc[dL*64] (u16 source plane of every output bit).  The next group's terms are
+// loaded into registers (LQ words per lane, all in flight) while this group is transposed.
+template <int LQ, bool PIPE, int UW>
+__global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastDiv dUd, u64 out_terms,
+                                                       u64 in_stride_words,
+                                                       const u64 *__restrict__ terms,
+                                                       const u32 *__restrict__ perm,
+                                                       u64 *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const u32 SA = dL | 1u;
+    u64 *rows = reinterpret_cast<u64 *>(smem_raw);
+    u64 *planes = rows + 64u * SA;
+    unsigned short *psrc = reinterpret_cast<unsigned short *>(planes + n_bits + 1);   // dL*64 entries
+    const u32 lane = threadIdx.x;
+    const TrLane trc = tr_lane(lane);
+    const u32 nb = (u32)n_bits;
+    const u32 Ud = dL / UW;                        // staging units (UW words = 8 or 16 bytes) per term
+    const u32 nu = 64u * Ud;                       // units in a full group
+    const u64 groups = (out_terms + 63) / 64;
+    typedef u64 StageUnit __attribute__((ext_vector_type(UW)));
+
+    // this lane's LQ staging slots: unit u = q*64 + lane of the group -> (term t, word k)
+    u32 rowoff[LQ];        // t*SA + k in rows[]
+    u32 tq[LQ];            // t
+#pragma unroll
+    for (int q = 0; q < LQ; ++q) {
+        const u32 u = min((u32)q * 64u + lane, nu - 1u);
+        const u32 t = csgn_fastdiv(u, dUd);
+        tq[q] = t;
+        rowoff[q] = t * SA + (u - t * Ud) * UW;
+    }
+    const u64 gskip = in_stride_words - SA;        // input offset = rowoff + t*(stride - SA)
+    StageUnit v[LQ];
+    auto fetch = [&](u64 g) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        const u64 *base = terms + t0 * in_stride_words;
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) {
+            // a term past the end re-reads the group's first term (discarded below)
+            const u64 off = tq[q] < nt ? rowoff[q] + tq[q] * gskip : 0ull;
+            v[q] = *reinterpret_cast<const StageUnit *>(base + off);
+        }
+    };
+    auto rows_put = [&](u32 off, StageUnit x, bool live) {
+#pragma unroll
+        for (int i = 0; i < UW; ++i)     // SA is odd: a row starts 8-byte, not 16-byte, aligned
+            rows[off + i] = live ? x[i] : 0ull;
+    };
+    auto rows_get = [&](u32 off) {
+        StageUnit x;
+#pragma unroll
+        for (int i = 0; i < UW; ++i)
+            x[i] = rows[off + i];
+        return x;
+    };
+
+    u64 g = blockIdx.x;
+    if (g < groups)
+        fetch(g);
+    // 0. source plane of every output bit (nb = "none": padding bits and out-of-range entries)
+    for (u32 j0 = 0; j0 < 64u * dL; j0 += 64u * kPermUnroll) {
+        u32 p[kPermUnroll];
+#pragma unroll
+        for (int q = 0; q < kPermUnroll; ++q)
+            p[q] = perm[min(j0 + (u32)q * 64u + lane, nb - 1u)];
+#pragma unroll
+        for (int q = 0; q < kPermUnroll; ++q) {
+            const u32 j = j0 + (u32)q * 64u + lane;
+            if (j < 64u * dL)
+                psrc[j] = (unsigned short)(j < nb ? min(p[q], nb) : nb);
+        }
+    }
+    if (lane == 0)
+        planes[nb] = 0;
+
+    // Order of the vector-memory operations inside one turn: wait for this group's terms, issue the
+    // PREVIOUS group's stores (results parked in o[] when PIPE), issue the next group's loads, then
+    // compute.  Everything issued has the whole compute phase to complete, so the vmcnt(0) at the
+    // top of the next turn finds it done (loads and stores share one in-order counter on gfx9).
+    StageUnit o[PIPE ? LQ : 1];
+    u64 gprev = ~0ull;
+    auto flush = [&](u64 gp) {
+        const u64 t0 = gp * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        StageUnit *obase = reinterpret_cast<StageUnit *>(out + t0 * dL);
+#pragma unroll
+        for (int q = 0; q < LQ; ++q)
+            if ((u32)q * 64u + lane < nt * Ud)
+                obase[(u32)q * 64u + lane] = o[PIPE ? q : 0];
+    };
+
+    for (; g < groups; g += gridDim.x) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        // 1. rows <- the 64 terms fetched earlier (slots past the end repeat the last unit)
+#pragma unroll
+        for (int q = 0; q < LQ; ++q)
+            rows_put(rowoff[q], v[q], tq[q] < nt);
+        __syncthreads();
+        if (PIPE && gprev != ~0ull)
+            flush(gprev);
+        if (g + gridDim.x < groups)
+            fetch(g + gridDim.x);
+        // 2. rows -> bit planes: lane b ends up with term-bit j = w*64 + 63 - b of all 64 terms.
+        //    kPermUnroll words in flight: the six exchange stages of one transpose are a serial
+        //    chain of cross-lane latencies, independent words fill the gaps.
+        for (u32 w0 = 0; w0 < dL; w0 += kPermUnroll) {
+            u32 h[2 * kPermUnroll];
+#pragma unroll
+            for (int q = 0; q < kPermUnroll; ++q) {
+                const u32 w = min(w0 + (u32)q, dL - 1u);
+                const u64 x = rows[lane * SA + w];
+                h[2 * q] = (u32)x;
+                h[2 * q + 1] = (u32)(x >> 32);
+            }
+            wave_transpose64_n<kPermUnroll>(h, trc);
+#pragma unroll
+            for (int q = 0; q < kPermUnroll; ++q) {
+                const u32 j = (w0 + (u32)q) * 64u + 63u - lane;
+                if (w0 + (u32)q < dL && j < nb)
+                    planes[j] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
+            }
+        }
+        __syncthreads();
+        // 3. new bit j <- old bit perm[j]; planes -> rows
+        for (u32 w0 = 0; w0 < dL; w0 += kPermUnroll) {
+            u32 h[2 * kPermUnroll];
+#pragma unroll
+            for (int q = 0; q < kPermUnroll; ++q) {
+                const u32 w = min(w0 + (u32)q, dL - 1u);
+                const u64 y = planes[psrc[w * 64u + 63u - lane]];
+                h[2 * q] = (u32)y;
+                h[2 * q + 1] = (u32)(y >> 32);
+            }
+            wave_transpose64_n<kPermUnroll>(h, trc);
+#pragma unroll
+            for (int q = 0; q < kPermUnroll; ++q)
+                if (w0 + (u32)q < dL)
+                    rows[lane * SA + w0 + (u32)q] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
+        }
+        __syncthreads();
+        // 4. rows -> out, coalesced: now, or parked in registers until the next turn's loads are in
+        if (PIPE) {
+#pragma unroll
+            for (int q = 0; q < LQ; ++q)
+                o[q] = rows_get(rowoff[q]);
+            gprev = g;
+        } else {
+            StageUnit *obase = reinterpret_cast<StageUnit *>(out + t0 * dL);
+#pragma unroll
+            for (int q = 0; q < LQ; ++q)
+                if ((u32)q * 64u + lane < nt * Ud)
+                    obase[(u32)q * 64u + lane] = rows_get(rowoff[q]);
+        }
+        __syncthreads();
+    }
+    if (PIPE && gprev != ~0ull)
+        flush(gprev);
+}
+
+// ---------------------------------------------------------------------------------------
 // harness kernels (definitions shared with oracle/csgn_oracle.c)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_synth_fill(u64 seed, u32 dL, u64 tail, u64 first_word,
@@ -1804,6 +2081,58 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     if (out_terms == 0)
         return hipSuccess;
     const u64 stride = per_term ? dL : terms_in * dL;
+    // bit-plane form (64 terms per wave) unless the batch is too small to fill a wave or the LDS
+    // image (rows + planes) would not fit; CSGN_PERM_BALLOT=1 forces the ballot form
+    {
+        const size_t lds = ((size_t)64 * (dL | 1) + n_bits + 1) * 8 + dL * 64 * 2;
+        if (terms_in != 0 && out_terms >= 16 && dL <= 64 && lds <= 160 * 1024 && !env_int("CSGN_PERM_BALLOT", 0)) {
+            const u64 groups = (out_terms + 63) / 64;
+            // persistent waves: as many as fit the LDS of the chip, equal group counts per wave
+            const u64 resident = 256ull * std::max<u64>(1, (160 * 1024) / lds);
+            const u64 rounds = (groups + resident - 1) / resident;
+            const u32 grid = (u32)((groups + rounds - 1) / rounds);
+            // 16-byte staging accesses when every term starts 16-byte aligned
+            const bool wide = dL % 2 == 0 && stride % 2 == 0 && (((uintptr_t)terms | (uintptr_t)out) & 15) == 0 &&
+                              !env_int("CSGN_PERM_NARROW", 0);
+            const u32 Ud = (u32)(wide ? dL / 2 : dL);
+            const FastDiv dUd = csgn_fastdiv_make(Ud);
+#define CSGN_PLANES_LAUNCH(LQ, PIPE, UW)                                                            \
+    do {                                                                                            \
+        if (lds > 65536) {      /* beyond the default dynamic-LDS window (N > ~3500 bits) */        \
+            hipError_t e = hipFuncSetAttribute(                                                     \
+                reinterpret_cast<const void *>(&k_permute_planes<LQ, PIPE, UW>),                    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e != hipSuccess)                                                                    \
+                return e;                                                                           \
+        }                                                                                           \
+        k_permute_planes<LQ, PIPE, UW><<<grid, 64, lds, s>>>(n_bits, (u32)dL, dUd, out_terms,       \
+                                                             stride, terms, perm, out);             \
+    } while (0)
+            if (wide) {
+                if (Ud <= 4)
+                    CSGN_PLANES_LAUNCH(4, true, 2);
+                else if (Ud <= 10)
+                    CSGN_PLANES_LAUNCH(10, true, 2);
+                else if (Ud <= 16)
+                    CSGN_PLANES_LAUNCH(16, true, 2);
+                else
+                    CSGN_PLANES_LAUNCH(32, false, 2);
+            } else {
+                if (Ud <= 4)
+                    CSGN_PLANES_LAUNCH(4, true, 1);
+                else if (Ud <= 8)
+                    CSGN_PLANES_LAUNCH(8, true, 1);
+                else if (Ud <= 20)
+                    CSGN_PLANES_LAUNCH(20, true, 1);
+                else if (Ud <= 32)
+                    CSGN_PLANES_LAUNCH(32, true, 1);
+                else
+                    CSGN_PLANES_LAUNCH(64, false, 1);
+            }
+#undef CSGN_PLANES_LAUNCH
+            return hipGetLastError();
+        }
+    }
     // terms per workgroup: a multiple of the 4 waves, LDS image <= 32 KB
     u32 tb = 64;
     while (tb > 4 && (u64)tb * dL * 8 > 32768)

@@ -517,7 +517,8 @@ def test_circuit_config5_style(hip, oracle):
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 1247, 2048, 2100, 4032, 4096, 8192, 10000])
 def test_permute_all_word_counts(hip, oracle, n):
-    """Every instantiation of the ballot bit-gather (4..64 words per pass, multi-pass above 64)."""
+    """Small batches (9 terms: the ballot bit-gather, 4..64 words per pass, multi-pass above 64),
+    first-term truncation and the per-term extension, for every word count."""
     dl = oracle.default_len(n)
     rng = np.random.default_rng(n)
     perm = rng.permutation(n).astype(np.uint64)
@@ -532,6 +533,36 @@ def test_permute_all_word_counts(hip, oracle, n):
     for i in range(3):
         assert np.array_equal(first[i * dl:(i + 1) * dl], out[3 * i * dl:(3 * i + 1) * dl])
     assert np.array_equal(hip.download(hip.permute_uniform(n, 3, 3, hip.upload(w), dperm, per_term=True)), out)
+
+
+@pytest.mark.parametrize("n", [1, 31, 63, 64, 65, 130, 1247, 1280, 4096, 4100, 8192, 10000])
+@pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot"])
+def test_permute_kernel_forms(hip, oracle, monkeypatch, n, form):
+    """Bit-plane form (64 terms per wave, 64x64 bit transposes; 16- and 8-byte staging) against
+    the ballot form and the oracle, on batches that leave ragged last waves; strided first-term
+    input and per-term mode."""
+    monkeypatch.setenv("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
+    monkeypatch.setenv("CSGN_PERM_NARROW", "1" if form == "planes-narrow" else "0")
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(1000 + n)
+    perm = rng.permutation(n).astype(np.uint64)
+    dperm = hip.upload(perm.astype(np.uint32))
+    for nb in (16, 64, 65, 200, 64 * 40 + 3):
+        w = oracle.synth(nb, n, 0, nb * dl)
+        dw = hip.upload(w)
+        out = hip.download(hip.permute_uniform(n, nb, 1, dw, dperm))
+        for i in range(nb):
+            assert np.array_equal(out[i * dl:(i + 1) * dl],
+                                  oracle.permute_ciphertext(n, perm, w[i * dl:(i + 1) * dl])), (n, nb, i)
+        if nb % 4 == 0:
+            first = hip.download(hip.permute_uniform(n, nb // 4, 4, dw, dperm))
+            assert np.array_equal(first.reshape(-1, dl), out.reshape(-1, dl)[::4])
+            assert np.array_equal(hip.download(hip.permute_uniform(n, nb // 4, 4, dw, dperm, per_term=True)), out)
+    # inverse permutation restores the input
+    inv = hip.upload(oracle.perm_inverse(perm).astype(np.uint32))
+    w = oracle.synth(77, n, 0, 128 * dl)
+    once = hip.permute_uniform(n, 128, 1, hip.upload(w), dperm)
+    assert np.array_equal(hip.download(hip.permute_uniform(n, 128, 1, once, inv)), w)
 
 
 @pytest.mark.parametrize("n,d", [(8320, 8), (8250, 5), (1247, 16), (193, 6), (704, 9), (1088, 7)])

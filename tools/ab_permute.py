@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Time csgn_permute_uniform in its kernel forms (bit-plane with 16-/8-byte staging, ballot), GB/s
+of input+output, in ONE process (dev tool)."""
+import os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from csgn_amd.batch import HipPath
+
+hip = HipPath(0)
+
+
+def timed(fn, rounds=9):
+    fn(); torch.cuda.synchronize(); ts = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b) / 1e3)
+    return statistics.median(ts)
+
+
+for n, batch in [(1247, 1 << 20), (1247, 1 << 16), (4096, 1 << 18), (130, 1 << 20), (10000, 1 << 16)]:
+    dl = hip.default_len(n)
+    W = hip.synth_fill(3, n, 0, batch * dl)
+    perm = hip.upload(np.random.default_rng(3).permutation(n).astype(np.uint32))
+    row = []
+    for form in ("planes", "narrow", "ballot") * 2:
+        os.environ["CSGN_PERM_BALLOT"] = "1" if form == "ballot" else "0"
+        os.environ["CSGN_PERM_NARROW"] = "1" if form == "narrow" else "0"
+        t = timed(lambda: hip.permute_uniform(n, batch, 1, W, perm))
+        row.append("%s %.0f" % (form, batch * 2 * 8 * dl / t / 1e9))
+    print(f"N={n} batch={batch}: " + " | ".join(row), flush=True)
+    del W
