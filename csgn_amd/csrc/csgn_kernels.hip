@@ -1005,6 +1005,7 @@ __device__ inline u32 lane_xor(u32 v)
 struct TrLane {
     u32 rot[4];     // rotate-right amount that lines the partner's half up with mine
     u32 keep[4];    // bits of my own word that stay
+    u32 sel8;       // v_perm_b32 selector of the byte stage
 };
 
 __device__ inline TrLane tr_lane(u32 lane)
@@ -1018,6 +1019,7 @@ __device__ inline TrLane tr_lane(u32 lane)
         c.rot[i] = upper ? k : 32u - k;
         c.keep[i] = upper ? ~M[i] : M[i];
     }
+    c.sel8 = (lane & 8u) ? 0x03070105u : 0x06020400u;
     return c;
 }
 
@@ -1080,7 +1082,19 @@ __device__ inline void wave_transpose64_n(u32 (&h)[2 * Q], const TrLane &c)
         h[2 * q + 1] = __builtin_amdgcn_perm(b[q], a[q], 0x07060302u);
     }
     __builtin_amdgcn_sched_barrier(0);
-    tr_stage_n<0, 2 * Q>(h, c);
+    // stage 8 moves whole bytes: one v_perm_b32 picks {own b0, partner b0, own b2, partner b2}
+    // (lanes with bit 3 clear) or {partner b1, own b1, partner b3, own b3}
+    {
+        u32 y[2 * Q];
+#pragma unroll
+        for (int r = 0; r < 2 * Q; ++r)
+            y[r] = lane_xor<8>(h[r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2 * Q; ++r)
+            h[r] = __builtin_amdgcn_perm(y[r], h[r], c.sel8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     tr_stage_n<1, 2 * Q>(h, c);
     tr_stage_n<2, 2 * Q>(h, c);
     tr_stage_n<3, 2 * Q>(h, c);
@@ -1089,8 +1103,8 @@ __device__ inline void wave_transpose64_n(u32 (&h)[2 * Q], const TrLane &c)
 constexpr int kPermUnroll = 5;
 
 // Workgroup = ONE wave = 64 terms at a time, persistent over groups of 64 terms.  LDS: rows[64][SA]
-// (SA = dL | 1 words, conflict-free column reads), planes[n_bits + 1] (the last entry stays 0: "no
-// source"), psrc[dL*64] (u16 source plane of every output bit).  The next group's terms are
+// (SA odd: conflict-free column reads), planes[dLp*64 + 1] (the last entry stays 0: "no source"),
+// psrc[dLp*64] (u16 source plane of every output bit).  The next group's terms are
 // loaded into registers (LQ words per lane, all in flight) while this group is transposed.
 template <int LQ, bool PIPE, int UW>
 __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastDiv dUd, u64 out_terms,
@@ -1100,10 +1114,12 @@ __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastD
                                                        u64 *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const u32 SA = dL | 1u;
+    const u32 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
+    const u32 SA = dLp | 1u;
+    const u32 none = dLp * 64u;                    // index of the all-zero plane
     u64 *rows = reinterpret_cast<u64 *>(smem_raw);
-    u64 *planes = rows + 64u * SA;
-    unsigned short *psrc = reinterpret_cast<unsigned short *>(planes + n_bits + 1);   // dL*64 entries
+    u64 *planes = rows + 64u * SA;                 // none + 1 entries
+    unsigned short *psrc = reinterpret_cast<unsigned short *>(planes + none + 1);   // none entries
     const u32 lane = threadIdx.x;
     const TrLane trc = tr_lane(lane);
     const u32 nb = (u32)n_bits;
@@ -1151,8 +1167,8 @@ __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastD
     u64 g = blockIdx.x;
     if (g < groups)
         fetch(g);
-    // 0. source plane of every output bit (nb = "none": padding bits and out-of-range entries)
-    for (u32 j0 = 0; j0 < 64u * dL; j0 += 64u * kPermUnroll) {
+    // 0. source plane of every output bit (`none` for padding bits and out-of-range entries)
+    for (u32 j0 = 0; j0 < none; j0 += 64u * kPermUnroll) {
         u32 p[kPermUnroll];
 #pragma unroll
         for (int q = 0; q < kPermUnroll; ++q)
@@ -1160,12 +1176,11 @@ __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastD
 #pragma unroll
         for (int q = 0; q < kPermUnroll; ++q) {
             const u32 j = j0 + (u32)q * 64u + lane;
-            if (j < 64u * dL)
-                psrc[j] = (unsigned short)(j < nb ? min(p[q], nb) : nb);
+            psrc[j] = (unsigned short)(j < nb && p[q] < nb ? p[q] : none);
         }
     }
     if (lane == 0)
-        planes[nb] = 0;
+        planes[none] = 0;
 
     // Order of the vector-memory operations inside one turn: wait for this group's terms, issue the
     // PREVIOUS group's stores (results parked in o[] when PIPE), issue the next group's loads, then
@@ -1197,40 +1212,35 @@ __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastD
             fetch(g + gridDim.x);
         // 2. rows -> bit planes: lane b ends up with term-bit j = w*64 + 63 - b of all 64 terms.
         //    kPermUnroll words in flight: the six exchange stages of one transpose are a serial
-        //    chain of cross-lane latencies, independent words fill the gaps.
-        for (u32 w0 = 0; w0 < dL; w0 += kPermUnroll) {
+        //    chain, independent words fill the gaps.  dLp is dL rounded up to kPermUnroll and every
+        //    LDS array is sized for it, so the loops need no guards (tail columns hold don't-cares).
+        for (u32 w0 = 0; w0 < dLp; w0 += kPermUnroll) {
             u32 h[2 * kPermUnroll];
 #pragma unroll
             for (int q = 0; q < kPermUnroll; ++q) {
-                const u32 w = min(w0 + (u32)q, dL - 1u);
-                const u64 x = rows[lane * SA + w];
+                const u64 x = rows[lane * SA + w0 + (u32)q];
                 h[2 * q] = (u32)x;
                 h[2 * q + 1] = (u32)(x >> 32);
             }
             wave_transpose64_n<kPermUnroll>(h, trc);
 #pragma unroll
-            for (int q = 0; q < kPermUnroll; ++q) {
-                const u32 j = (w0 + (u32)q) * 64u + 63u - lane;
-                if (w0 + (u32)q < dL && j < nb)
-                    planes[j] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
-            }
+            for (int q = 0; q < kPermUnroll; ++q)
+                planes[(w0 + (u32)q) * 64u + 63u - lane] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
         }
         __syncthreads();
         // 3. new bit j <- old bit perm[j]; planes -> rows
-        for (u32 w0 = 0; w0 < dL; w0 += kPermUnroll) {
+        for (u32 w0 = 0; w0 < dLp; w0 += kPermUnroll) {
             u32 h[2 * kPermUnroll];
 #pragma unroll
             for (int q = 0; q < kPermUnroll; ++q) {
-                const u32 w = min(w0 + (u32)q, dL - 1u);
-                const u64 y = planes[psrc[w * 64u + 63u - lane]];
+                const u64 y = planes[psrc[(w0 + (u32)q) * 64u + 63u - lane]];
                 h[2 * q] = (u32)y;
                 h[2 * q + 1] = (u32)(y >> 32);
             }
             wave_transpose64_n<kPermUnroll>(h, trc);
 #pragma unroll
             for (int q = 0; q < kPermUnroll; ++q)
-                if (w0 + (u32)q < dL)
-                    rows[lane * SA + w0 + (u32)q] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
+                rows[lane * SA + w0 + (u32)q] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
         }
         __syncthreads();
         // 4. rows -> out, coalesced: now, or parked in registers until the next turn's loads are in
@@ -2084,13 +2094,17 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     // bit-plane form (64 terms per wave) unless the batch is too small to fill a wave or the LDS
     // image (rows + planes) would not fit; CSGN_PERM_BALLOT=1 forces the ballot form
     {
-        const size_t lds = ((size_t)64 * (dL | 1) + n_bits + 1) * 8 + dL * 64 * 2;
+        const u64 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
+        const size_t lds = ((size_t)64 * (dLp | 1) + dLp * 64 + 1) * 8 + dLp * 64 * 2;
         if (terms_in != 0 && out_terms >= 16 && dL <= 64 && lds <= 160 * 1024 && !env_int("CSGN_PERM_BALLOT", 0)) {
             const u64 groups = (out_terms + 63) / 64;
-            // persistent waves: as many as fit the LDS of the chip, equal group counts per wave
-            const u64 resident = 256ull * std::max<u64>(1, (160 * 1024) / lds);
-            const u64 rounds = (groups + resident - 1) / resident;
-            const u32 grid = (u32)((groups + rounds - 1) / rounds);
+            // persistent waves: as many as the chip holds at once, equal group counts per wave
+            int cus = 256;
+            {
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess)
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            }
             // 16-byte staging accesses when every term starts 16-byte aligned
             const bool wide = dL % 2 == 0 && stride % 2 == 0 && (((uintptr_t)terms | (uintptr_t)out) & 15) == 0 &&
                               !env_int("CSGN_PERM_NARROW", 0);
@@ -2105,6 +2119,19 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
             if (e != hipSuccess)                                                                    \
                 return e;                                                                           \
         }                                                                                           \
+        /* how many of these waves a CU really holds: the runtime's answer, and LDS handed out in  \
+           granules (measured: 7 x 23.3 KB is reported to fit 160 KB but the seventh wave runs after \
+           the other six).  A wave beyond that number would start when the rest have finished. */   \
+        int per_cu = 0;                                                                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_permute_planes<LQ, PIPE, UW>, 64, \
+                                                         lds) != hipSuccess || per_cu < 1)          \
+            per_cu = 1;                                                                             \
+        per_cu = std::max(1, std::min(per_cu, (int)(160 * 1024 / ((lds + 1023) / 1024 * 1024))));   \
+        if (const int cap = env_int("CSGN_PERM_WAVES", 0))                                          \
+            per_cu = std::min(per_cu, cap);                                                         \
+        const u64 resident = (u64)cus * (u64)per_cu;                                                \
+        const u64 rounds = (groups + resident - 1) / resident;                                      \
+        const u32 grid = (u32)((groups + rounds - 1) / rounds);                                     \
         k_permute_planes<LQ, PIPE, UW><<<grid, 64, lds, s>>>(n_bits, (u32)dL, dUd, out_terms,       \
                                                              stride, terms, perm, out);             \
     } while (0)
