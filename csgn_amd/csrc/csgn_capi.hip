@@ -281,15 +281,36 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
                          uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
 {
     REQUIRE(d_off_left && d_off_right && d_off_out && h_plan, "null pointer");
-    u64 *d_plan = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_plan, csgn::mul_ragged_plan_scratch_words(batch) * sizeof(u64)));
+    // The call returns host numbers, so it ends with a stream synchronise anyway; its small device
+    // scratch is kept per host thread and device (grow-only) because hipMalloc + hipFree around
+    // every plan cost more than the plan (hipFree synchronises the whole device).
+    struct PlanScratch {
+        u64 *p = nullptr;
+        size_t words = 0;
+    };
+    static thread_local PlanScratch cache[16];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t need = csgn::mul_ragged_plan_scratch_words(batch);
+    PlanScratch local;
+    PlanScratch &sc = (dev >= 0 && dev < 16) ? cache[dev] : local;
+    if (sc.words < need) {
+        if (sc.p)
+            (void)hipFree(sc.p);
+        sc.p = nullptr;
+        sc.words = 0;
+        const size_t grow = need + need / 2 + 1024;
+        HIP_TRY(hipMalloc((void **)&sc.p, grow * sizeof(u64)));
+        sc.words = grow;
+    }
     hipError_t e = csgn::mul_ragged_plan(batch, (const u64 *)d_off_left, (const u64 *)d_off_right,
-                                         (u64 *)d_off_out, d_plan, S(stream));
+                                         (u64 *)d_off_out, sc.p, S(stream));
     if (e == hipSuccess)
-        e = hipMemcpyAsync(h_plan, d_plan, 4 * sizeof(u64), hipMemcpyDeviceToHost, S(stream));
+        e = hipMemcpyAsync(h_plan, sc.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, S(stream));
     if (e == hipSuccess)
         e = hipStreamSynchronize(S(stream));
-    (void)hipFree(d_plan);
+    if (&sc == &local && local.p)
+        (void)hipFree(local.p);
     if (e != hipSuccess)
         return hip_fail(e, "csgn_mul_ragged_plan");
     return CSGN_OK;

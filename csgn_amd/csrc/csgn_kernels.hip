@@ -254,7 +254,23 @@ __device__ inline u32 csr_find(const u64 *__restrict__ off, u32 lo, u32 hi, u64 
     return lo;
 }
 
-template <typename Unit>
+// largest p >= lo with off[p] <= term, looking near lo first (requires off[lo] <= term): the
+// common answers are lo itself (one load) or a pair a few steps on
+__device__ inline u32 csr_gallop(const u64 *__restrict__ off, u32 lo, u32 batch, u64 term)
+{
+    u32 hi = lo + 1u, step = 1u;
+    while (hi < batch && off[hi] <= term) {
+        lo = hi;
+        step <<= 1;
+        hi = (batch - lo > step) ? lo + step : batch;
+    }
+    return csr_find(off, lo, hi, term);
+}
+
+// A workgroup owns C consecutive 4 KiB chunks of the flattened output: one uniform search for its
+// first term, then every wave walks forward from the pair it was in (csr_gallop), so the
+// log2(batch) dependent loads are paid once per C chunks instead of twice per chunk.
+template <typename Unit, int C>
 __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R,
@@ -264,28 +280,36 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU)
 {
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const u64 g0 = unit_base + (u64)bid * 256u;
-    if (g0 >= total_units)
+    const u64 g_begin = unit_base + (u64)bid * (256u * C);
+    if (g_begin >= total_units)
         return;
-    const u64 term0 = g0 / U;                                   // wave-uniform
-    const u32 p0 = csr_find(offOut, 0u, batch, term0);          // uniform search: loads broadcast
-    const u64 g = g0 + threadIdx.x;
-    if (g >= total_units)
-        return;
-    // this lane's term: g0 = term0*U + r0, so (r0 + tid) / U is a 32-bit division
-    const u32 r = (u32)(g0 - term0 * U) + threadIdx.x;
-    const u32 dt = csgn_fastdiv(r, dU);
-    const u64 term = term0 + dt;
-    const u32 k = r - dt * U;
-    const u32 p = csr_find(offOut, p0, batch, term);           // empty pairs make the span unbounded
-    const u64 l0 = offL[p], r0 = offR[p];
-    const u32 t2 = (u32)(offR[p + 1] - r0);
-    const u32 q = (u32)(term - offOut[p]);                      // product term index inside the pair
-    const u32 i = q / t2, j = q - i * t2;
-    unit_store<Unit, true>(out + g, L[(l0 + i) * U + k] & R[(r0 + j) * U + k]);
+    const u64 term0 = g_begin / U;                              // workgroup-uniform
+    const u32 r0blk = (u32)(g_begin - term0 * U);
+    u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+        if (g_begin + (u32)c * 256u >= total_units)
+            break;
+        // this lane's term: a 32-bit division of its distance from the workgroup's first term
+        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
+        const u32 dt = csgn_fastdiv(r, dU);
+        const u64 term = term0 + dt;
+        const u32 k = r - dt * U;
+        u32 p = pw;
+        if (g < total_units) {
+            p = csr_gallop(offOut, pw, batch, term);            // runs of empty pairs are walked over
+            const u64 l0 = offL[p], rr0 = offR[p];
+            const u32 t2 = (u32)(offR[p + 1] - rr0);
+            const u32 q = (u32)(term - offOut[p]);              // product term index inside the pair
+            const u32 i = q / t2, j = q - i * t2;
+            unit_store<Unit, true>(out + g, L[(l0 + i) * U + k] & R[(rr0 + j) * U + k]);
+        }
+        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);       // later chunks start from here
+    }
 }
 
-template <typename Unit>
+template <typename Unit, int C>
 __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R,
@@ -295,24 +319,32 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU)
 {
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const u64 g0 = unit_base + (u64)bid * 256u;
-    if (g0 >= total_units)
+    const u64 g_begin = unit_base + (u64)bid * (256u * C);
+    if (g_begin >= total_units)
         return;
-    const u64 term0 = g0 / U;
-    const u32 p0 = csr_find(offOut, 0u, batch, term0);
-    const u64 g = g0 + threadIdx.x;
-    if (g >= total_units)
-        return;
-    const u32 r = (u32)(g0 - term0 * U) + threadIdx.x;
-    const u32 dt = csgn_fastdiv(r, dU);
-    const u64 term = term0 + dt;
-    const u32 k = r - dt * U;
-    const u32 p = csr_find(offOut, p0, batch, term);
-    const u64 l0 = offL[p], r0 = offR[p];
-    const u64 t1 = offL[p + 1] - l0;
-    const u64 q = term - offOut[p];                             // offOut[p] = l0 + r0
-    const Unit v = (q < t1) ? L[(l0 + q) * U + k] : R[(r0 + (q - t1)) * U + k];
-    unit_store<Unit, true>(out + g, v);
+    const u64 term0 = g_begin / U;
+    const u32 r0blk = (u32)(g_begin - term0 * U);
+    u32 pw = csr_find(offOut, 0u, batch, term0);
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+        if (g_begin + (u32)c * 256u >= total_units)
+            break;
+        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
+        const u32 dt = csgn_fastdiv(r, dU);
+        const u64 term = term0 + dt;
+        const u32 k = r - dt * U;
+        u32 p = pw;
+        if (g < total_units) {
+            p = csr_gallop(offOut, pw, batch, term);
+            const u64 l0 = offL[p], rr0 = offR[p];
+            const u64 t1 = offL[p + 1] - l0;
+            const u64 q = term - offOut[p];                     // offOut[p] = l0 + rr0
+            const Unit v = (q < t1) ? L[(l0 + q) * U + k] : R[(rr0 + (q - t1)) * U + k];
+            unit_store<Unit, true>(out + g, v);
+        }
+        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);
+    }
 }
 
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
@@ -1509,6 +1541,20 @@ MulTuning mul_tuning()
     return t;
 }
 
+// 4 KiB chunks per workgroup of the flat ragged kernels: as many as 8 (the workgroup's first search
+// is paid once per C chunks) while the grid still has >= 8192 workgroups to fill the chip with.
+// CSGN_RAGGED_C = 1, 2, 4, 8, 16 overrides.
+static int ragged_chunks(u64 total_units)
+{
+    const int forced = env_int("CSGN_RAGGED_C", 0);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16)
+        return forced;
+    int c = 1;
+    while (c < 8 && total_units / (256u * 2u * (u64)c) >= 8192u)
+        c *= 2;
+    return c;
+}
+
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s)
 {
@@ -1581,19 +1627,32 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    for (u64 u0 = 0; u0 < total_units; u0 += kMaxBlocks256 * 256u) {
-        const u64 nu = (total_units - u0 < kMaxBlocks256 * 256u) ? total_units - u0 : kMaxBlocks256 * 256u;
-        const u32 blocks = ceil_div_u64(nu, 256u);
-        if (wide)
-            k_mul_ragged_flat<unit16><<<blocks, 256, 0, s>>>(
-                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, total_units, U, dU);
-        else
-            k_mul_ragged_flat<unit8><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, u0,
-                                                            total_units, U, dU);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess)
-            return e;
+    const int chunks = ragged_chunks(total_units);
+    const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
+    for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
+        const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
+        const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+#define CSGN_RAGGED_LAUNCH(CH)                                                                      \
+    do {                                                                                            \
+        if (wide)                                                                                   \
+            k_mul_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU);           \
+        else                                                                                        \
+            k_mul_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
+                                                                (u32)batch, u0, u0 + nu, U, dU);    \
+    } while (0)
+        switch (chunks) {
+        case 1: CSGN_RAGGED_LAUNCH(1); break;
+        case 2: CSGN_RAGGED_LAUNCH(2); break;
+        case 4: CSGN_RAGGED_LAUNCH(4); break;
+        case 16: CSGN_RAGGED_LAUNCH(16); break;
+        default: CSGN_RAGGED_LAUNCH(8); break;
+        }
+#undef CSGN_RAGGED_LAUNCH
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            return le;
     }
     return hipSuccess;
 }
@@ -1643,18 +1702,32 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u32 U = (u32)(wide ? dL / 2 : dL);
     const u64 total_units = total_terms_out * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    for (u64 u0 = 0; u0 < total_units; u0 += kMaxBlocks256 * 256u) {
-        const u64 nu = (total_units - u0 < kMaxBlocks256 * 256u) ? total_units - u0 : kMaxBlocks256 * 256u;
-        const u32 blocks = ceil_div_u64(nu, 256u);
-        if (wide)
-            k_add_ragged_flat<unit16><<<blocks, 256, 0, s>>>(
-                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, total_units, U, dU);
-        else
-            k_add_ragged_flat<unit8><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, u0,
-                                                            total_units, U, dU);
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
+    const int chunks = ragged_chunks(total_units);
+    const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
+    for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
+        const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
+        const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+#define CSGN_RAGGED_LAUNCH(CH)                                                                      \
+    do {                                                                                            \
+        if (wide)                                                                                   \
+            k_add_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU);           \
+        else                                                                                        \
+            k_add_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
+                                                                (u32)batch, u0, u0 + nu, U, dU);    \
+    } while (0)
+        switch (chunks) {
+        case 1: CSGN_RAGGED_LAUNCH(1); break;
+        case 2: CSGN_RAGGED_LAUNCH(2); break;
+        case 4: CSGN_RAGGED_LAUNCH(4); break;
+        case 16: CSGN_RAGGED_LAUNCH(16); break;
+        default: CSGN_RAGGED_LAUNCH(8); break;
+        }
+#undef CSGN_RAGGED_LAUNCH
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            return le;
     }
     return hipSuccess;
 }

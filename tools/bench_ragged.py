@@ -3,7 +3,8 @@
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from csgn_amd.batch import HipPath
+from csgn_amd.batch import HipPath, check
+CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0,1,4,8').split(',')]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
@@ -27,8 +28,24 @@ for name,t1s,t2s in [
     outw=int(np.sum(np.asarray(t1s,dtype=np.int64)*np.asarray(t2s,dtype=np.int64)))*dl
     alg=8*(int(offL[-1])*dl+int(offR[-1])*dl+outw)
     t=timed(lambda: hip.mul_ragged(n,L,dL_,R,dR_))
-    print(f"mul_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak), out {outw*8/1e6:.0f} MB", flush=True)
+    print(f"mul_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak), out {outw*8/1e6:.0f} MB  [plan + alloc + kernel]", flush=True)
+    # the kernel alone (offsets planned once), per chunks-per-workgroup setting
+    out, off_out = hip.mul_ragged(n,L,dL_,R,dR_)
+    mt1, mt2, tot = int(max(t1s)), int(max(t2s)), outw // dl
+    row=[]
+    for ch in CHUNKS:
+        os.environ["CSGN_RAGGED_C"]=str(ch)
+        t=timed(lambda: check(hip.lib.csgn_mul_ragged(n,len(t1s),L.data_ptr(),dL_.data_ptr(),R.data_ptr(),dR_.data_ptr(),
+                                                      out.data_ptr(),off_out.data_ptr(),mt1,mt2,tot,hip.stream)))
+        row.append(f"C={ch}: {alg/t/1e9:6.0f}")
+    print(f"   kernel only, GB/s   " + "  ".join(row), flush=True)
+    del out
     alg=2*8*dl*(int(offL[-1])+int(offR[-1]))
-    tot=int(offL[-1]+offR[-1]); t=timed(lambda: hip.add_ragged(n,L,dL_,R,dR_, total_terms_out=tot))
-    print(f"add_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak)", flush=True)
+    tot=int(offL[-1]+offR[-1])
+    row=[]
+    for ch in CHUNKS:
+        os.environ["CSGN_RAGGED_C"]=str(ch)
+        t=timed(lambda: hip.add_ragged(n,L,dL_,R,dR_, total_terms_out=tot))
+        row.append(f"C={ch}: {alg/t/1e9:6.0f}")
+    print(f"add_ragged {name:<32} GB/s (alloc + kernel)   " + "  ".join(row), flush=True)
     del L,R
