@@ -14,11 +14,13 @@ struct MulTuning {
     int m;      // CSGN_MUL_M: column units per lane, 0 = auto
     int ti;
     int nt;
-    int flat;   // CSGN_MUL_FLAT: units per lane of the flat kernel (0 = default 1); -1 = use the LDS-tiled kernel
+    int flat;   // CSGN_MUL_FLAT: 0 = choose per shape (mul_plan); k > 0 = flat kernel, k units per lane; -1 = LDS-tiled kernel
     int bs;     // CSGN_MUL_BS: override the tiled kernel's block size (0 = auto)
     int xcd;    // CSGN_MUL_XCD: XCD-contiguous block order: 0 off, 1 flat kernel only (default), 2 both kernels
 };
 MulTuning mul_tuning();
+// name of the kernel(s) mul_uniform dispatches to for this shape (16-byte aligned buffers assumed)
+const char *mul_uniform_kernel_name(u64 n_bits, u64 t1, u64 t2);
 
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s);

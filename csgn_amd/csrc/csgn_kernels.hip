@@ -1431,6 +1431,61 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
     return hipSuccess;
 }
 
+// Which kernel an all-pairs product takes (measured with COLD operands -- every launch reads pairs
+// that are not in any cache, tools/bench_cold.py, profiles/r01/bench_cold*.log):
+//   * output >= 4x the operands (t1*t2 >= 4*(t1+t2)), 16-byte units: the flat kernel (one output
+//     unit per lane, linear 4 KiB per workgroup, XCD-contiguous order) AFTER a touch pass that
+//     reads one dword of every operand line.  The flat kernel alone stalls on the first touch of
+//     every left term (an HBM miss under full write load, 4.6 TB/s at 1024x1024); with the
+//     operands already in the memory-side cache it runs at 7.2-7.5 TB/s against 6.9 for the
+//     LDS-tiled kernel, 6.2 against 3.9 at 32x32, 5.7 against 4.6 at 8x8.  The touch is a second
+//     read of the operands, hence the 4x condition, and is done per <= 64 MB of operands so that
+//     they are still in the 256 MB cache when their pairs run.
+//   * otherwise rows shorter than a workgroup (t2*U < 256 units; < 64 for the 8-byte units of an
+//     odd dL, whose flat kernel only writes 2 KiB per workgroup): the flat kernel, no touch (the
+//     tiled kernel leaves column lanes idle: 1.4 vs 6.0 TB/s at t2 = 1).
+//   * everything else (thin products with long rows, 8-byte units): the LDS-tiled kernel.
+// CSGN_MUL_FLAT (-1 tiled, k > 0 flat with k units per lane) and CSGN_MUL_TOUCH (0..3: bit 0 left,
+// bit 1 right operand) override for sweeps.
+struct MulPlan {
+    int flat;       // 0 = LDS-tiled kernel, k > 0 = flat kernel with k units per lane
+    int touch;      // operands to pull into the memory-side cache first (bit 0 left, bit 1 right)
+};
+
+static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2)
+{
+    const MulTuning tune = mul_tuning();
+    const u64 PU = t1 * t2 * U;
+    MulPlan p = {0, 0};
+    if (PU >= (1ull << 31) || tune.flat == -1)
+        return p;
+    const int touch_env = env_int("CSGN_MUL_TOUCH", -1);
+    if (tune.flat > 0) {
+        p.flat = tune.flat;
+        p.touch = touch_env > 0 ? (touch_env & 3) : 0;
+        return p;
+    }
+    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2)) {
+        p.flat = 1;
+        p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
+    } else if (t2 * U < (unit_bytes == 16 ? 256u : 64u)) {
+        p.flat = 1;
+        p.touch = touch_env > 0 ? (touch_env & 3) : 0;
+    }
+    return p;
+}
+
+// Read one dword of every 128-byte line of [p, p+bytes): pulls an operand into the memory-side
+// cache ahead of a kernel whose first touch of it would otherwise be a serialising HBM miss.
+__global__ void __launch_bounds__(256) k_touch(const u32 *__restrict__ p, u64 lines, u32 dwords_per_line)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < lines) {
+        const u32 v = p[i * dwords_per_line];
+        asm volatile("" ::"v"(v));
+    }
+}
+
 // One uniform chunk (pairs are contiguous in L, R and out).
 template <typename Unit>
 hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, const u64 *R, u64 *out,
@@ -1456,23 +1511,24 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         }
         return hipSuccess;
     }
-    // Small products (and CSGN_MUL_FLAT=k sweeps): the flat kernel, which re-reads both
-    // operands through L1/L2 for every output unit.  It is the faster of the two ONLY while the
-    // operands of the pairs in flight stay cache-resident (7.3 vs 6.9 TB/s at 1024x1024 with a
-    // 40 MB operand set) and collapses to 4.6 TB/s when they stream from HBM (the bench's
-    // 21 GB), so larger products take the LDS-tiled kernel, which reads each right-operand
-    // unit once per TI rows and holds 7.0 TB/s either way.
-    if ((tune.flat > 0 || (tune.flat == 0 && PU <= 8192)) && PU < (1ull << 31)) {
-        const int mf = tune.flat ? tune.flat : 1;
-        // left-term prefetch distance: ~6 MB of output ahead per XCD stream (8x that when the
-        // workgroups of a row are spread over all XCDs), only when a row fills a workgroup
+    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2);
+    if (plan.flat) {
+        const int mf = plan.flat;
+        // left-term prefetch from inside the kernel (only without the touch pass, only when a row
+        // fills a workgroup): ~6 MB of output ahead per XCD stream
         u32 pfr = 0;
-        if ((u64)t2 * U >= 256u) {
+        if (!plan.touch && (u64)t2 * U >= 256u) {
             const u64 ahead = (u64)env_int("CSGN_MUL_PF_KB", tune.xcd ? 6144 : 49152) << 10;
             const u64 row_bytes = (u64)t2 * U * sizeof(Unit);
             pfr = (u32)((ahead + row_bytes - 1) / row_bytes);
         }
-        const u64 pairs_per = (0xFFFFFF00ull / PU) ? (0xFFFFFF00ull / PU) : 1;   // units (= threads) per launch < 2^32
+        u64 pairs_per = (0xFFFFFF00ull / PU) ? (0xFFFFFF00ull / PU) : 1;   // units (= threads) per launch < 2^32
+        if (plan.touch) {
+            // touched operands must still be in the 256 MB memory-side cache when their pair runs:
+            // at most 64 MB of them per touch + launch
+            const u64 op_bytes = (u64)(t1 + t2) * U * sizeof(Unit);
+            pairs_per = std::min<u64>(pairs_per, std::max<u64>(1, (64ull << 20) / op_bytes));
+        }
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
                       dU = csgn_fastdiv_make(U);
         for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
@@ -1482,6 +1538,14 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
             const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
             const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
             Unit *Oc = Ou + p0 * PU;
+            if (plan.touch) {
+                const u32 lb = 128;       // the L2 fills whole 128-byte lines (a 256-byte stride loses the gain)
+                const u64 ll = (np * t1 * U * sizeof(Unit) + lb - 1) / lb, rl = (np * t2 * U * sizeof(Unit) + lb - 1) / lb;
+                if (plan.touch & 1)
+                    k_touch<<<ceil_div_u64(ll, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Lc), ll, lb / 4);
+                if (plan.touch & 2)
+                    k_touch<<<ceil_div_u64(rl, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Rc), rl, lb / 4);
+            }
 #define CSGN_FLAT(MF)                                                                                  \
     do {                                                                                               \
         if (tune.xcd)                                                                                  \
@@ -1529,7 +1593,7 @@ MulTuning mul_tuning()
     if (t.ti < 1)
         t.ti = 1;
     t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
-    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = auto (flat when a pair has <= 8192 output units, else LDS-tiled); >0 = flat with that unroll; -1 = always tiled
+    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = auto (mul_plan); >0 = flat with that unroll; -1 = always tiled
     if (t.flat != -1 && t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
         t.flat = 0;
     t.xcd = env_int("CSGN_MUL_XCD", 1);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both
@@ -1553,6 +1617,17 @@ static int ragged_chunks(u64 total_units)
     while (c < 8 && total_units / (256u * 2u * (u64)c) >= 8192u)
         c *= 2;
     return c;
+}
+
+const char *mul_uniform_kernel_name(u64 n_bits, u64 t1, u64 t2)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    const bool wide = dL % 2 == 0;
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    if (t1 == 1 && t2 == 1)
+        return "k_and_stream";
+    const MulPlan p = mul_plan(wide ? 16 : 8, U, t1, t2);
+    return p.flat ? (p.touch ? "k_touch+k_mul_flat" : "k_mul_flat") : "k_mul_tiled";
 }
 
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,

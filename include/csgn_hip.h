@@ -240,6 +240,11 @@ int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_
 int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
                 uint64_t *d_digest, void *stream);
 
+/* Name of the kernel(s) csgn_mul_uniform dispatches to for this shape ("k_and_stream",
+ * "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"); a static string, no GPU needed.  Lets a
+ * profiler-driven harness (bench.py) label its roofline with the kernel that really runs. */
+const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t t1, uint64_t t2);
+
 /* Debug hook: quotient n/d computed by the same division-by-invariant helper the kernels
  * use (csgn_amd/csrc/csgn_common.h); lets the CPU tests pin it without a GPU. */
 uint32_t csgn_debug_fastdiv(uint32_t n, uint32_t d);

@@ -16,39 +16,66 @@ import os
 import sys
 
 
-def read_counter(dirname, counter, kernel_sub):
-    vals = []
+def read_counter(dirname, counter, kernel_subs):
+    """Counter values of every dispatch whose kernel name contains one of kernel_subs, keyed by
+    the substring that matched."""
+    vals = {k: [] for k in kernel_subs}
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Counter_Name") == counter and kernel_sub in row.get("Kernel_Name", ""):
-                    vals.append(float(row["Counter_Value"]))
+                if row.get("Counter_Name") != counter:
+                    continue
+                for k in kernel_subs:
+                    if k in row.get("Kernel_Name", ""):
+                        vals[k].append(float(row["Counter_Value"]))
+                        break
     return vals
+
+
+def per_launch(vals, main):
+    """Sum over all listed kernels divided by the number of dispatches of the main kernel: helper
+    kernels (k_touch runs twice per multiply launch) are charged to the launch they serve."""
+    n = len(vals.get(main, []))
+    return (sum(sum(v) for v in vals.values()) / n, n) if n else (None, 0)
 
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "k_mul_tiled"
-    out = {"kernel": kernel_sub}
+    kernel_arg = sys.argv[3] if len(sys.argv) > 3 else "k_mul_tiled"
+    kernel_subs = kernel_arg.split("+")          # e.g. "k_touch+k_mul_flat": the last one is the main kernel
+    main_k = kernel_subs[-1]
+    out = {"kernel": kernel_arg}
     for path in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if kernel_sub in row["Name"]:
-                    out["calls"] = int(row["Calls"])
-                    out["avg_duration_ms"] = float(row["AverageNs"]) / 1e6
-                    out["min_duration_ms"] = float(row["MinNs"]) / 1e6
-                    out["max_duration_ms"] = float(row["MaxNs"]) / 1e6
-    w = read_counter(os.path.join(src, "pmc_WRITE_SIZE"), "WRITE_SIZE", kernel_sub)
-    r = read_counter(os.path.join(src, "pmc_FETCH_SIZE"), "FETCH_SIZE", kernel_sub)
-    if w:
-        out["write_size_kib_per_launch"] = sum(w) / len(w)
-        out["hbm_write_bytes_per_launch"] = sum(w) / len(w) * 1024
-    if r:
-        out["fetch_size_kib_per_launch_raw"] = sum(r) / len(r)
-        out["hbm_read_bytes_per_launch"] = sum(r) / len(r) * 1024 * 2      # gfx950 x2 correction
-    if w and r:
+                for k in kernel_subs:
+                    if k in row["Name"]:
+                        st = out.setdefault("stats", {}).setdefault(k, {})
+                        st["calls"] = int(row["Calls"])
+                        st["avg_duration_ms"] = float(row["AverageNs"]) / 1e6
+                        st["min_duration_ms"] = float(row["MinNs"]) / 1e6
+                        st["max_duration_ms"] = float(row["MaxNs"]) / 1e6
+                        st["total_ms"] = float(row["TotalDurationNs"]) / 1e6 if "TotalDurationNs" in row else st["calls"] * st["avg_duration_ms"]
+                        break
+    if "stats" in out and main_k in out["stats"]:
+        m = out["stats"][main_k]
+        out["calls"] = m["calls"]
+        out["avg_duration_ms"] = m["avg_duration_ms"]                                    # main kernel alone
+        out["avg_duration_ms_with_helpers"] = sum(v["total_ms"] for v in out["stats"].values()) / m["calls"]
+    w = read_counter(os.path.join(src, "pmc_WRITE_SIZE"), "WRITE_SIZE", kernel_subs)
+    r = read_counter(os.path.join(src, "pmc_FETCH_SIZE"), "FETCH_SIZE", kernel_subs)
+    wv, wn = per_launch(w, main_k)
+    rv, rn = per_launch(r, main_k)
+    if wn:
+        out["write_size_kib_per_launch"] = wv
+        out["hbm_write_bytes_per_launch"] = wv * 1024
+    if rn:
+        out["fetch_size_kib_per_launch_raw"] = rv
+        out["hbm_read_bytes_per_launch"] = rv * 1024 * 2      # gfx950 x2 correction
+        out["fetch_size_kib_raw_by_kernel"] = {k: (sum(v) / rn) for k, v in r.items()}
+    if wn and rn:
         out["hbm_bytes_per_launch"] = out["hbm_write_bytes_per_launch"] + out["hbm_read_bytes_per_launch"]
-        out["pmc_launches_sampled"] = [len(w), len(r)]
+        out["pmc_launches_sampled"] = [wn, rn]
     for name in ("bench_trace.json", "pmc_WRITE_SIZE.json"):
         p = os.path.join(src, name)
         if os.path.exists(p):
