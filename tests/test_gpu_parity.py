@@ -116,6 +116,44 @@ def test_mul_tiled_kernel_matches_oracle(hip, oracle, monkeypatch, n, d, t1, t2)
         assert np.array_equal(out[b * per:(b + 1) * per], want), (n, t1, t2, b)
 
 
+@pytest.mark.parametrize("n,d", CONTEXTS)
+@pytest.mark.parametrize("touch", [0, 1, 3])
+def test_mul_flat_kernel_with_touch_matches_oracle(hip, oracle, monkeypatch, n, d, touch):
+    """The flat kernel forced on every context, with and without the operand touch pass (which
+    only reads: results cannot depend on it)."""
+    monkeypatch.setenv("CSGN_MUL_FLAT", "1")
+    monkeypatch.setenv("CSGN_MUL_TOUCH", str(touch))
+    dl = oracle.default_len(n)
+    batch = 2
+    for (t1, t2) in [(1, 2), (3, 5), (33, 65), (5, 300), (129, 130)]:
+        L = oracle.synth(1000 + t1, n, 0, batch * t1 * dl)
+        R = oracle.synth(2000 + t2, n, 0, batch * t2 * dl)
+        out = hip.download(hip.mul_uniform(n, batch, t1, t2, hip.upload(L), hip.upload(R)))
+        per = t1 * t2 * dl
+        for b in range(batch):
+            want, _ = oracle.mul(n, L[b * t1 * dl:(b + 1) * t1 * dl], R[b * t2 * dl:(b + 1) * t2 * dl])
+            assert np.array_equal(out[b * per:(b + 1) * per], want), (n, t1, t2, b)
+
+
+def test_mul_touch_chunking_across_64mb_of_operands(hip, oracle):
+    """Default dispatch on a batch whose operands exceed one touch chunk (64 MB): 30 000 pairs of
+    8x8 terms at N=1247 are cut after pair 26 214; pairs on both sides of the cut, the ends and a
+    random sample are compared with the oracle."""
+    n, dl, t, batch = 1247, 20, 8, 30000
+    assert hip.lib.csgn_mul_uniform_kernel(n, t, t).decode() == "k_touch+k_mul_flat"
+    L = hip.synth_fill(11, n, 0, batch * t * dl)
+    R = hip.synth_fill(12, n, 0, batch * t * dl)
+    out = hip.mul_uniform(n, batch, t, t, L, R)
+    hl, hr, ho = hip.download(L), hip.download(R), hip.download(out)
+    per = t * t * dl
+    cut = (64 << 20) // (2 * t * dl * 8)
+    picks = {0, 1, batch - 1, cut - 1, cut, cut + 1, 2 * cut - 1} | set(
+        np.random.default_rng(5).integers(0, batch, 200).tolist())
+    for b in sorted(p for p in picks if 0 <= p < batch):
+        want, _ = oracle.mul(n, hl[b * t * dl:(b + 1) * t * dl], hr[b * t * dl:(b + 1) * t * dl])
+        assert np.array_equal(ho[b * per:(b + 1) * per], want), b
+
+
 @pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
 def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
     monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
