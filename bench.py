@@ -247,8 +247,8 @@ def main():
     avg_launch_s = kernel_ms / 1e3 / n_launches
     # the kernel(s) the library dispatches this shape to ("k_touch+k_mul_flat": the operand touch
     # pass is inside the timed launch and charged to it)
-    kernel_name = hip.lib.csgn_mul_uniform_kernel(N_BITS, T, T).decode()
     pairs_per_launch = batch / launches_per_step
+    kernel_name = hip.lib.csgn_mul_uniform_kernel(N_BITS, int(pairs_per_launch), T, T).decode()
     achieved = pairs_per_launch * bytes_per_mul / avg_launch_s
 
     # ---- validity: the arena still holds the last `slots` products; check sampled ones ----

@@ -66,7 +66,7 @@ SIGNATURES = {
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
     "csgn_synth_fill": (C.c_int, [u64, u64, u64, u64, vp, vp]),
     "csgn_digest": (C.c_int, [vp, u64, u64, vp, vp]),
-    "csgn_mul_uniform_kernel": (C.c_char_p, [u64, u64, u64]),
+    "csgn_mul_uniform_kernel": (C.c_char_p, [u64, u64, u64, u64]),
     "csgn_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
 }
 

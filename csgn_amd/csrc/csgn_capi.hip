@@ -531,9 +531,9 @@ int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
     return CSGN_OK;
 }
 
-const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t t1, uint64_t t2)
+const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2)
 {
-    return csgn::mul_uniform_kernel_name(n_bits, t1, t2);
+    return csgn::mul_uniform_kernel_name(n_bits, pairs, t1, t2);
 }
 
 /* debug hook used by the CPU tests to pin the division-by-invariant helper */

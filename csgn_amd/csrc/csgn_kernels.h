@@ -19,8 +19,9 @@ struct MulTuning {
     int xcd;    // CSGN_MUL_XCD: XCD-contiguous block order: 0 off, 1 flat kernel only (default), 2 both kernels
 };
 MulTuning mul_tuning();
-// name of the kernel(s) mul_uniform dispatches to for this shape (16-byte aligned buffers assumed)
-const char *mul_uniform_kernel_name(u64 n_bits, u64 t1, u64 t2);
+// name of the kernel(s) mul_uniform dispatches one launch of `pairs` pairs of this shape to
+// (16-byte aligned buffers assumed)
+const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2);
 
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s);

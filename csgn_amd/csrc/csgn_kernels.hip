@@ -1433,7 +1433,8 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 
 // Which kernel an all-pairs product takes (measured with COLD operands -- every launch reads pairs
 // that are not in any cache, tools/bench_cold.py, profiles/r01/bench_cold*.log):
-//   * output >= 4x the operands (t1*t2 >= 4*(t1+t2)), 16-byte units: the flat kernel (one output
+//   * output >= 4x the operands (t1*t2 >= 4*(t1+t2)), 16-byte units, and at least 4 MB of operands
+//     in the launch (a stream, not a single product): the flat kernel (one output
 //     unit per lane, linear 4 KiB per workgroup, XCD-contiguous order) AFTER a touch pass that
 //     reads one dword of every operand line.  The flat kernel alone stalls on the first touch of
 //     every left term (an HBM miss under full write load, 4.6 TB/s at 1024x1024); with the
@@ -1452,7 +1453,7 @@ struct MulPlan {
     int touch;      // operands to pull into the memory-side cache first (bit 0 left, bit 1 right)
 };
 
-static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2)
+static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
 {
     const MulTuning tune = mul_tuning();
     const u64 PU = t1 * t2 * U;
@@ -1465,7 +1466,11 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2)
         p.touch = touch_env > 0 ? (touch_env & 3) : 0;
         return p;
     }
-    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2)) {
+    // a call with a few MB of operands is not a stream: they are usually still cached from the
+    // kernel that produced them, and two extra launches triple the cost of a small product
+    // (class API, 64x64: 10.9 us per multiply with the touch, 3.0-3.8 without)
+    const bool streaming = pairs * (t1 + t2) * U * unit_bytes >= (4ull << 20);
+    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && (streaming || touch_env > 0)) {
         p.flat = 1;
         p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
     } else if (t2 * U < (unit_bytes == 16 ? 256u : 64u)) {
@@ -1511,7 +1516,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         }
         return hipSuccess;
     }
-    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2);
+    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2, pairs);
     if (plan.flat) {
         const int mf = plan.flat;
         // left-term prefetch from inside the kernel (only without the touch pass, only when a row
@@ -1619,14 +1624,14 @@ static int ragged_chunks(u64 total_units)
     return c;
 }
 
-const char *mul_uniform_kernel_name(u64 n_bits, u64 t1, u64 t2)
+const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2)
 {
     const u64 dL = (n_bits + 63) / 64;
     const bool wide = dL % 2 == 0;
     const u32 U = (u32)(wide ? dL / 2 : dL);
     if (t1 == 1 && t2 == 1)
         return "k_and_stream";
-    const MulPlan p = mul_plan(wide ? 16 : 8, U, t1, t2);
+    const MulPlan p = mul_plan(wide ? 16 : 8, U, t1, t2, pairs);
     return p.flat ? (p.touch ? "k_touch+k_mul_flat" : "k_mul_flat") : "k_mul_tiled";
 }
 

@@ -109,7 +109,11 @@ int csgn_key_mask(uint64_t n_bits, const uint64_t *h_key, uint64_t d, uint64_t *
  * batch through a fixed arena, SURVEY 8d "streaming rule"); out_slots == 0 means one slot
  * per pair.  With out_slots < batch the call is split into launches of <= out_slots pairs
  * in stream order so later pairs overwrite earlier ones deterministically.
- * Limits: dL*8 <= 16384 bytes per term; t1*t2*dL < 2^32 per pair. */
+ * Limits: dL*8 <= 16384 bytes per term; t1*t2*dL < 2^32 per pair.
+ * The kernel is chosen per shape (csgn_mul_uniform_kernel names it): launches of >= 4 MB of
+ * operands whose output is >= 4x the operands are preceded by a read-only pass over the
+ * operands that leaves them in the GPU's memory-side cache, so the operands are READ twice;
+ * nothing but d_out is written. */
 int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
                      const uint64_t *d_left, const uint64_t *d_right, uint64_t *d_out,
                      uint64_t out_slots, void *stream);
@@ -124,7 +128,8 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
 /* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets; pass the plan's
  * max_t1 = h_plan[1], max_t2 = h_plan[2], total_out_terms = h_plan[0].  Nearly uniform batches
  * of large products run the LDS-tiled kernel; skewed or small ones a flat kernel whose grid is
- * the real output (each lane finds its pair by binary search over d_off_out). */
+ * the real output (a workgroup finds its first pair by binary search over d_off_out, its waves
+ * walk forward from there). */
 int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
@@ -240,10 +245,11 @@ int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_
 int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
                 uint64_t *d_digest, void *stream);
 
-/* Name of the kernel(s) csgn_mul_uniform dispatches to for this shape ("k_and_stream",
- * "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"); a static string, no GPU needed.  Lets a
- * profiler-driven harness (bench.py) label its roofline with the kernel that really runs. */
-const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t t1, uint64_t t2);
+/* Name of the kernel(s) csgn_mul_uniform dispatches ONE launch of `pairs` pairs of this shape to
+ * ("k_and_stream", "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"; pairs = min(batch,
+ * out_slots) of the call); a static string, no GPU needed.  Lets a profiler-driven harness
+ * (bench.py) label its roofline with the kernel that really runs. */
+const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2);
 
 /* Debug hook: quotient n/d computed by the same division-by-invariant helper the kernels
  * use (csgn_amd/csrc/csgn_common.h); lets the CPU tests pin it without a GPU. */

@@ -475,12 +475,15 @@ static int cmd_latency(int iters)
     SecretKey sk(ctx);
     Plaintext one(1), zero(0);
     Ciphertext a = sk.encrypt(one), b = sk.encrypt(zero);
-    Ciphertext big = a + b;
-    for (int i = 0; i < 6; ++i)
+    Ciphertext big = a + b, mid = a + b;
+    for (int i = 0; i < 6; ++i) {
         big = big * (a + b);                        // 128 terms
+        if (i == 4)
+            mid = big;                              // 64 terms
+    }
     struct Case { const char *name; int kind; } cases[] = {
         {"mul 1x1", 0}, {"add 1+1", 1}, {"decrypt 1 term", 2}, {"encrypt", 3},
-        {"mul 128x2", 4}, {"decrypt 128 terms", 5}};
+        {"mul 128x2", 4}, {"decrypt 128 terms", 5}, {"mul 64x64", 6}};
     for (const Case &c : cases) {
         Timer t(c.name);
         int acc = 0;
@@ -492,6 +495,7 @@ static int cmd_latency(int iters)
             case 2: acc += sk.decrypt(a).getValue(); break;
             case 3: { Ciphertext r = sk.encrypt(one); acc += (int)r.getLen(); break; }
             case 4: { Ciphertext r = big * (a + b); acc += (int)r.getLen(); break; }
+            case 6: { Ciphertext r = mid * mid; acc += (int)r.getLen(); break; }
             default: acc += sk.decrypt(big).getValue(); break;
             }
         }

@@ -75,18 +75,20 @@ def test_mul_dispatch_names(lib, monkeypatch):
     """csgn_mul_uniform_kernel reports the measured dispatch rule without a GPU."""
     for k in ("CSGN_MUL_FLAT", "CSGN_MUL_TOUCH"):
         monkeypatch.delenv(k, raising=False)
-    name = lambda n, t1, t2: lib.csgn_mul_uniform_kernel(n, t1, t2).decode()
+    name = lambda n, t1, t2, pairs=1 << 16: lib.csgn_mul_uniform_kernel(n, pairs, t1, t2).decode()
     assert name(1247, 1, 1) == "k_and_stream"
-    assert name(1247, 1024, 1024) == "k_touch+k_mul_flat"      # the bench shape
+    assert name(1247, 1024, 1024, 128) == "k_touch+k_mul_flat"     # the bench launch: 128 pairs, 42 MB of operands
+    assert name(1247, 1024, 1024, 1) == "k_mul_tiled"              # a single product is not a stream
     assert name(4096, 256, 256) == "k_touch+k_mul_flat"
-    assert name(1247, 8, 8) == "k_touch+k_mul_flat"            # output = 4x operands
-    assert name(1247, 4, 4) == "k_mul_flat"                    # operands too large a share to read twice
-    assert name(1247, 1024, 1) == "k_mul_flat"                 # rows shorter than a workgroup
-    assert name(1247, 2, 383) == "k_mul_tiled"                 # thin product, long rows
-    assert name(1300, 128, 128) == "k_mul_tiled"               # odd dL: 8-byte units
+    assert name(1247, 8, 8) == "k_touch+k_mul_flat"                # output = 4x operands
+    assert name(1247, 64, 64, 1) == "k_mul_tiled"
+    assert name(1247, 4, 4) == "k_mul_flat"                        # operands too large a share to read twice
+    assert name(1247, 1024, 1) == "k_mul_flat"                     # rows shorter than a workgroup
+    assert name(1247, 2, 383) == "k_mul_tiled"                     # thin product, long rows
+    assert name(1300, 128, 128) == "k_mul_tiled"                   # odd dL: 8-byte units
     assert name(1300, 200, 2) == "k_mul_flat"
     monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
-    assert name(1247, 1024, 1024) == "k_mul_tiled"
+    assert name(1247, 1024, 1024, 128) == "k_mul_tiled"
 
 
 def test_fastdiv_helper_is_exact(lib):

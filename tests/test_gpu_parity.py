@@ -140,7 +140,7 @@ def test_mul_touch_chunking_across_64mb_of_operands(hip, oracle):
     8x8 terms at N=1247 are cut after pair 26 214; pairs on both sides of the cut, the ends and a
     random sample are compared with the oracle."""
     n, dl, t, batch = 1247, 20, 8, 30000
-    assert hip.lib.csgn_mul_uniform_kernel(n, t, t).decode() == "k_touch+k_mul_flat"
+    assert hip.lib.csgn_mul_uniform_kernel(n, batch, t, t).decode() == "k_touch+k_mul_flat"
     L = hip.synth_fill(11, n, 0, batch * t * dl)
     R = hip.synth_fill(12, n, 0, batch * t * dl)
     out = hip.mul_uniform(n, batch, t, t, L, R)
