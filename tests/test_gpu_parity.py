@@ -154,6 +154,23 @@ def test_mul_touch_chunking_across_64mb_of_operands(hip, oracle):
         assert np.array_equal(ho[b * per:(b + 1) * per], want), b
 
 
+@pytest.mark.parametrize("n,t1,t2,batch", [(1247, 100, 77, 200), (4096, 40, 40, 104), (1247, 33, 65, 300),
+                                           (128, 64, 64, 2100)])
+def test_mul_streaming_launches_default_dispatch(hip, oracle, n, t1, t2, batch):
+    """Launches with >= 4 MB of operands take the touch + flat pair by default; every product of
+    the batch is compared with the oracle."""
+    assert hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode() == "k_touch+k_mul_flat"
+    dl = oracle.default_len(n)
+    L = hip.synth_fill(21, n, 0, batch * t1 * dl)
+    R = hip.synth_fill(22, n, 0, batch * t2 * dl)
+    ho = hip.download(hip.mul_uniform(n, batch, t1, t2, L, R))
+    hl, hr = hip.download(L), hip.download(R)
+    per = t1 * t2 * dl
+    for b in range(batch):
+        want, _ = oracle.mul(n, hl[b * t1 * dl:(b + 1) * t1 * dl], hr[b * t2 * dl:(b + 1) * t2 * dl])
+        assert np.array_equal(ho[b * per:(b + 1) * per], want), (n, t1, t2, b)
+
+
 @pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
 def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
     monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
