@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          const u64 *__restrict__ offR,
                                                          Unit *__restrict__ out,
                                                          const u64 *__restrict__ offOut, u32 batch,
-                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU)
+                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU,
+                                                         u32 pf_pairs)
 {
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const u64 g_begin = unit_base + (u64)bid * (256u * C);
@@ -286,6 +287,25 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
     const u64 term0 = g_begin / U;                              // workgroup-uniform
     const u32 r0blk = (u32)(g_begin - term0 * U);
     u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
+    // The workgroup that holds the start of a pair pulls the operands of the pair `pf_pairs` further
+    // on into the caches (one dword per 128-byte line, values unused): by the time that pair's
+    // rows are written its left terms are hits instead of HBM misses under full write load.
+    if (pf_pairs && term0 - offOut[pw] < (256u * C) / U + 1u) {
+        const u32 pt = min(pw + pf_pairs, batch - 1u);
+        const u64 lb = offL[pt] * U * sizeof(Unit), le = offL[pt + 1] * U * sizeof(Unit);
+        const u64 rb = offR[pt] * U * sizeof(Unit), re = offR[pt + 1] * U * sizeof(Unit);
+        const char *Lb = reinterpret_cast<const char *>(L), *Rb = reinterpret_cast<const char *>(R);
+#pragma unroll 1
+        for (u64 a = lb + (u64)threadIdx.x * 128u, n = 0; a < le && n < 8; a += 256u * 128u, ++n) {
+            const u32 v = *reinterpret_cast<const u32 *>(Lb + a);
+            asm volatile("" ::"v"(v));
+        }
+#pragma unroll 1
+        for (u64 a = rb + (u64)threadIdx.x * 128u, n = 0; a < re && n < 8; a += 256u * 128u, ++n) {
+            const u32 v = *reinterpret_cast<const u32 *>(Rb + a);
+            asm volatile("" ::"v"(v));
+        }
+    }
 #pragma unroll 1
     for (int c = 0; c < C; ++c) {
         const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
@@ -1708,6 +1728,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
     const int chunks = ragged_chunks(total_units);
+    const u32 pf_pairs = (u32)env_int("CSGN_RAGGED_PF", 32);    // operand prefetch distance in pairs, 0 = off
     const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
     for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
         const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
@@ -1717,10 +1738,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         if (wide)                                                                                   \
             k_mul_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU);           \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
         else                                                                                        \
             k_mul_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
-                                                                (u32)batch, u0, u0 + nu, U, dU);    \
+                                                                (u32)batch, u0, u0 + nu, U, dU,     \
+                                                                pf_pairs);                          \
     } while (0)
         switch (chunks) {
         case 1: CSGN_RAGGED_LAUNCH(1); break;

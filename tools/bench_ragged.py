@@ -4,7 +4,9 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from csgn_amd.batch import HipPath, check
-CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0,1,4,8').split(',')]
+CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
+NSETS=[3]
+VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no prefetch',{'CSGN_RAGGED_PF':'0'}),('cold, C=1',{'CSGN_RAGGED_C':'1'}),('cold + pretouch',{'PRETOUCH':'1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
@@ -29,16 +31,37 @@ for name,t1s,t2s in [
     alg=8*(int(offL[-1])*dl+int(offR[-1])*dl+outw)
     t=timed(lambda: hip.mul_ragged(n,L,dL_,R,dR_))
     print(f"mul_ragged {name:<32} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak), out {outw*8/1e6:.0f} MB  [plan + alloc + kernel]", flush=True)
-    # the kernel alone (offsets planned once), per chunks-per-workgroup setting
+    # the kernel alone (offsets planned once), COLD operands: three operand sets with the same
+    # offsets taken in turn (> 256 MB together for the skewed batches), per setting
     out, off_out = hip.mul_ragged(n,L,dL_,R,dR_)
     mt1, mt2, tot = int(max(t1s)), int(max(t2s)), outw // dl
+    sets=[(L,R)]+[(hip.synth_fill(10+k,n,0,int(offL[-1])*dl), hip.synth_fill(20+k,n,0,int(offR[-1])*dl)) for k in range(2)]
     row=[]
-    for ch in CHUNKS:
-        os.environ["CSGN_RAGGED_C"]=str(ch)
-        t=timed(lambda: check(hip.lib.csgn_mul_ragged(n,len(t1s),L.data_ptr(),dL_.data_ptr(),R.data_ptr(),dR_.data_ptr(),
-                                                      out.data_ptr(),off_out.data_ptr(),mt1,mt2,tot,hip.stream)))
-        row.append(f"C={ch}: {alg/t/1e9:6.0f}")
+    for label,env in VARIANTS:
+        for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF"):
+            os.environ.pop(k,None)
+        os.environ.update({k:v for k,v in env.items() if k.startswith('CSGN')})
+        NSETS[0]=int(env.get('NSETS','3'))
+        turn=[0]
+        def one():
+            Lk,Rk=sets[turn[0]%NSETS[0]]; turn[0]+=1
+            check(hip.lib.csgn_mul_ragged(n,len(t1s),Lk.data_ptr(),dL_.data_ptr(),Rk.data_ptr(),dR_.data_ptr(),
+                                          out.data_ptr(),off_out.data_ptr(),mt1,mt2,tot,hip.stream))
+        if env.get("PRETOUCH"):
+            ts=[]
+            for _ in range(9):
+                Lk,Rk=sets[turn[0]%NSETS[0]]
+                Lk.view(torch.int64).sum(); Rk.view(torch.int64).sum()      # operands into the caches, untimed
+                a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+                a.record(); one(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b)/1e3)
+            t=statistics.median(ts)
+        else:
+            t=timed(one, rounds=9)
+        row.append(f"{label}: {alg/t/1e9:6.0f}")
+    for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF"):
+        os.environ.pop(k,None)
     print(f"   kernel only, GB/s   " + "  ".join(row), flush=True)
+    del sets
     del out
     alg=2*8*dl*(int(offL[-1])+int(offR[-1]))
     tot=int(offL[-1]+offR[-1])
