@@ -32,6 +32,8 @@ SIGNATURES = {
     "csgn_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(u64)]),
     "csgn_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
     "csgn_free": (C.c_int, [vp]),
+    "csgn_host_alloc": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_size_t]),
+    "csgn_host_free": (C.c_int, [vp]),
     "csgn_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "csgn_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "csgn_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t, vp]),

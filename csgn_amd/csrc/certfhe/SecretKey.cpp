@@ -210,14 +210,15 @@ Plaintext SecretKey::decrypt(Ciphertext &ciphertext)
         return Plaintext(0);                   // empty term list XORs to 0
     ensureMask();
     const size_t scratch = (csgn_decrypt_scratch_bytes(1, terms) + 7) & ~(size_t)7;
-    std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch + 8);
-    unsigned char *d_bit = static_cast<unsigned char *>(work->ptr) + scratch;
+    std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch);
+    // the answer lands in pinned host memory the kernel writes itself: no device-to-host copy
+    void *d_bit = nullptr;
+    volatile unsigned char *h_bit = detail::resultSlot(&d_bit);
     detail::check(csgn_decrypt_uniform(n, 1, terms, ciphertext.deviceValues(), device_mask->data(),
-                                       d_bit, work->ptr, detail::stream()),
+                                       static_cast<uint8_t *>(d_bit), work->ptr, detail::stream()),
                   "csgn_decrypt_uniform");
-    unsigned char bit = 0;
-    detail::downloadBytes(&bit, d_bit, 1);
-    return Plaintext((int)bit);
+    detail::syncDevice();
+    return Plaintext((int)(*h_bit & 1u));
 }
 
 // ------------------------------------------------------------------ permutation

@@ -93,6 +93,29 @@ BlockCache *cache()
 }
 }
 
+// One pinned, GPU-addressable 64-byte slot per host thread and device for single-value answers
+// (SecretKey::decrypt): the kernel writes the bit straight into host memory, a stream
+// synchronise makes it visible, and the device-to-host copy of one byte -- a third of the call's
+// latency -- disappears.  Slots are never freed before process exit (one per thread and GPU).
+namespace {
+struct ResultSlot {
+    void *host = nullptr;
+    void *dev = nullptr;
+};
+thread_local ResultSlot g_slots[16];
+}
+
+volatile unsigned char *resultSlot(void **dev_alias)
+{
+    ensureDevice();
+    ResultSlot local;
+    ResultSlot &sl = (g_device >= 0 && g_device < 16) ? g_slots[g_device] : local;
+    if (!sl.host)
+        check(csgn_host_alloc(&sl.host, &sl.dev, 64), "csgn_host_alloc");
+    *dev_alias = sl.dev;
+    return static_cast<volatile unsigned char *>(sl.host);
+}
+
 void check(int rc, const char *what)
 {
     if (rc == CSGN_OK)

@@ -41,6 +41,9 @@ std::shared_ptr<DevicePayload> allocWords(uint64_t words);
 std::shared_ptr<DevicePayload> uploadWords(const uint64_t *host, uint64_t words);
 void downloadBytes(void *host, const void *dev, size_t bytes);
 void syncDevice();
+// Pinned host byte(s) a kernel can write directly (valid after syncDevice()); *dev_alias is the
+// address to hand to the kernel.  One slot per thread and device, reused by every call.
+volatile unsigned char *resultSlot(void **dev_alias);
 // Returns every cached HBM block of the calling thread to the driver.
 void releaseBlockCache();
 

@@ -126,6 +126,27 @@ int csgn_free(void *d_ptr)
     return CSGN_OK;
 }
 
+int csgn_host_alloc(void **h_ptr, void **d_alias, size_t bytes)
+{
+    REQUIRE(h_ptr && d_alias && bytes, "null pointer or zero size");
+    *h_ptr = *d_alias = nullptr;
+    HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer(d_alias, *h_ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(*h_ptr);
+        *h_ptr = *d_alias = nullptr;
+        return hip_fail(e, "hipHostGetDevicePointer");
+    }
+    return CSGN_OK;
+}
+
+int csgn_host_free(void *h_ptr)
+{
+    if (h_ptr)
+        HIP_TRY(hipHostFree(h_ptr));
+    return CSGN_OK;
+}
+
 int csgn_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
 {
     if (bytes == 0)

@@ -71,6 +71,11 @@ int csgn_device_info(int device, char *h_name, size_t cap, int *h_cu_count, uint
 
 int csgn_malloc(void **d_ptr, size_t bytes);
 int csgn_free(void *d_ptr);
+/* Pinned host memory the GPU can address: *h_ptr for the host, *d_alias for kernels (results
+ * a kernel writes there are visible to the host after csgn_stream_sync, no copy).  Used by the
+ * C++ classes for the one-byte answer of SecretKey::decrypt. */
+int csgn_host_alloc(void **h_ptr, void **d_alias, size_t bytes);
+int csgn_host_free(void *h_ptr);
 int csgn_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int csgn_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int csgn_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
