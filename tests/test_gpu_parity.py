@@ -702,6 +702,42 @@ def test_largest_supported_term_and_rejection(hip, oracle):
         hip.mul_uniform(n + 1, 1, 1, 1, hip.upload(a), hip.upload(b))
 
 
+@pytest.mark.parametrize("flat", ["-1", "1"])
+def test_largest_single_product_index_edges(hip, monkeypatch, flat):
+    """One 16384 x 13107-term product at N=1247: 4 294 901 760 output words (34 GB), just under the
+    documented 2^32-word limit and 2 147 450 880 sixteen-byte units, just under 2^31 -- the
+    index arithmetic of both all-pairs kernels at its edge.  Sixty-odd whole rows (ends, rows at the
+    2^32..2^35 byte marks, random ones) and 50 000 scattered terms are compared with torch's own
+    bitwise_and (independent of the kernels); one more left term is refused."""
+    import torch
+    from csgn_amd.capi import CsgnError
+    monkeypatch.setenv("CSGN_MUL_FLAT", flat)
+    n, dl, t1, t2 = 1247, 20, 16384, 13107
+    assert t1 * t2 * dl < 2**32 <= (t1 + 1) * t2 * dl
+    L = hip.synth_fill(31, n, 0, t1 * dl)
+    R = hip.synth_fill(32, n, 0, t2 * dl)
+    out = hip.mul_uniform(n, 1, t1, t2, L, R)
+    Lw, Rw, Ow = (x.view(-1, dl) for x in (L, R, out[:t1 * t2 * dl]))
+    g = torch.Generator(device="cpu").manual_seed(7)
+    # whole rows: the ends, the rows around unit 2^31/... and byte 2^32/2^33/2^34/2^35, 48 random ones
+    rows = {0, 1, t1 - 2, t1 - 1} | {(b // 160) // t2 + k for b in (2**32, 2**33, 2**34, 2**35) for k in (-1, 0, 1)}
+    rows |= set(torch.randint(0, t1, (48,), generator=g).tolist())
+    for i in sorted(r for r in rows if 0 <= r < t1):
+        assert torch.equal(Ow[i * t2:(i + 1) * t2], torch.bitwise_and(Lw[i:i + 1], Rw)), i
+    # scattered terms, 2000 at a time (one 200 000-index gather from the 34 GB tensor hung inside
+    # torch on this image; the kernels under test are not involved in the gather)
+    for _ in range(25):
+        idx = torch.randint(0, t1 * t2, (2000,), generator=g, dtype=torch.int64).to(Ow.device)
+        assert torch.equal(Ow[idx], torch.bitwise_and(Lw[idx // t2], Rw[idx % t2]))
+    del out, Ow
+    torch.cuda.empty_cache()
+    from csgn_amd.capi import check
+    big = hip.synth_fill(33, n, 0, (t1 + 1) * dl)
+    with pytest.raises(CsgnError):                              # refused before any launch
+        check(hip.lib.csgn_mul_uniform(n, 1, t1 + 1, t2, big.data_ptr(), R.data_ptr(), L.data_ptr(), 0,
+                                       hip.stream))
+
+
 @pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (63, 4)])
 def test_fused_product_and_sum_decrypt(hip, oracle, n, d):
     """Dec(L*R) and Dec(L+R) computed without materialising the result equal the decryption of
