@@ -310,6 +310,8 @@ class Ref:
         L.ref_time_mul.argtypes = [u64, u64, u64p, u64, u64p, u64, u64, u64p]
         L.ref_time_decrypt.restype = C.c_double
         L.ref_time_decrypt.argtypes = [u64, u64, u64p, u64p, u64, u64, u64p]
+        L.ref_time_circuit.restype = C.c_double
+        L.ref_time_circuit.argtypes = [u64, u64, C.c_uint, u64, C.c_uint, C.POINTER(u64), C.POINTER(C.c_uint)]
         L.ref_text.restype = u64
         L.ref_text.argtypes = [C.c_int, u64, u64, u64p, u64p, u64, C.c_char_p, u64]
 
@@ -402,6 +404,12 @@ class Ref:
         key, v = as_u64(key), as_u64(v)
         sink = u64(0)
         return float(self.lib.ref_time_decrypt(n, d, _p64(key), _p64(v), v.size, iters, C.byref(sink)))
+
+    def time_circuit(self, n: int, d: int, levels: int, iters: int, seed: int = 1):
+        """(seconds, result terms, decrypted bit) of `iters` depth-`levels` config-5 circuits."""
+        terms, bit = u64(0), C.c_uint(0)
+        t = float(self.lib.ref_time_circuit(n, d, levels, iters, seed, C.byref(terms), C.byref(bit)))
+        return t, int(terms.value), int(bit.value)
 
     TEXT_KINDS = {"ciphertext": 0, "key": 1, "context": 2, "plaintext": 3, "permutation": 4}
 

@@ -19,6 +19,7 @@
 #include <ctime>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "certFHE.h"
 
@@ -268,6 +269,50 @@ double ref_time_decrypt(uint64_t n, uint64_t d, const uint64_t *key,
     if (sink)
         *sink = acc;
     delete[] bl;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+/* BASELINE config 5 through the public class API: x0 = Enc(b0); level l odd: x = x + Enc(b),
+ * even: x = x * (Enc(b) + Enc(b')); `levels` levels, `iters` repetitions on the same fresh
+ * inputs.  Returns the seconds spent in the arithmetic plus one final decrypt per repetition
+ * (encryption of the inputs is outside the timed region); *terms_out = terms of the result,
+ * *bit_out = its decryption. */
+double ref_time_circuit(uint64_t n, uint64_t d, unsigned levels, uint64_t iters, unsigned seed,
+                        uint64_t *terms_out, unsigned *bit_out)
+{
+    Context ctx(n, d);
+    SecretKey sk(ctx);
+    srand(seed);
+    std::vector<Ciphertext> in;
+    for (unsigned i = 0; i < 2 * levels + 2; ++i) {
+        Plaintext p((int)((i * 7 + 3) % 5 < 3));
+        in.push_back(sk.encrypt(p));
+    }
+    uint64_t terms = 0;
+    unsigned bit = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t it = 0; it < iters; ++it) {
+        Ciphertext x = in[0];
+        unsigned k = 1;
+        for (unsigned level = 1; level <= levels; ++level) {
+            // compound forms: the reference's copy assignment leaves the target without a
+            // Context, so `x = x * y` would crash it
+            if (level % 2) {
+                x += in[k];
+                k += 1;
+            } else {
+                x *= (in[k] + in[k + 1]);
+                k += 2;
+            }
+        }
+        bit = (unsigned)sk.decrypt(x).getValue();
+        terms = x.getLen() / ctx.getDefaultN();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (terms_out)
+        *terms_out = terms;
+    if (bit_out)
+        *bit_out = bit;
     return std::chrono::duration<double>(t1 - t0).count();
 }
 

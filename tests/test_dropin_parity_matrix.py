@@ -63,3 +63,25 @@ from tests.test_oracle_vs_ref import (  # noqa: E402,F401
     test_permute_ciphertext_and_key,
     test_text_forms_match_reference,
 )
+
+
+def test_config5_circuit_through_the_class_api(ref):
+    """BASELINE config 5 (Context(4096,32), depth 16) driven purely through the public classes of
+    the drop-in: 766 terms at the end and the plaintext the circuit has in the clear; the genuine
+    reference, where its build travelled with the snapshot, gives the same."""
+    def clear(levels):
+        bit = lambda i: int((i * 7 + 3) % 5 < 3)
+        x, k = bit(0), 1
+        for level in range(1, levels + 1):
+            if level % 2:
+                x ^= bit(k); k += 1
+            else:
+                x &= bit(k) ^ bit(k + 1); k += 2
+        return x
+    for n, d, levels, terms in [(4096, 32, 16, 766), (1247, 16, 16, 766), (1247, 16, 9, 47)]:
+        t, got_terms, got_bit = ref.time_circuit(n, d, levels, 2)
+        assert (got_terms, got_bit) == (terms, clear(levels)), (n, levels)
+        from oracle.binding import load_ref
+        genuine = load_ref()
+        if genuine is not None:
+            assert genuine.time_circuit(n, d, levels, 1)[1:] == (terms, clear(levels))
