@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
         const u32 c = csgn_fastdiv(u, ddL);
         const u32 k = u - c * dL;
         const u64 gw = c0 * dL + u;
-        u64 w = DEVRNG ? csgn_splitmix64(seed + CSGN_GOLDEN * (gw + 1)) : rnd[gw];
+        u64 w = DEVRNG ? csgn_rng_word(seed, gw) : rnd[gw];
         if (k == dL - 1)
             w &= tail;
         tile[u] = w;
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
         if (DEVRNG) {
 #pragma unroll
             for (int q = 0; q < VEC; ++q)
-                w[j].w[q] = csgn_splitmix64(seed + CSGN_GOLDEN * (g * VEC + q + 1));
+                w[j].w[q] = csgn_rng_word(seed, g * VEC + q);
         } else {
             w[j] = unit_to_words(rnd[g]);
         }
