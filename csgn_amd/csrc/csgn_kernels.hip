@@ -704,6 +704,17 @@ __global__ void __launch_bounds__(256) k_partial_to_bits(const u32 *__restrict__
 // secret slot came out 1, else give it the spare random bit), then all lanes write the
 // tile out coalesced, OR-ing the key mask into plaintext-1 ciphertexts.
 // ---------------------------------------------------------------------------------------
+// Device-RNG draws of one ciphertext with plaintext 0 (throughput mode only): which of the D secret
+// positions is the chosen one (src/SecretKey.cpp:51) and the spare coin of :76.  One splitmix64
+// word: the high half picks the position by multiply-shift range reduction (no 64-bit modulo), the
+// low bit is the coin.
+__device__ inline void enc_draw(u64 seed, u64 c, const u64 *__restrict__ key, u64 D, u32 &pos, u32 &spare)
+{
+    const u64 r = csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1));
+    pos = (u32)key[__umulhi((u32)(r >> 32), (u32)D)];
+    spare = (u32)r & 1u;
+}
+
 template <bool DEVRNG>
 __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 batch, u32 CB,
                                                  FastDiv ddL, const uint8_t *__restrict__ plain,
@@ -743,8 +754,9 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
         u64 pos;
         u32 spare;
         if (DEVRNG) {
-            pos = key[csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1)) % D];
-            spare = (u32)(csgn_splitmix64((seed ^ 0x8CB92BA72F3D8DD7ull) + CSGN_GOLDEN * (c + 1)) >> 32) & 1u;
+            u32 p32;
+            enc_draw(seed, c, key, D, p32, spare);
+            pos = p32;
         } else {
             pos = chosen[c];
             spare = last[c] & 1u;
@@ -856,8 +868,9 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
             pl = plain[c] & 1u;
             if (!pl) {
                 if (DEVRNG) {
-                    pos = (u32)key[csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1)) % D];
-                    sp = (unsigned char)((csgn_splitmix64((seed ^ 0x8CB92BA72F3D8DD7ull) + CSGN_GOLDEN * (c + 1)) >> 32) & 1u);
+                    u32 coin;
+                    enc_draw(seed, c, key, D, pos, coin);
+                    sp = (unsigned char)coin;
                 } else {
                     pos = chosen[c];
                     sp = last[c] & 1u;
@@ -2192,6 +2205,9 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
     if (batch == 0)
         return hipSuccess;
     // fast form: K aligned 4 KiB segments = TB whole ciphertexts per workgroup, one lane per unit
+    // (a wave-local variant -- whole ciphertexts per wave, ballots only, no LDS or barrier -- measured
+    // slower: 2.6 vs 3.3 TB/s device-RNG at N=1247; its 960-byte wave stores lose more than the
+    // barriers cost)
     {
         const bool wide = (dL % 2 == 0) && aligned16(out) && aligned16(mask) && (device_rng || aligned16(rnd));
         const u32 U = (u32)(wide ? dL / 2 : dL);

@@ -881,20 +881,31 @@ def test_compaction_of_squared_sum(hip, oracle):
     assert bit == hip.download(hip.decrypt_uniform(n, 1, 4, sq, dmask))[0] == 1
 
 
-@pytest.mark.parametrize("lds", [0, 1])
-def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, monkeypatch, lds):
-    """Both encrypt kernels (register/ballot segments; LDS-staged general form) against the
-    genuine reference's fresh ciphertexts, plus agreement of the two device-RNG streams."""
-    monkeypatch.setenv("CSGN_ENC_LDS", str(lds))
+ENC_FORMS = {"seg": {}, "lds": {"CSGN_ENC_LDS": "1"}}
+
+
+@pytest.mark.parametrize("form", sorted(ENC_FORMS))
+def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, monkeypatch, form):
+    """Both encrypt kernels (register/ballot segments; LDS-staged general form) against the genuine
+    reference's fresh ciphertexts, plus agreement of their device-RNG streams on several contexts
+    (even and odd dL, term sizes that do and do not pack into segments)."""
+    def use(f):
+        monkeypatch.delenv("CSGN_ENC_LDS", raising=False)
+        for k, v in ENC_FORMS[f].items():
+            monkeypatch.setenv(k, v)
+    use(form)
     test_encrypt_explicit_reproduces_reference_ciphertexts(hip, oracle, kat)
-    n, d = 1247, 16
-    key = make_key(n, d, 6)
-    dmask = hip.upload(hip.key_mask(n, key))
-    plain = np.random.default_rng(1).integers(0, 2, size=5000).astype(np.uint8)
-    mine = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
-    monkeypatch.setenv("CSGN_ENC_LDS", str(1 - lds))
-    other = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
-    assert np.array_equal(mine, other)
+    for n, d in [(1247, 16), (4096, 32), (65, 4), (63, 4), (130, 5), (8192, 8)]:
+        key = make_key(n, d, 6)
+        dmask = hip.upload(hip.key_mask(n, key))
+        plain = np.random.default_rng(1).integers(0, 2, size=5000).astype(np.uint8)
+        use(form)
+        mine = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
+        use("lds")
+        other = hip.download(hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=5))
+        assert np.array_equal(mine, other), (n, d)
+        bits = hip.download(hip.decrypt_uniform(n, 5000, 1, hip.upload(mine), dmask))
+        assert np.array_equal(bits, plain)
 
 
 def test_config3_depth10_chain_then_1024x1024(hip, oracle):

@@ -19,8 +19,9 @@ for n,d in [(1247,16),(4096,32)]:
     rnd=hip.synth_fill(9,n,0,batch*dl)
     chosen=hip.upload(np.random.default_rng(3).choice(key,batch).astype(np.uint32))
     last=hip.upload(np.random.default_rng(4).integers(0,2,batch).astype(np.uint8))
-    for lds in ("0","1"):
-        os.environ["CSGN_ENC_LDS"]=lds
+    for form,env in (("seg",{}),("lds",{"CSGN_ENC_LDS":"1"})):
+        os.environ.pop("CSGN_ENC_LDS",None)
+        os.environ.update(env); lds=form
         te=timed(lambda: hip.encrypt_explicit(n,d,plain,rnd,chosen,last,dmask))
         tr=timed(lambda: hip.encrypt_device_rng(n,d,plain,dkey,dmask,7))
-        print(f"N={n} lds={lds}: explicit {batch*dl*8/te/1e9:7.0f} GB/s out ({2*batch*dl*8/te/1e9:7.0f} in+out) | device rng {batch*dl*8/tr/1e9:7.0f} GB/s out", flush=True)
+        print(f"N={n} {lds}: explicit {batch*dl*8/te/1e9:7.0f} GB/s out ({2*batch*dl*8/te/1e9:7.0f} in+out) | device rng {batch*dl*8/tr/1e9:7.0f} GB/s out", flush=True)
