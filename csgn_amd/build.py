@@ -21,8 +21,9 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(LIBDIR, "libcsgn_hip.so")
 CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
 
-HIP_SOURCES = ["csgn_capi.hip", "csgn_kernels.hip"]
-HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h"]
+HIP_SOURCES = ["csgn_capi.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
+               "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip"]
+HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h"]
 
 
 def _hipcc() -> str:

@@ -1,6 +1,6 @@
 // csgn_capi.hip -- the extern "C" surface of libcsgn_hip.so (declared in include/csgn_hip.h).
 // Argument validation, error reporting and stream plumbing only; the kernels live in
-// csgn_kernels.hip.  There is deliberately no CPU fallback anywhere in this library.
+// csgn_{mul,add,decrypt,encrypt,permute,compact,harness}.hip.  There is deliberately no CPU fallback anywhere in this library.
 #include "csgn_hip.h"
 #include "csgn_kernels.h"
 

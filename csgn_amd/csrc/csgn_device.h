@@ -1,0 +1,140 @@
+// csgn_device.h -- helpers shared by the kernel translation units (csgn_mul.hip, csgn_add.hip,
+// csgn_decrypt.hip, csgn_encrypt.hip, csgn_permute.hip, csgn_compact.hip, csgn_harness.hip):
+// 16-/8-byte unit access, the XCD-contiguous block order, CSR pair search, launch limits and the
+// environment knobs.  Everything has internal linkage (one copy per translation unit).
+//
+// Common shape of the data path: lanes own consecutive 16-byte units so every wave-level
+// load/store is one global_{load,store}_dwordx4 covering 1 KiB of contiguous, 128-B-aligned
+// HBM.  All of it is bitwise integer work bound by HBM bandwidth: there is no MFMA anywhere.
+// Design notes live in DESIGN.md; reference citations (/root/reference/...) name the scalar loop
+// each kernel replaces.
+#pragma once
+
+#include "csgn_kernels.h"
+
+#include <cstdlib>
+
+namespace csgn {
+
+namespace {
+
+constexpr u32 kWave = 64;
+
+template <typename Unit, bool NT>
+__device__ inline void unit_store(Unit *p, Unit v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+// true iff every mask bit is set in x
+__device__ inline bool unit_covers(unit16 x, unit16 m)
+{
+    unit16 d = (x & m) ^ m;
+    return (d.x | d.y | d.z | d.w) == 0u;
+}
+__device__ inline bool unit_covers(unit8 x, unit8 m) { return (x & m) == m; }
+
+inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// HIP refuses a launch whose gridDim.x * blockDim.x reaches 2^32 (hipErrorInvalidConfiguration),
+// so the number of workgroups per launch is bounded by the block size, not by 2^31.
+constexpr u64 kMaxBlocks256 = ((1ull << 32) - 1) / 256;    // 256-thread workgroups
+constexpr u64 kMaxBlocks512 = ((1ull << 32) - 1) / 512;    // the tiled kernel's upper block size
+constexpr u64 kMaxBlocks1024 = ((1ull << 32) - 1) / 1024;
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; placement is
+// a speed matter only, never correctness).  Remapping the block id so that XCD x owns the
+// x-th contiguous eighth of the logical block range makes every XCD's L2 write back one
+// sequential address stream instead of every 8th 4 KiB chunk: +5 % on a pure fill
+// (tools/wbench.hip: 6.9 -> 7.3 TB/s).  Bijective for any grid size.
+__device__ inline u32 xcd_contiguous_block(u32 b, u32 nblocks)
+{
+    const u32 q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
+    return x * q + min(x, r) + (b >> 3);
+}
+
+// largest p in [lo, hi) with off[p] <= term   (requires off[lo] <= term)
+__device__ inline u32 csr_find(const u64 *__restrict__ off, u32 lo, u32 hi, u64 term)
+{
+    while (hi - lo > 1) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= term)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// largest p >= lo with off[p] <= term, looking near lo first (requires off[lo] <= term): the
+// common answers are lo itself (one load) or a pair a few steps on
+__device__ inline u32 csr_gallop(const u64 *__restrict__ off, u32 lo, u32 batch, u64 term)
+{
+    u32 hi = lo + 1u, step = 1u;
+    while (hi < batch && off[hi] <= term) {
+        lo = hi;
+        step <<= 1;
+        hi = (batch - lo > step) ? lo + step : batch;
+    }
+    return csr_find(off, lo, hi, term);
+}
+
+template <int VEC>
+struct UnitWords {
+    u64 w[VEC];
+};
+__device__ inline UnitWords<2> unit_to_words(unit16 v)
+{
+    UnitWords<2> r;
+    r.w[0] = ((u64)v.y << 32) | v.x;
+    r.w[1] = ((u64)v.w << 32) | v.z;
+    return r;
+}
+__device__ inline UnitWords<1> unit_to_words(unit8 v)
+{
+    UnitWords<1> r;
+    r.w[0] = v;
+    return r;
+}
+__device__ inline void words_to_unit(const UnitWords<2> &r, unit16 &v)
+{
+    v.x = (u32)r.w[0];
+    v.y = (u32)(r.w[0] >> 32);
+    v.z = (u32)r.w[1];
+    v.w = (u32)(r.w[1] >> 32);
+}
+__device__ inline void words_to_unit(const UnitWords<1> &r, unit8 &v) { v = r.w[0]; }
+
+// ------------------------------------------------------------------------- launch helpers
+template <typename T>
+inline bool aligned16(const T *p)
+{
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+inline int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// 4 KiB chunks per workgroup of the flat ragged kernels: as many as 8 (the workgroup's first search
+// is paid once per C chunks) while the grid still has >= 8192 workgroups to fill the chip with.
+// CSGN_RAGGED_C = 1, 2, 4, 8, 16 overrides.
+inline int ragged_chunks(u64 total_units)
+{
+    const int forced = env_int("CSGN_RAGGED_C", 0);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16)
+        return forced;
+    int c = 1;
+    while (c < 8 && total_units / (256u * 2u * (u64)c) >= 8192u)
+        c *= 2;
+    return c;
+}
+
+} // namespace
+
+} // namespace csgn

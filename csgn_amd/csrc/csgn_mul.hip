@@ -1,0 +1,740 @@
+// csgn_mul.hip -- all-pairs multiply: 1x1 stream, flat and LDS-tiled kernels, the operand touch pass, ragged (CSR) form and its planner.
+// Hand-written CDNA4 (gfx950) HIP; shared helpers in csgn_device.h, design notes in DESIGN.md.
+#include "csgn_device.h"
+
+namespace csgn {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// 1x1 batch: out = a & b over a flat stream of units.
+// Replaces Ciphertext::defaultN_multiply (src/Ciphertext.cpp:124-131) for a whole batch of
+// fresh ciphertext pairs (BASELINE configs 2 and 4): 3 x 16 B of HBM traffic per unit.
+// ---------------------------------------------------------------------------------------
+// One 16-byte unit per lane and one 4 KiB segment per short-lived workgroup: measured
+// (tools/rbench.hip) this beats every deeper-unrolled or grid-stride form on MI355X because the
+// chip-wide access front stays dense in address space (6.1 vs 5.3 TB/s).
+template <typename Unit, bool NT>
+__global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
+                                                    const Unit *__restrict__ b,
+                                                    Unit *__restrict__ o, u64 n_units)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n_units)
+        unit_store<Unit, NT>(o + i, a[i] & b[i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Small uniform shapes (t1*t2*U below one tile): flat map from output unit to
+// (pair, left term i, right column c).  Operands are tiny and re-read through L1/L2.
+// Replaces the general path of Ciphertext::multiply (src/Ciphertext.cpp:146-163).
+// ---------------------------------------------------------------------------------------
+template <typename Unit, int MF, bool XCD>
+__global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
+                                                  const Unit *__restrict__ R,
+                                                  Unit *__restrict__ out, u32 total_units, u32 t1,
+                                                  u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU,
+                                                  u32 pf_rows, u32 total_rows)
+{
+    // One launch covers < 2^32 output units, so every index below is 32-bit.  Loads are
+    // unconditional on clamped indices so that all 2*MF of them are in flight together.
+    //
+    // Left-term prefetch: every output row needs a NEW 16*U-byte left term, and with operands
+    // streaming from HBM each of the row's workgroups would sit out a full HBM miss on it
+    // (measured: 4.6 TB/s instead of 7.4).  The lanes that own the first U units of a row
+    // therefore also touch the left term of the row `pf_rows` further down the launch (left
+    // operands of consecutive pairs are contiguous, so this runs across pair boundaries); by
+    // the time that row is dispatched its term sits in L2 / Infinity Cache.  The value is only
+    // kept alive, never used.
+    const u32 CU = t2 * U, LU = t1 * U, PU = t1 * CU;
+    const u32 bid = XCD ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u32 last = total_units - 1;
+    Unit l[MF], r[MF], pf_val;
+    bool pf_on = false;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u32 g = min(bid * (256u * MF) + (u32)m * 256u + threadIdx.x, last);
+        const u32 pair = csgn_fastdiv(g, dPU);
+        const u32 rr = g - pair * PU;
+        const u32 i = csgn_fastdiv(rr, dCU);
+        const u32 c = rr - i * CU;
+        const u32 k = c - csgn_fastdiv(c, dU) * U;
+        l[m] = L[(u64)pair * LU + i * U + k];
+        r[m] = R[(u64)pair * CU + c];
+        if (m == 0 && pf_rows) {
+            const u32 grow = pair * t1 + i + pf_rows;           // global row of this launch
+            if (c < U && grow < total_rows) {
+                pf_val = L[(u64)grow * U + c];
+                pf_on = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+        const u32 g = bid * (256u * MF) + (u32)m * 256u + threadIdx.x;
+        if (g <= last)
+            unit_store<Unit, true>(out + g, l[m] & r[m]);
+    }
+    if (pf_on)
+        asm volatile("" ::"v"(pf_val));
+}
+
+// ---------------------------------------------------------------------------------------
+// All-pairs multiply, LDS-tiled.  Replaces Ciphertext::multiply's general path
+// (src/Ciphertext.cpp:146-163):  out[(i*t2 + j)*dL + k] = L[i*dL + k] & R[j*dL + k].
+//
+// For a fixed left term i the output row is the WHOLE right operand masked by one
+// broadcast term, so the product is a pure streaming write (reads are < 0.3 % of the
+// bytes at 1024x1024).  A workgroup owns TI left terms x (BS*M) right-operand units:
+//   - the TI left terms sit in LDS (TI*U units: 640 B at N=1247 with the default TI=4);
+//   - each lane keeps its M right units in registers for the whole tile;
+//   - per row, a lane reads the one left unit it needs (index c mod U) with ds_read_b128
+//     and issues M global_store_dwordx4; a wave instruction writes 1 KiB contiguous.
+// Defaults (mul_tuning): 256 threads, M = 1 for 16-byte units (2 for 8-byte units), TI = 4.
+// SAMEK only matters for M > 1: when U divides the block size every one of a lane's M columns
+// needs the same left unit, so there is one LDS read per row instead of M.
+// ---------------------------------------------------------------------------------------
+struct MulArgs {
+    const void *L;
+    const void *R;
+    void *out;
+    const u64 *offL;
+    const u64 *offR;
+    const u64 *offOut;
+    u32 t1, t2, U, TI, col_tiles, row_tiles;
+    u32 xcd_remap;
+    u32 pair_base;      // ragged launches cut into chunks: first pair of this launch
+};
+
+template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
+__global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Unit *lds = reinterpret_cast<Unit *>(smem_raw);
+
+    const u32 BS = blockDim.x, tid = threadIdx.x, U = a.U;
+    const u32 tiles = a.col_tiles * a.row_tiles;
+    const u32 bid = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u32 pair_local = bid / tiles;
+    const u32 tile = bid - pair_local * tiles;
+    const u32 pair = a.pair_base + pair_local;
+    const u32 row_tile = tile / a.col_tiles;
+    const u32 col_tile = tile - row_tile * a.col_tiles;
+
+    u32 t1, t2;
+    u64 lbase, rbase, obase;   // in units
+    if (RAGGED) {
+        const u64 l0 = a.offL[pair], r0 = a.offR[pair];
+        t1 = (u32)(a.offL[pair + 1] - l0);
+        t2 = (u32)(a.offR[pair + 1] - r0);
+        lbase = l0 * U;
+        rbase = r0 * U;
+        obase = a.offOut[pair] * U;
+    } else {
+        t1 = a.t1;
+        t2 = a.t2;
+        lbase = (u64)pair * t1 * U;
+        rbase = (u64)pair * t2 * U;
+        obase = (u64)pair * t1 * t2 * U;
+    }
+    const u32 cu = t2 * U;
+    const u32 i0 = row_tile * a.TI;
+    const u32 c0 = col_tile * BS * M;
+    if (i0 >= t1 || c0 >= cu)
+        return;                               // whole workgroup leaves together
+    const u32 rows = min(a.TI, t1 - i0);
+
+    // stage the left tile: rows*U consecutive units, coalesced (wave 0 only at the default tile)
+    const Unit *Lp = reinterpret_cast<const Unit *>(a.L) + lbase + (u64)i0 * U;
+    for (u32 u = tid; u < rows * U; u += BS)
+        lds[u] = Lp[u];
+
+    // this lane's right-operand units stay in registers for the whole tile.  (Measured A/B on
+    // one device, bench.py batch 8192: issuing this load first and unconditionally, so that it
+    // overlaps the left-tile fetch, is 4-5 % SLOWER end to end, 39.1 k vs 41.5 k mult/s; the
+    // 8 resident workgroups per CU already hide the prologue latency.)
+    const Unit *Rp = reinterpret_cast<const Unit *>(a.R) + rbase;
+    Unit r[M];
+    u32 k[M];
+    bool valid[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const u32 c = c0 + (u32)m * BS + tid;
+        valid[m] = c < cu;
+        if (valid[m])
+            r[m] = Rp[c];
+        k[m] = c % U;
+    }
+    __syncthreads();
+
+    Unit *orow = reinterpret_cast<Unit *>(a.out) + obase + (u64)i0 * cu + c0 + tid;
+#pragma unroll 2
+    for (u32 i = 0; i < rows; ++i) {
+        if (SAMEK) {
+            const Unit l = lds[i * U + k[0]];
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                if (valid[m])
+                    unit_store<Unit, NT>(orow + (u32)m * BS, r[m] & l);
+        } else {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                if (valid[m])
+                    unit_store<Unit, NT>(orow + (u32)m * BS, r[m] & lds[i * U + k[m]]);
+        }
+        orow += cu;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Ragged batches (CSR offsets), skew-proof form.  The grid covers the FLATTENED output
+// (one 16-byte unit per lane, 4 KiB per workgroup, address order), so its size is the real
+// output, not batch x the largest shape.  A lane finds the pair that owns its output term by
+// binary search over the product offsets: first the workgroup's starting pair (identical
+// addresses in every lane, so the loads broadcast), then a short per-lane search inside the
+// few pairs one workgroup can span.
+// ---------------------------------------------------------------------------------------
+
+// A workgroup owns C consecutive 4 KiB chunks of the flattened output: one uniform search for its
+// first term, then every wave walks forward from the pair it was in (csr_gallop), so the
+// log2(batch) dependent loads are paid once per C chunks instead of twice per chunk.
+template <typename Unit, int C>
+__global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
+                                                         const u64 *__restrict__ offL,
+                                                         const Unit *__restrict__ R,
+                                                         const u64 *__restrict__ offR,
+                                                         Unit *__restrict__ out,
+                                                         const u64 *__restrict__ offOut, u32 batch,
+                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU,
+                                                         u32 pf_pairs)
+{
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g_begin = unit_base + (u64)bid * (256u * C);
+    if (g_begin >= total_units)
+        return;
+    const u64 term0 = g_begin / U;                              // workgroup-uniform
+    const u32 r0blk = (u32)(g_begin - term0 * U);
+    u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
+    // The workgroup that holds the start of a pair pulls the operands of the pair `pf_pairs` further
+    // on into the caches (one dword per 128-byte line, values unused): by the time that pair's
+    // rows are written its left terms are hits instead of HBM misses under full write load.
+    if (pf_pairs && term0 - offOut[pw] < (256u * C) / U + 1u) {
+        const u32 pt = min(pw + pf_pairs, batch - 1u);
+        const u64 lb = offL[pt] * U * sizeof(Unit), le = offL[pt + 1] * U * sizeof(Unit);
+        const u64 rb = offR[pt] * U * sizeof(Unit), re = offR[pt + 1] * U * sizeof(Unit);
+        const char *Lb = reinterpret_cast<const char *>(L), *Rb = reinterpret_cast<const char *>(R);
+#pragma unroll 1
+        for (u64 a = lb + (u64)threadIdx.x * 128u, n = 0; a < le && n < 8; a += 256u * 128u, ++n) {
+            const u32 v = *reinterpret_cast<const u32 *>(Lb + a);
+            asm volatile("" ::"v"(v));
+        }
+#pragma unroll 1
+        for (u64 a = rb + (u64)threadIdx.x * 128u, n = 0; a < re && n < 8; a += 256u * 128u, ++n) {
+            const u32 v = *reinterpret_cast<const u32 *>(Rb + a);
+            asm volatile("" ::"v"(v));
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+        if (g_begin + (u32)c * 256u >= total_units)
+            break;
+        // this lane's term: a 32-bit division of its distance from the workgroup's first term
+        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
+        const u32 dt = csgn_fastdiv(r, dU);
+        const u64 term = term0 + dt;
+        const u32 k = r - dt * U;
+        u32 p = pw;
+        if (g < total_units) {
+            p = csr_gallop(offOut, pw, batch, term);            // runs of empty pairs are walked over
+            const u64 l0 = offL[p], rr0 = offR[p];
+            const u32 t2 = (u32)(offR[p + 1] - rr0);
+            const u32 q = (u32)(term - offOut[p]);              // product term index inside the pair
+            const u32 i = q / t2, j = q - i * t2;
+            unit_store<Unit, true>(out + g, L[(l0 + i) * U + k] & R[(rr0 + j) * U + k]);
+        }
+        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);       // later chunks start from here
+    }
+}
+
+// Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
+// launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
+// and the fix-up -- 1M pairs plan in tens of microseconds.
+__global__ void __launch_bounds__(256) k_plan_chunks(u64 batch, const u64 *__restrict__ offL,
+                                                     const u64 *__restrict__ offR,
+                                                     u64 *__restrict__ offOut, u64 *__restrict__ partial,
+                                                     u64 *__restrict__ plan4)
+{
+    __shared__ u64 sums[256];
+    const u32 tid = threadIdx.x;
+    const u64 b0 = (u64)blockIdx.x * 1024u + (u64)tid * 4u;
+    u64 c[4], m1 = 0, m2 = 0, mp = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = 0;
+        if (b0 + j < batch) {
+            const u64 t1 = offL[b0 + j + 1] - offL[b0 + j], t2 = offR[b0 + j + 1] - offR[b0 + j];
+            c[j] = t1 * t2;
+            m1 = max(m1, t1);
+            m2 = max(m2, t2);
+            mp = max(mp, c[j]);
+        }
+        mine += c[j];
+    }
+    sums[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
+        for (u32 t = 0; t < 256; ++t) {
+            const u64 v = sums[t];
+            sums[t] = run;
+            run += v;
+        }
+        partial[blockIdx.x] = run;
+    }
+    __syncthreads();
+    u64 run = sums[tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b0 + j < batch)
+            offOut[b0 + j] = run;                      // chunk-local; k_plan_fix adds the chunk base
+        run += c[j];
+    }
+    // wave-level maxima, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        m1 = max(m1, (u64)__shfl_down(m1, off, 64));
+        m2 = max(m2, (u64)__shfl_down(m2, off, 64));
+        mp = max(mp, (u64)__shfl_down(mp, off, 64));
+    }
+    if ((tid & (kWave - 1)) == 0) {
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1), m1);
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 2), m2);
+        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 3), mp);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 batch, u64 *__restrict__ partial,
+                                                             u64 *__restrict__ offOut, u64 *__restrict__ plan4)
+{
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 chunk = (nchunks + 1023) / 1024;
+    const u64 c0 = min(nchunks, (u64)tid * chunk), c1 = min(nchunks, c0 + chunk);
+    u64 sum = 0;
+    for (u64 c = c0; c < c1; ++c)
+        sum += partial[c];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
+        for (u32 t = 0; t < 1024; ++t) {
+            const u64 v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        offOut[batch] = run;
+        plan4[0] = run;
+    }
+    __syncthreads();
+    u64 run = part[tid];
+    for (u64 c = c0; c < c1; ++c) {
+        const u64 v = partial[c];
+        partial[c] = run;
+        run += v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
+                                                  u64 *__restrict__ offOut)
+{
+    const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (b < batch)
+        offOut[b] += partial[b >> 10];
+}
+
+// Block size for the tiled kernel: a multiple of 64 that U divides (so every column a lane
+// owns needs the same left unit), at least 256 threads, at most 512.  0 = none exists.
+u32 samek_block(u32 U)
+{
+    for (u32 bs = 256; bs <= 512; bs += 64)
+        if (bs % U == 0)
+            return bs;
+    return 0;
+}
+
+template <typename Unit, int M, bool RAGGED>
+hipError_t launch_tiled_m(const MulArgs &a, u32 bs, bool samek, bool nt, u32 blocks, size_t lds,
+                          hipStream_t s)
+{
+    if (samek) {
+        if (nt)
+            k_mul_tiled<Unit, M, true, RAGGED, true><<<blocks, bs, lds, s>>>(a);
+        else
+            k_mul_tiled<Unit, M, true, RAGGED, false><<<blocks, bs, lds, s>>>(a);
+    } else {
+        if (nt)
+            k_mul_tiled<Unit, M, false, RAGGED, true><<<blocks, bs, lds, s>>>(a);
+        else
+            k_mul_tiled<Unit, M, false, RAGGED, false><<<blocks, bs, lds, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+// Launch the tiled kernel for `pairs` pairs whose shapes are bounded by (t1, t2).
+template <typename Unit, bool RAGGED>
+hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
+{
+    const MulTuning tune = mul_tuning();
+    // With M > 1 a block size that U divides lets every column of a lane share one LDS read
+    // (SAMEK); with the default M == 1 there is a single column per lane and 256 threads
+    // (4 KiB-aligned row segments) measured fastest.
+    // auto: 256 threads x 4 KiB row segments -- one 16-byte unit per lane, or two 8-byte units
+    // when dL is odd (measured at N=1300: 5.3 -> 6.4 TB/s, the 2 KiB segments of M=1 lose)
+    const int m_req = tune.m ? tune.m : (sizeof(Unit) == 8 ? 2 : 1);
+    u32 bs = tune.bs ? (u32)tune.bs : (tune.m > 1 ? samek_block(U) : 256u);
+    if (bs == 0)
+        bs = 256;
+    const bool samek = bs % U == 0;
+    const u32 cu = a.t2 * U;
+    // do not give a lane more columns than the row has
+    int m = m_req;
+    while (m > 1 && (u64)bs * (m / 2) >= cu)
+        m /= 2;
+    // left tile: TI terms, capped so the LDS image stays <= 32 KB
+    u32 ti = (u32)tune.ti;
+    const u32 cap = (u32)(32768u / (U * sizeof(Unit)));
+    if (ti > cap)
+        ti = cap ? cap : 1;
+    if (ti > a.t1)
+        ti = a.t1;
+    a.U = U;
+    a.TI = ti;
+    // XCD-contiguous order helps the (linear) flat kernel but measured 7 % slower on the tiled
+    // kernel's comb-shaped store pattern, so it is opt-in here (CSGN_MUL_XCD=2)
+    a.xcd_remap = tune.xcd == 2 ? 1u : 0u;
+    a.col_tiles = (cu + bs * m - 1) / (bs * m);
+    a.row_tiles = (a.t1 + ti - 1) / ti;
+    const u64 tiles = (u64)a.col_tiles * a.row_tiles;
+    const size_t lds = (size_t)ti * U * sizeof(Unit);
+    // at most kMaxBlocks512 workgroups per launch (gridDim.x * blockDim.x < 2^32)
+    if (tiles > kMaxBlocks512 || pairs >= (1ull << 32))
+        return hipErrorInvalidValue;
+    const u64 max_pairs = kMaxBlocks512 / tiles;
+    for (u64 p0 = 0; p0 < pairs; p0 += max_pairs) {
+        const u64 np = (pairs - p0 < max_pairs) ? pairs - p0 : max_pairs;
+        MulArgs b = a;
+        b.pair_base = RAGGED ? (u32)p0 : 0u;
+        if (!RAGGED) {
+            b.L = reinterpret_cast<const Unit *>(a.L) + p0 * a.t1 * U;
+            b.R = reinterpret_cast<const Unit *>(a.R) + p0 * a.t2 * U;
+            b.out = reinterpret_cast<Unit *>(a.out) + p0 * a.t1 * a.t2 * U;
+        }
+        const u32 blocks = (u32)(np * tiles);
+        hipError_t e;
+        switch (m) {
+        case 1: e = launch_tiled_m<Unit, 1, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        case 2: e = launch_tiled_m<Unit, 2, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        case 4: e = launch_tiled_m<Unit, 4, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        default: e = launch_tiled_m<Unit, 8, RAGGED>(b, bs, samek, tune.nt, blocks, lds, s); break;
+        }
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+// Which kernel an all-pairs product takes (measured with COLD operands -- every launch reads pairs
+// that are not in any cache, tools/bench_cold.py, profiles/r01/bench_cold*.log):
+//   * output >= 4x the operands (t1*t2 >= 4*(t1+t2)), 16-byte units, and at least 4 MB of operands
+//     in the launch (a stream, not a single product): the flat kernel (one output
+//     unit per lane, linear 4 KiB per workgroup, XCD-contiguous order) AFTER a touch pass that
+//     reads one dword of every operand line.  The flat kernel alone stalls on the first touch of
+//     every left term (an HBM miss under full write load, 4.6 TB/s at 1024x1024); with the
+//     operands already in the memory-side cache it runs at 7.2-7.5 TB/s against 6.9 for the
+//     LDS-tiled kernel, 6.2 against 3.9 at 32x32, 5.7 against 4.6 at 8x8.  The touch is a second
+//     read of the operands, hence the 4x condition, and is done per <= 64 MB of operands so that
+//     they are still in the 256 MB cache when their pairs run.
+//   * otherwise rows shorter than a workgroup (t2*U < 256 units; < 64 for the 8-byte units of an
+//     odd dL, whose flat kernel only writes 2 KiB per workgroup): the flat kernel, no touch (the
+//     tiled kernel leaves column lanes idle: 1.4 vs 6.0 TB/s at t2 = 1).
+//   * everything else (thin products with long rows, 8-byte units): the LDS-tiled kernel.
+// CSGN_MUL_FLAT (-1 tiled, k > 0 flat with k units per lane) and CSGN_MUL_TOUCH (0..3: bit 0 left,
+// bit 1 right operand) override for sweeps.
+struct MulPlan {
+    int flat;       // 0 = LDS-tiled kernel, k > 0 = flat kernel with k units per lane
+    int touch;      // operands to pull into the memory-side cache first (bit 0 left, bit 1 right)
+};
+
+static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
+{
+    const MulTuning tune = mul_tuning();
+    const u64 PU = t1 * t2 * U;
+    MulPlan p = {0, 0};
+    if (PU >= (1ull << 31) || tune.flat == -1)
+        return p;
+    const int touch_env = env_int("CSGN_MUL_TOUCH", -1);
+    if (tune.flat > 0) {
+        p.flat = tune.flat;
+        p.touch = touch_env > 0 ? (touch_env & 3) : 0;
+        return p;
+    }
+    // a call with a few MB of operands is not a stream: they are usually still cached from the
+    // kernel that produced them, and two extra launches triple the cost of a small product
+    // (class API, 64x64: 10.9 us per multiply with the touch, 3.0-3.8 without)
+    const bool streaming = pairs * (t1 + t2) * U * unit_bytes >= (4ull << 20);
+    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && (streaming || touch_env > 0)) {
+        p.flat = 1;
+        p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
+    } else if (t2 * U < (unit_bytes == 16 ? 256u : 64u)) {
+        p.flat = 1;
+        p.touch = touch_env > 0 ? (touch_env & 3) : 0;
+    }
+    return p;
+}
+
+// Read one dword of every 128-byte line of [p, p+bytes): pulls an operand into the memory-side
+// cache ahead of a kernel whose first touch of it would otherwise be a serialising HBM miss.
+__global__ void __launch_bounds__(256) k_touch(const u32 *__restrict__ p, u64 lines, u32 dwords_per_line)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < lines) {
+        const u32 v = p[i * dwords_per_line];
+        asm volatile("" ::"v"(v));
+    }
+}
+
+// One uniform chunk (pairs are contiguous in L, R and out).
+template <typename Unit>
+hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, const u64 *R, u64 *out,
+                             hipStream_t s)
+{
+    const Unit *Lu = reinterpret_cast<const Unit *>(L);
+    const Unit *Ru = reinterpret_cast<const Unit *>(R);
+    Unit *Ou = reinterpret_cast<Unit *>(out);
+    const u64 PU = (u64)t1 * t2 * U;
+    const u64 total = pairs * PU;
+    if (total == 0)
+        return hipSuccess;
+    const MulTuning tune = mul_tuning();
+    if (t1 == 1 && t2 == 1) {
+        // at most 2^31-1 workgroups of 256 units per launch
+        const u64 per_launch = kMaxBlocks256 * 256u;
+        for (u64 u0 = 0; u0 < total; u0 += per_launch) {
+            const u64 nu = (total - u0 < per_launch) ? total - u0 : per_launch;
+            k_and_stream<Unit, true><<<ceil_div_u64(nu, 256u), 256, 0, s>>>(Lu + u0, Ru + u0, Ou + u0, nu);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2, pairs);
+    if (plan.flat) {
+        const int mf = plan.flat;
+        // left-term prefetch from inside the kernel (only without the touch pass, only when a row
+        // fills a workgroup): ~6 MB of output ahead per XCD stream
+        u32 pfr = 0;
+        if (!plan.touch && (u64)t2 * U >= 256u) {
+            const u64 ahead = (u64)env_int("CSGN_MUL_PF_KB", tune.xcd ? 6144 : 49152) << 10;
+            const u64 row_bytes = (u64)t2 * U * sizeof(Unit);
+            pfr = (u32)((ahead + row_bytes - 1) / row_bytes);
+        }
+        u64 pairs_per = (0xFFFFFF00ull / PU) ? (0xFFFFFF00ull / PU) : 1;   // units (= threads) per launch < 2^32
+        if (plan.touch) {
+            // touched operands must still be in the 256 MB memory-side cache when their pair runs:
+            // at most 64 MB of them per touch + launch
+            const u64 op_bytes = (u64)(t1 + t2) * U * sizeof(Unit);
+            pairs_per = std::min<u64>(pairs_per, std::max<u64>(1, (64ull << 20) / op_bytes));
+        }
+        const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
+                      dU = csgn_fastdiv_make(U);
+        for (u64 p0 = 0; p0 < pairs; p0 += pairs_per) {
+            const u64 np = (pairs - p0 < pairs_per) ? pairs - p0 : pairs_per;
+            const u32 tot = (u32)(np * PU);
+            const u32 trows = (u32)(np * t1);
+            const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
+            const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
+            Unit *Oc = Ou + p0 * PU;
+            if (plan.touch) {
+                const u32 lb = 128;       // the L2 fills whole 128-byte lines (a 256-byte stride loses the gain)
+                const u64 ll = (np * t1 * U * sizeof(Unit) + lb - 1) / lb, rl = (np * t2 * U * sizeof(Unit) + lb - 1) / lb;
+                if (plan.touch & 1)
+                    k_touch<<<ceil_div_u64(ll, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Lc), ll, lb / 4);
+                if (plan.touch & 2)
+                    k_touch<<<ceil_div_u64(rl, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Rc), rl, lb / 4);
+            }
+#define CSGN_FLAT(MF)                                                                                  \
+    do {                                                                                               \
+        if (tune.xcd)                                                                                  \
+            k_mul_flat<Unit, MF, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows);  \
+        else                                                                                           \
+            k_mul_flat<Unit, MF, false><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows); \
+    } while (0)
+            switch (mf) {
+            case 1: CSGN_FLAT(1); break;
+            case 2: CSGN_FLAT(2); break;
+            case 4: CSGN_FLAT(4); break;
+            default: CSGN_FLAT(8); break;
+            }
+#undef CSGN_FLAT
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+    MulArgs a = {};
+    a.L = L;
+    a.R = R;
+    a.out = out;
+    a.t1 = t1;
+    a.t2 = t2;
+    return launch_tiled<Unit, false>(a, pairs, U, s);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------ public
+
+MulTuning mul_tuning()
+{
+    MulTuning t;
+    // Defaults from the MI355X sweeps recorded in DESIGN.md / profiles/: 256-thread workgroups
+    // (4 KiB row segments), one column unit per lane, 4 left terms per tile, non-temporal
+    // stores.  Short-lived workgroups keep the chip-wide write front dense in address space,
+    // which is what HBM rewards; long-lived tiles (TI=64) lose ~20 % to the scattered store pattern.
+    t.m = env_int("CSGN_MUL_M", 0);          // 0 = auto: 1 column unit per lane (2 for 8-byte units)
+    if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
+        t.m = 0;
+    t.ti = env_int("CSGN_MUL_TI", 4);
+    if (t.ti < 1)
+        t.ti = 1;
+    t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
+    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = auto (mul_plan); >0 = flat with that unroll; -1 = always tiled
+    if (t.flat != -1 && t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
+        t.flat = 0;
+    t.xcd = env_int("CSGN_MUL_XCD", 1);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both
+    if (t.xcd < 0 || t.xcd > 2)
+        t.xcd = 1;
+    t.bs = env_int("CSGN_MUL_BS", 0);
+    if (t.bs % 64 != 0 || t.bs < 64 || t.bs > 512)
+        t.bs = 0;
+    return t;
+}
+
+const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    const bool wide = dL % 2 == 0;
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    if (t1 == 1 && t2 == 1)
+        return "k_and_stream";
+    const MulPlan p = mul_plan(wide ? 16 : 8, U, t1, t2, pairs);
+    return p.flat ? (p.touch ? "k_touch+k_mul_flat" : "k_mul_flat") : "k_mul_tiled";
+}
+
+hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
+                       u64 out_slots, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0 || t1 == 0 || t2 == 0)
+        return hipSuccess;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    const u64 slots = (out_slots == 0 || out_slots > batch) ? batch : out_slots;
+    for (u64 p0 = 0; p0 < batch; p0 += slots) {
+        const u64 np = (batch - p0 < slots) ? batch - p0 : slots;
+        const u64 *Lc = L + p0 * t1 * dL;
+        const u64 *Rc = R + p0 * t2 * dL;
+        hipError_t e = wide ? mul_uniform_chunk<unit16>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s)
+                            : mul_uniform_chunk<unit8>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+u64 mul_ragged_plan_scratch_words(u64 batch) { return 4 + (batch + 1023) / 1024 + 1; }
+
+hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
+                           hipStream_t s)
+{
+    // d_work: [plan4 (total, max t1, max t2, max t1*t2)][one partial per 1024-pair chunk]
+    u64 *plan4 = d_work, *partial = d_work + 4;
+    const u64 nchunks = (batch + 1023) / 1024;
+    hipError_t e = hipMemsetAsync(d_work, 0, mul_ragged_plan_scratch_words(batch) * 8, s);
+    if (e != hipSuccess)
+        return e;
+    if (nchunks > kMaxBlocks256)
+        return hipErrorInvalidValue;
+    if (batch)
+        k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
+    k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
+    if (batch)
+        k_plan_fix<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, partial, offOut);
+    return hipGetLastError();
+}
+
+hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
+                      const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
+                      u64 total_out_terms, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
+        return hipSuccess;
+    if (batch >= (1ull << 32))
+        return hipErrorInvalidValue;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    // Nearly uniform batches of large products keep the LDS-tiled kernel (one grid sized for the
+    // largest shape); anything skewed or small goes through the flat ragged kernel, whose grid
+    // is the real output.
+    const bool tiled = env_int("CSGN_RAGGED_FLAT", 0) == 0 && max_t1 * max_t2 * U > 8192 &&
+                       batch * max_t1 * max_t2 <= 2 * total_out_terms;
+    if (tiled) {
+        MulArgs a = {};
+        a.L = L;
+        a.R = R;
+        a.out = out;
+        a.offL = offL;
+        a.offR = offR;
+        a.offOut = offOut;
+        a.t1 = (u32)max_t1;
+        a.t2 = (u32)max_t2;
+        return wide ? launch_tiled<unit16, true>(a, batch, U, s) : launch_tiled<unit8, true>(a, batch, U, s);
+    }
+    const u64 total_units = total_out_terms * U;
+    const FastDiv dU = csgn_fastdiv_make(U);
+    const int chunks = ragged_chunks(total_units);
+    const u32 pf_pairs = (u32)env_int("CSGN_RAGGED_PF", 32);    // operand prefetch distance in pairs, 0 = off
+    const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
+    for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
+        const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
+        const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+#define CSGN_RAGGED_LAUNCH(CH)                                                                      \
+    do {                                                                                            \
+        if (wide)                                                                                   \
+            k_mul_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
+        else                                                                                        \
+            k_mul_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
+                                                                (u32)batch, u0, u0 + nu, U, dU,     \
+                                                                pf_pairs);                          \
+    } while (0)
+        switch (chunks) {
+        case 1: CSGN_RAGGED_LAUNCH(1); break;
+        case 2: CSGN_RAGGED_LAUNCH(2); break;
+        case 4: CSGN_RAGGED_LAUNCH(4); break;
+        case 16: CSGN_RAGGED_LAUNCH(16); break;
+        default: CSGN_RAGGED_LAUNCH(8); break;
+        }
+#undef CSGN_RAGGED_LAUNCH
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            return le;
+    }
+    return hipSuccess;
+}
+
+} // namespace csgn
