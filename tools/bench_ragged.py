@@ -72,3 +72,20 @@ for name,t1s,t2s in [
         row.append(f"C={ch}: {alg/t/1e9:6.0f}")
     print(f"add_ragged {name:<32} GB/s (alloc + kernel)   " + "  ".join(row), flush=True)
     del L,R
+
+# ragged decrypt: term lists of skewed lengths (the products of the batches above have this shape)
+key = np.random.default_rng(1).permutation(n)[:16].astype(np.uint64)
+dmask = hip.upload(hip.key_mask(n, key))
+for name, ts in [
+    ("uniform 4096 terms x4096", [4096] * 4096),
+    ("lognormal mean~1100 x16384", np.clip(rng.lognormal(6.5, 1, 16384), 1, 200000).astype(int)),
+    ("one 1M-term + 65535 single terms", [1 << 20] + [1] * 65535),
+    ("1M single terms (ragged path)", [1] * (1 << 20)),
+]:
+    off = csr(ts)
+    tot = int(off[-1])
+    W = hip.synth_fill(3, n, 0, tot * dl)
+    doff = hip.upload(off)
+    t = timed(lambda: hip.decrypt_ragged(n, W, doff, dmask, total_terms=tot))
+    print(f"decrypt_ragged {name:<34} {t*1e3:8.3f} ms  {tot*dl*8/t/1e9:8.1f} GB/s ({100*tot*dl*8/t/8e12:4.1f}% of peak), {tot*dl*8/1e6:.0f} MB", flush=True)
+    del W
