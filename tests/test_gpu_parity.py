@@ -620,6 +620,38 @@ def test_permute_kernel_forms(hip, oracle, monkeypatch, n, form):
     assert np.array_equal(hip.download(hip.permute_uniform(n, 128, 1, once, inv)), w)
 
 
+def test_permute_forms_fuzz(hip, oracle, monkeypatch):
+    """120 random (N, batch, terms per input, per-term mode) cases, some with out-of-range
+    permutation entries ("no source"): the bit-plane kernel with 16- and 8-byte staging and the
+    ballot kernel must agree word for word; every tenth case is also checked against the oracle."""
+    import torch
+    rng = np.random.default_rng(2026)
+    for it in range(120):
+        n = int(rng.integers(1, 4097))
+        batch = int(rng.choice([16, 17, 63, 64, 65, 127, 128, 129, 1000, 4097, 20000]))
+        dl = oracle.default_len(n)
+        perm = rng.permutation(n).astype(np.uint32)
+        if it % 5 == 0:
+            perm[rng.integers(0, n, size=max(1, n // 7))] = n + int(rng.integers(0, 1000))
+        dperm = hip.upload(perm)
+        terms_in = int(rng.choice([1, 1, 3]))
+        per_term = bool(rng.integers(0, 2)) if terms_in > 1 else False
+        W = hip.synth_fill(it, n, 0, batch * terms_in * dl)
+        outs = []
+        for form in ("planes", "narrow", "ballot"):
+            monkeypatch.setenv("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
+            monkeypatch.setenv("CSGN_PERM_NARROW", "1" if form == "narrow" else "0")
+            outs.append(hip.permute_uniform(n, batch, terms_in, W, dperm, per_term=per_term).clone())
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (n, batch, terms_in, per_term)
+        if it % 10 == 3:                              # a true permutation (it % 5 != 0): oracle too
+            hw, ho = hip.download(W), hip.download(outs[0])
+            stride = dl if per_term else terms_in * dl
+            for b in (0, batch // 2, batch - 1):
+                src = hw[b * stride:b * stride + dl]
+                assert np.array_equal(ho[b * dl:(b + 1) * dl],
+                                      oracle.permute_ciphertext(n, perm.astype(np.uint64), src)), (n, b)
+
+
 @pytest.mark.parametrize("n,d", [(8320, 8), (8250, 5), (1247, 16), (193, 6), (704, 9), (1088, 7)])
 @pytest.mark.parametrize("loop", [0, 1])
 def test_decrypt_kernel_forms(hip, oracle, monkeypatch, n, d, loop):
