@@ -171,6 +171,40 @@ def test_mul_streaming_launches_default_dispatch(hip, oracle, n, t1, t2, batch):
         assert np.array_equal(ho[b * per:(b + 1) * per], want), (n, t1, t2, b)
 
 
+def test_mul_kernel_forms_fuzz(hip, oracle, monkeypatch):
+    """80 random (N, t1, t2, batch, arena slots) cases: the default dispatch, the LDS-tiled kernel
+    and the flat kernel with and without the touch pass must produce identical words; every eighth
+    case is also compared with the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    for it in range(80):
+        n = int(rng.choice([63, 64, 65, 130, 1247, 1300, 2048, 4096]))
+        dl = oracle.default_len(n)
+        t1, t2 = (int(x) for x in rng.integers(1, 200, size=2))
+        if it % 7 == 0:
+            t1, t2 = int(rng.integers(1, 4)), int(rng.integers(1, 1500))
+        batch = int(rng.integers(1, 24))
+        slots = int(rng.choice([0, 0, 1, 3])) if batch > 3 else 0
+        L = hip.synth_fill(2 * it, n, 0, batch * t1 * dl)
+        R = hip.synth_fill(2 * it + 1, n, 0, batch * t2 * dl)
+        outs = []
+        for env in ({}, {"CSGN_MUL_FLAT": "-1"}, {"CSGN_MUL_FLAT": "1", "CSGN_MUL_TOUCH": "3"},
+                    {"CSGN_MUL_FLAT": "2", "CSGN_MUL_TOUCH": "0", "CSGN_MUL_XCD": "0"}):
+            for k in ("CSGN_MUL_FLAT", "CSGN_MUL_TOUCH", "CSGN_MUL_XCD"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            outs.append(hip.mul_uniform(n, batch, t1, t2, L, R, out_slots=slots).clone())
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (n, t1, t2, batch, slots)
+        if it % 8 == 0 and slots == 0:
+            hl, hr, ho = hip.download(L), hip.download(R), hip.download(outs[0])
+            per = t1 * t2 * dl
+            for b in {0, batch - 1}:
+                want, _ = oracle.mul(n, hl[b * t1 * dl:(b + 1) * t1 * dl], hr[b * t2 * dl:(b + 1) * t2 * dl])
+                assert np.array_equal(ho[b * per:(b + 1) * per], want), (n, t1, t2, b)
+
+
 @pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
 def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
     monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
