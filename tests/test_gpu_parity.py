@@ -1106,6 +1106,59 @@ def test_ragged_skewed_batches(hip, oracle, monkeypatch, n, d, force_flat):
         assert np.array_equal(sout[int(soff[b]) * dl:int(soff[b + 1]) * dl], want_s), b
 
 
+def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
+    """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
+    ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
+    prefetch off / 32 / 5000 pairs ahead, and through the default dispatch: identical words; every
+    fifth batch is compared pair by pair with the oracle."""
+    import torch
+    rng = np.random.default_rng(4242)
+    for it in range(30):
+        n = int(rng.choice([65, 1247, 1300, 4096]))
+        dl = oracle.default_len(n)
+        batch = int(rng.choice([1, 7, 300, 2500]))
+        t1s = rng.integers(0, 9, size=batch)
+        t2s = rng.integers(0, 9, size=batch)
+        if it % 3 == 0:
+            t1s[rng.integers(0, batch)], t2s[rng.integers(0, batch)] = 200, 150
+        if it % 4 == 0 and batch > 600:
+            t1s[100:600] = 0                                   # a run of empty pairs longer than a workgroup
+        if not int(np.sum(t1s * t2s)):
+            t1s[0] = t2s[0] = 2
+        offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+        L = hip.synth_fill(3 * it, n, 0, max(1, int(offL[-1])) * dl)
+        R = hip.synth_fill(3 * it + 1, n, 0, max(1, int(offR[-1])) * dl)
+        dOL, dOR = hip.upload(offL), hip.upload(offR)
+        tot_add = int(offL[-1] + offR[-1])
+        ref_mul = ref_add = None
+        for env in ({}, {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "1", "CSGN_RAGGED_PF": "0"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "8", "CSGN_RAGGED_PF": "32"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "16", "CSGN_RAGGED_PF": "5000"}):
+            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m, moff = hip.mul_ragged(n, L, dOL, R, dOR)
+            a, aoff = hip.add_ragged(n, L, dOL, R, dOR, total_terms_out=tot_add)
+            if ref_mul is None:
+                ref_mul, ref_moff, ref_add, ref_aoff = m.clone(), moff.clone(), a.clone(), aoff.clone()
+            else:
+                assert torch.equal(m, ref_mul) and torch.equal(moff, ref_moff), (it, env)
+                assert torch.equal(a, ref_add) and torch.equal(aoff, ref_aoff), (it, env)
+        assert np.array_equal(hip.download(ref_moff), csr((t1s * t2s).tolist()))
+        if it % 5 == 0:
+            hl, hr, hm, ha = (hip.download(x) for x in (L, R, ref_mul, ref_add))
+            mo, ao = hip.download(ref_moff), hip.download(ref_aoff)
+            for b in range(0, batch, max(1, batch // 40)):
+                lh = hl[int(offL[b]) * dl:int(offL[b + 1]) * dl]
+                rh = hr[int(offR[b]) * dl:int(offR[b + 1]) * dl]
+                if t1s[b] and t2s[b]:
+                    want, _ = oracle.mul(n, lh, rh)
+                    assert np.array_equal(hm[int(mo[b]) * dl:int(mo[b + 1]) * dl], want), (it, b)
+                want_s, _ = oracle.add(lh, rh)
+                assert np.array_equal(ha[int(ao[b]) * dl:int(ao[b + 1]) * dl], want_s), (it, b)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 1023, 1024, 1025, 5000, 200000])
 def test_mul_ragged_plan_offsets(hip, batch):
     """The chunked plan scan (1024-pair chunks, partial scan, fix-up) against numpy for batch
