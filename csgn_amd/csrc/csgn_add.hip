@@ -51,11 +51,12 @@ template <typename Unit, bool NT>
 __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
                                                   Unit *__restrict__ out, u32 total_units, u32 LU,
-                                                  u32 RU, FastDiv dOU)
+                                                  u32 RU, FastDiv dOU, u32 xcd)
 {
     // one unit per lane, < 2^32 units per launch (see k_and_stream for why)
     const u32 OU = LU + RU;
-    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    const u32 bid = xcd ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u32 g = bid * 256u + threadIdx.x;
     if (g < total_units) {
         const u32 pair = csgn_fastdiv(g, dOU);
         const u32 r = g - pair * OU;
@@ -87,6 +88,7 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     const u64 OU = (t1 + t2) * U;
     const u64 pairs_per = (0xFFFFFF00ull / OU) ? (0xFFFFFF00ull / OU) : 1;       // units (= threads) per launch < 2^32
     const FastDiv d = csgn_fastdiv_make((u32)OU);
+    const u32 sxcd = stream_xcd(batch * OU);
     for (u64 p0 = 0; p0 < batch; p0 += pairs_per) {
         const u64 np = (batch - p0 < pairs_per) ? batch - p0 : pairs_per;
         const u32 tot = (u32)(np * OU);
@@ -95,11 +97,11 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
             k_add_flat<unit16, true><<<blocks, 256, 0, s>>>(
                 reinterpret_cast<const unit16 *>(L) + p0 * t1 * U,
                 reinterpret_cast<const unit16 *>(R) + p0 * t2 * U,
-                reinterpret_cast<unit16 *>(out) + p0 * OU, tot, (u32)(t1 * U), (u32)(t2 * U), d);
+                reinterpret_cast<unit16 *>(out) + p0 * OU, tot, (u32)(t1 * U), (u32)(t2 * U), d, sxcd);
         else
             k_add_flat<unit8, true><<<blocks, 256, 0, s>>>(L + p0 * t1 * U, R + p0 * t2 * U,
                                                            out + p0 * OU, tot, (u32)(t1 * U),
-                                                           (u32)(t2 * U), d);
+                                                           (u32)(t2 * U), d, sxcd);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;

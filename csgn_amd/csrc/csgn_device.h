@@ -121,6 +121,17 @@ inline int env_int(const char *name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Block order of the one-unit-per-lane stream kernels (1x1 multiply, uniform add): XCD-contiguous
+// once a launch is large (measured +3-5 % from 32 M units = 512 MB per stream up, -1-2 % at
+// 10 M units).  CSGN_STREAM_XCD = 0 / 1 forces it.
+inline u32 stream_xcd(u64 units)
+{
+    const int forced = env_int("CSGN_STREAM_XCD", -1);
+    if (forced == 0 || forced == 1)
+        return (u32)forced;
+    return units >= (1ull << 25) ? 1u : 0u;
+}
+
 // 4 KiB chunks per workgroup of the flat ragged kernels: as many as 8 (the workgroup's first search
 // is paid once per C chunks) while the grid still has >= 8192 workgroups to fill the chip with.
 // CSGN_RAGGED_C = 1, 2, 4, 8, 16 overrides.

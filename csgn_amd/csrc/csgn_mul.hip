@@ -17,9 +17,10 @@ namespace {
 template <typename Unit, bool NT>
 __global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
                                                     const Unit *__restrict__ b,
-                                                    Unit *__restrict__ o, u64 n_units)
+                                                    Unit *__restrict__ o, u64 n_units, u32 xcd)
 {
-    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u32 bid = xcd ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const u64 i = (u64)bid * 256u + threadIdx.x;
     if (i < n_units)
         unit_store<Unit, NT>(o + i, a[i] & b[i]);
 }
@@ -521,7 +522,8 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         const u64 per_launch = kMaxBlocks256 * 256u;
         for (u64 u0 = 0; u0 < total; u0 += per_launch) {
             const u64 nu = (total - u0 < per_launch) ? total - u0 : per_launch;
-            k_and_stream<Unit, true><<<ceil_div_u64(nu, 256u), 256, 0, s>>>(Lu + u0, Ru + u0, Ou + u0, nu);
+            k_and_stream<Unit, true><<<ceil_div_u64(nu, 256u), 256, 0, s>>>(Lu + u0, Ru + u0, Ou + u0, nu,
+                                                                            stream_xcd(nu));
             hipError_t e = hipGetLastError();
             if (e != hipSuccess)
                 return e;
