@@ -405,10 +405,17 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         /* how many of these waves a CU really holds: the runtime's answer, and LDS handed out in  \
            granules (measured: 7 x 23.3 KB is reported to fit 160 KB but the seventh wave runs after \
            the other six).  A wave beyond that number would start when the rest have finished. */   \
-        int per_cu = 0;                                                                             \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_permute_planes<LQ, PIPE, UW>, 64, \
-                                                         lds) != hipSuccess || per_cu < 1)          \
-            per_cu = 1;                                                                             \
+        static thread_local size_t asked_lds = 0;     /* the query is remembered per kernel and LDS size */ \
+        static thread_local int asked_per_cu = 0;                                                   \
+        if (asked_lds != lds) {                                                                     \
+            int q = 0;                                                                              \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_permute_planes<LQ, PIPE, UW>, 64, \
+                                                             lds) != hipSuccess || q < 1)           \
+                q = 1;                                                                              \
+            asked_per_cu = q;                                                                       \
+            asked_lds = lds;                                                                        \
+        }                                                                                           \
+        int per_cu = asked_per_cu;                                                                  \
         per_cu = std::max(1, std::min(per_cu, (int)(160 * 1024 / ((lds + 1023) / 1024 * 1024))));   \
         if (const int cap = env_int("CSGN_PERM_WAVES", 0))                                          \
             per_cu = std::min(per_cu, cap);                                                         \
