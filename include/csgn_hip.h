@@ -33,8 +33,9 @@
  *   - Every function returns CSGN_OK (0) or a negative csgn_status; csgn_last_error() gives
  *     a thread-local message.  The reference has no error convention at all;
  *     misuse that is UB there is a reported error here.
- *   - Thread safety: no hidden global state except the per-thread error string; one host
- *     thread (or process) per GPU may call concurrently.
+ *   - Thread safety: no hidden global state except per-thread items (the error string and the
+ *     ragged planner's small device scratch); one host thread (or process) per GPU may call
+ *     concurrently.
  *   - There is NO CPU fallback: without a gfx950 device every compute call fails with
  *     CSGN_ERR_NO_DEVICE.
  */
