@@ -68,6 +68,17 @@ SIGNATURES = {
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
     "csgn_synth_fill": (C.c_int, [u64, u64, u64, u64, vp, vp]),
     "csgn_digest": (C.c_int, [vp, u64, u64, vp, vp]),
+    "csgn_circuit_create": (C.c_int, [u64, u64, C.POINTER(vp)]),
+    "csgn_circuit_destroy": (None, [vp]),
+    "csgn_circuit_input": (C.c_int, [vp, u64, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_add": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_mul": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_decrypt": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_build": (C.c_int, [vp]),
+    "csgn_circuit_value": (vp, [vp, C.c_uint32]),
+    "csgn_circuit_value_terms": (u64, [vp, C.c_uint32]),
+    "csgn_circuit_bits": (vp, [vp, C.c_uint32]),
+    "csgn_circuit_run": (C.c_int, [vp, vp]),
     "csgn_mul_uniform_kernel": (C.c_char_p, [u64, u64, u64, u64]),
     "csgn_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
 }

@@ -153,4 +153,88 @@ Ciphertext CiphertextBatch::at(uint64_t i) const
     return c;
 }
 
+// ------------------------------------------------------------------ BatchCircuit
+
+BatchCircuit::BatchCircuit(const Context &context, uint64_t count) : handle(nullptr), ctx(context), count_(count)
+{
+    detail::ensureDevice();
+    detail::check(csgn_circuit_create(ctx.getN(), count, &handle), "csgn_circuit_create");
+}
+
+BatchCircuit::~BatchCircuit()
+{
+    if (handle) {
+        detail::syncDevice();           // a launch of the graph may still be running
+        csgn_circuit_destroy(handle);
+    }
+}
+
+unsigned BatchCircuit::input(uint64_t terms)
+{
+    uint32_t id = 0;
+    detail::check(csgn_circuit_input(handle, terms, &id), "csgn_circuit_input");
+    return id;
+}
+
+unsigned BatchCircuit::add(unsigned a, unsigned b)
+{
+    uint32_t id = 0;
+    detail::check(csgn_circuit_add(handle, a, b, &id), "csgn_circuit_add");
+    return id;
+}
+
+unsigned BatchCircuit::mul(unsigned a, unsigned b)
+{
+    uint32_t id = 0;
+    detail::check(csgn_circuit_mul(handle, a, b, &id), "csgn_circuit_mul");
+    return id;
+}
+
+unsigned BatchCircuit::decrypt(unsigned a, const SecretKey &key)
+{
+    key.ensureMask();
+    masks.push_back(key.device_mask);   // the graph holds the pointer: keep the block alive
+    uint32_t id = 0;
+    detail::check(csgn_circuit_decrypt(handle, a, key.device_mask->data(), &id), "csgn_circuit_decrypt");
+    return id;
+}
+
+void BatchCircuit::build() { detail::check(csgn_circuit_build(handle), "csgn_circuit_build"); }
+
+void BatchCircuit::set(unsigned input, const CiphertextBatch &batch)
+{
+    const uint64_t terms = csgn_circuit_value_terms(handle, input);
+    uint64_t *dst = csgn_circuit_value(handle, input);
+    if (!dst || batch.size() != count_ || batch.terms() != terms || batch.context().getN() != ctx.getN())
+        throw std::invalid_argument("certFHE::BatchCircuit::set: shape mismatch or circuit not built");
+    detail::check(csgn_memcpy_d2d(dst, batch.deviceValues(), (size_t)(count_ * terms * ctx.getDefaultN() * 8),
+                                  detail::stream()),
+                  "csgn_memcpy_d2d");
+}
+
+void BatchCircuit::run() { detail::check(csgn_circuit_run(handle, detail::stream()), "csgn_circuit_run"); }
+
+CiphertextBatch BatchCircuit::value(unsigned id) const
+{
+    const uint64_t terms = csgn_circuit_value_terms(handle, id);
+    const uint64_t *src = csgn_circuit_value(handle, id);
+    if (!src || terms == 0)
+        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value or circuit not built");
+    CiphertextBatch out(ctx, count_, terms);
+    detail::check(csgn_memcpy_d2d(out.payload->ptr, src, (size_t)(count_ * terms * ctx.getDefaultN() * 8),
+                                  detail::stream()),
+                  "csgn_memcpy_d2d");
+    return out;
+}
+
+std::vector<unsigned char> BatchCircuit::bits(unsigned bits_id) const
+{
+    const uint8_t *src = csgn_circuit_bits(handle, bits_id);
+    if (!src)
+        throw std::invalid_argument("certFHE::BatchCircuit::bits: no such result or circuit not built");
+    std::vector<unsigned char> out(count_, 0);
+    detail::downloadBytes(out.data(), src, count_);
+    return out;
+}
+
 } // namespace certFHE

@@ -5,6 +5,7 @@
 #include "csgn_kernels.h"
 
 #include <cstdarg>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 
@@ -555,6 +556,174 @@ int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
 const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2)
 {
     return csgn::mul_uniform_kernel_name(n_bits, pairs, t1, t2);
+}
+
+/* ---------------------------------------------------------------- circuits ---- */
+/* A fixed add/multiply/decrypt circuit over uniform batches, all values in one HBM block, the
+ * launches captured once into a hipGraph: a launch-bound circuit (BASELINE config 5: 24
+ * operations of a few microseconds each) is replayed with one hipGraphLaunch. */
+struct csgn_circuit {
+    struct Value {
+        uint64_t terms;
+        size_t offset;        // bytes into block
+    };
+    struct Op {
+        int kind;             // 0 add, 1 mul, 2 decrypt
+        uint32_t a, b, out;
+        const uint64_t *mask;
+        size_t scratch, bits; // byte offsets (decrypt)
+    };
+    uint64_t n_bits = 0, batch = 0;
+    std::vector<Value> values;
+    std::vector<Op> ops;
+    std::vector<size_t> bits_offsets;
+    size_t bytes = 0;
+    void *block = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+size_t circuit_reserve(csgn_circuit *c, size_t n)
+{
+    const size_t at = (c->bytes + 255) & ~(size_t)255;
+    c->bytes = at + n;
+    return at;
+}
+}
+
+int csgn_circuit_create(uint64_t n_bits, uint64_t batch, csgn_circuit **circuit)
+{
+    REQUIRE(circuit, "circuit is null");
+    *circuit = nullptr;
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(batch > 0, "batch must be > 0");
+    csgn_circuit *c = new csgn_circuit();
+    c->n_bits = n_bits;
+    c->batch = batch;
+    *circuit = c;
+    return CSGN_OK;
+}
+
+void csgn_circuit_destroy(csgn_circuit *c)
+{
+    if (!c)
+        return;
+    if (c->exec)
+        (void)hipGraphExecDestroy(c->exec);
+    if (c->graph)
+        (void)hipGraphDestroy(c->graph);
+    if (c->block)
+        (void)hipFree(c->block);
+    delete c;
+}
+
+int csgn_circuit_input(csgn_circuit *c, uint64_t terms, uint32_t *value)
+{
+    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
+    REQUIRE(terms > 0, "an input needs at least one term");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
+    *value = (uint32_t)(c->values.size() - 1);
+    return CSGN_OK;
+}
+
+static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uint32_t *value)
+{
+    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
+    REQUIRE(a < c->values.size() && b < c->values.size(), "operand value does not exist");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    const uint64_t ta = c->values[a].terms, tb = c->values[b].terms;
+    const uint64_t terms = kind ? ta * tb : ta + tb;
+    if (kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || ta * tb * dl >= (1ull << 32)))
+        return fail(CSGN_ERR_UNSUPPORTED, "product of %llu x %llu terms exceeds 2^32 words",
+                    (unsigned long long)ta, (unsigned long long)tb);
+    if (!kind && terms * dl >= (1ull << 31))
+        return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu terms exceeds 2^31 words", (unsigned long long)terms);
+    c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
+    const uint32_t out = (uint32_t)(c->values.size() - 1);
+    c->ops.push_back({kind, a, b, out, nullptr, 0, 0});
+    *value = out;
+    return CSGN_OK;
+}
+
+int csgn_circuit_add(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 0, a, b, value); }
+int csgn_circuit_mul(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 1, a, b, value); }
+
+int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id)
+{
+    REQUIRE(c && bits_id && d_mask && !c->exec, "null argument, or the circuit is already built");
+    REQUIRE(a < c->values.size(), "operand value does not exist");
+    const size_t scratch = circuit_reserve(c, csgn::decrypt_scratch_bytes(c->batch, c->batch * c->values[a].terms));
+    const size_t bits = circuit_reserve(c, (size_t)c->batch);
+    c->ops.push_back({2, a, 0, 0, d_mask, scratch, bits});
+    c->bits_offsets.push_back(bits);
+    *bits_id = (uint32_t)(c->bits_offsets.size() - 1);
+    return CSGN_OK;
+}
+
+int csgn_circuit_build(csgn_circuit *c)
+{
+    REQUIRE(c && !c->exec, "null circuit, or already built");
+    REQUIRE(!c->ops.empty(), "the circuit has no operations");
+    HIP_TRY(hipMalloc(&c->block, c->bytes ? c->bytes : 256));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    unsigned char *base = static_cast<unsigned char *>(c->block);
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
+        const csgn_circuit::Op &op = c->ops[i];
+        const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);
+        if (op.kind == 2) {
+            const uint64_t t = c->values[op.a].terms;
+            e = csgn::decrypt(c->n_bits, c->batch, t, c->batch * t, (const u64 *)A, nullptr, (const u64 *)op.mask,
+                              base + op.bits, base + op.scratch, s);
+        } else {
+            const uint64_t *B = reinterpret_cast<const uint64_t *>(base + c->values[op.b].offset);
+            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
+            const uint64_t ta = c->values[op.a].terms, tb = c->values[op.b].terms;
+            e = op.kind ? csgn::mul_uniform(c->n_bits, c->batch, ta, tb, (const u64 *)A, (const u64 *)B, (u64 *)O, 0, s)
+                        : csgn::add_uniform(c->n_bits, c->batch, ta, tb, (const u64 *)A, (const u64 *)B, (u64 *)O, s);
+        }
+    }
+    hipGraph_t g = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s, &g);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (g)
+            (void)hipGraphDestroy(g);
+        return hip_fail(e != hipSuccess ? e : e2, "csgn_circuit_build (stream capture)");
+    }
+    c->graph = g;
+    HIP_TRY(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
+    return CSGN_OK;
+}
+
+uint64_t *csgn_circuit_value(csgn_circuit *c, uint32_t value)
+{
+    if (!c || !c->block || value >= c->values.size())
+        return nullptr;
+    return reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(c->block) + c->values[value].offset);
+}
+
+uint64_t csgn_circuit_value_terms(csgn_circuit *c, uint32_t value)
+{
+    return (c && value < c->values.size()) ? c->values[value].terms : 0;
+}
+
+uint8_t *csgn_circuit_bits(csgn_circuit *c, uint32_t bits_id)
+{
+    if (!c || !c->block || bits_id >= c->bits_offsets.size())
+        return nullptr;
+    return static_cast<unsigned char *>(c->block) + c->bits_offsets[bits_id];
+}
+
+int csgn_circuit_run(csgn_circuit *c, void *stream)
+{
+    REQUIRE(c && c->exec, "the circuit is not built");
+    HIP_TRY(hipGraphLaunch(c->exec, S(stream)));
+    return CSGN_OK;
 }
 
 /* debug hook used by the CPU tests to pin the division-by-invariant helper */

@@ -35,6 +35,7 @@ class SecretKey {
     void invalidateMask();
     void ensureMask() const;
     friend class CiphertextBatch;      // extension (Batch.h): reads the device-resident key mask
+    friend class BatchCircuit;         // extension (Batch.h)
 
   public:
     SecretKey() = delete;

@@ -251,6 +251,32 @@ int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_
 int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
                 uint64_t *d_digest, void *stream);
 
+/* ------------------------------------------------------------------ circuits ---- */
+
+/* A fixed circuit of adds, multiplies and decrypts over uniform batches of `batch` ciphertexts
+ * (the "circuit runner" of SURVEY 8f-2): every value lives in one HBM block owned by the
+ * circuit, and csgn_circuit_build captures all launches into a hipGraph, so a launch-bound
+ * circuit (BASELINE config 5: 24 operations of a few microseconds each on single ciphertexts)
+ * replays with one graph launch.  Values are numbered from 0 in creation order.  Usage:
+ * create; input()*; add()/mul()/decrypt()*; build(); then, per evaluation, write the inputs to
+ * csgn_circuit_value(c, id) (batch*terms*dL words each, e.g. csgn_memcpy_d2d or an encrypt
+ * kernel writing there directly), csgn_circuit_run, and read results / csgn_circuit_bits after
+ * synchronising the stream.  Results are the same words the one-by-one calls produce. */
+typedef struct csgn_circuit csgn_circuit;
+int csgn_circuit_create(uint64_t n_bits, uint64_t batch, csgn_circuit **circuit);
+void csgn_circuit_destroy(csgn_circuit *circuit);
+int csgn_circuit_input(csgn_circuit *circuit, uint64_t terms, uint32_t *value);
+int csgn_circuit_add(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *value);   /* a + b: concatenation */
+int csgn_circuit_mul(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *value);   /* a * b: all-pairs AND */
+/* Decrypt value `a` under the key whose dL-word mask is d_mask (must stay valid); *bits_id
+ * names a `batch`-byte result buffer. */
+int csgn_circuit_decrypt(csgn_circuit *circuit, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id);
+int csgn_circuit_build(csgn_circuit *circuit);
+uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
+uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);
+uint8_t *csgn_circuit_bits(csgn_circuit *circuit, uint32_t bits_id);          /* device pointer */
+int csgn_circuit_run(csgn_circuit *circuit, void *stream);
+
 /* Name of the kernel(s) csgn_mul_uniform dispatches ONE launch of `pairs` pairs of this shape to
  * ("k_and_stream", "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"; pairs = min(batch,
  * out_slots) of the call); a static string, no GPU needed.  Lets a profiler-driven harness

@@ -467,6 +467,72 @@ static int cmd_batch(int count)
     return 0;
 }
 
+static int cmd_graph(int count)
+{
+    // BatchCircuit (extension): BASELINE config 5 captured once into a hipGraph and replayed on
+    // three different input sets; every replay must equal the same circuit done operation by
+    // operation on CiphertextBatch (words) and the circuit in the clear (bits).
+    Library::initializeLibrary();
+    Context ctx(4096, 32);
+    SecretKey sk(ctx);
+    const int levels = 16, inputs = 1 + levels / 2 + 2 * (levels / 2);
+    BatchCircuit c(ctx, (uint64_t)count);
+    std::vector<unsigned> in;
+    for (int i = 0; i < inputs; ++i)
+        in.push_back(c.input(1));
+    unsigned x = in[0];
+    int k = 1;
+    for (int level = 1; level <= levels; ++level) {
+        if (level % 2) {
+            x = c.add(x, in[k]);
+            k += 1;
+        } else {
+            x = c.mul(x, c.add(in[k], in[k + 1]));
+            k += 2;
+        }
+    }
+    const unsigned res = c.decrypt(x, sk);
+    c.build();
+    for (int round = 0; round < 3; ++round) {
+        std::vector<std::vector<unsigned char> > bits(inputs, std::vector<unsigned char>(count));
+        std::vector<CiphertextBatch> fresh;
+        for (int i = 0; i < inputs; ++i) {
+            for (int j = 0; j < count; ++j)
+                bits[i][j] = (unsigned char)(((j + 3 * round) * 2654435761u + i * 40503u) >> 11 & 1);
+            fresh.push_back(CiphertextBatch::encrypt(sk, bits[i], 7000 + 100 * round + i));
+            c.set(in[i], fresh.back());
+        }
+        c.run();
+        CiphertextBatch y = fresh[0];
+        std::vector<unsigned char> yb = bits[0];
+        k = 1;
+        for (int level = 1; level <= levels; ++level) {
+            if (level % 2) {
+                y = y + fresh[k];
+                for (int j = 0; j < count; ++j)
+                    yb[j] ^= bits[k][j];
+                k += 1;
+            } else {
+                y = y * (fresh[k] + fresh[k + 1]);
+                for (int j = 0; j < count; ++j)
+                    yb[j] &= (unsigned char)(bits[k][j] ^ bits[k + 1][j]);
+                k += 2;
+            }
+        }
+        EXPECT(c.bits(res) == yb);
+        CiphertextBatch g = c.value(x);
+        EXPECT(g.terms() == 766 && g.terms() == y.terms());
+        for (int j = 0; j < count; j += (count > 4 ? count / 4 : 1)) {
+            Ciphertext a = g.at(j), b = y.at(j);
+            EXPECT(a.getLen() == b.getLen());
+            for (uint64_t w = 0; w < a.getLen(); ++w)
+                EXPECT(a.getValues()[w] == b.getValues()[w]);
+        }
+    }
+    printf("graph ok count=%d\n", count);
+    return 0;
+}
+
 static int cmd_latency(int iters)
 {
     // steady-state cost of single operations through the value-semantic class API
@@ -531,6 +597,8 @@ int main(int argc, char **argv)
             return cmd_wire(argc, argv);
         if (cmd == "batch")
             return cmd_batch(argc > 2 ? atoi(argv[2]) : 4096);
+        if (cmd == "graph")
+            return cmd_graph(argc > 2 ? atoi(argv[2]) : 5);
         if (cmd == "latency")
             return cmd_latency(argc > 2 ? atoi(argv[2]) : 2000);
         return 64;

@@ -120,6 +120,16 @@ def test_fails_loudly_without_gpu(lib):
     buf = np.zeros(64, dtype=np.uint64)
     rc = lib.csgn_mul_uniform(1247, 1, 1, 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, 0, None)
     assert rc < 0, "compute call must not succeed without a GPU"
+    # a circuit can be described on the host, but building it (allocation + graph capture) cannot succeed
+    c = C.c_void_p()
+    assert lib.csgn_circuit_create(1247, 4, C.byref(c)) == 0
+    a, b, r = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert lib.csgn_circuit_input(c, 1, C.byref(a)) == 0 and lib.csgn_circuit_input(c, 2, C.byref(b)) == 0
+    assert lib.csgn_circuit_mul(c, a, b, C.byref(r)) == 0 and lib.csgn_circuit_value_terms(c, r) == 2
+    assert lib.csgn_circuit_add(c, r, 17, C.byref(r)) == -1         # no such value
+    assert lib.csgn_circuit_build(c) < 0
+    assert lib.csgn_circuit_run(c, None) == -1
+    lib.csgn_circuit_destroy(c)
 
 
 def test_integration_md_binding_stub_compiles(tmp_path):

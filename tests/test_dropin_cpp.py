@@ -172,6 +172,14 @@ def test_batch_extension(driver):
     assert "batch ok count=7" in run(driver, "batch", 7).stdout
 
 
+@pytest.mark.gpu
+def test_batch_circuit_graph_extension(driver):
+    """certFHE::BatchCircuit: BASELINE config 5 captured into a hipGraph, replayed on three input
+    sets, against the same circuit done operation by operation and in the clear."""
+    assert "graph ok count=1" in run(driver, "graph", 1).stdout
+    assert "graph ok count=37" in run(driver, "graph", 37).stdout
+
+
 def test_libcertfhe_exports_the_reference_class_surface(driver):
     """libcertFHE.so defines every public member of the reference's classes that user code can
     call (src/Ciphertext.h:65-143, src/SecretKey.h:67-143, src/Context.h:28-69,

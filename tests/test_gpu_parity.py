@@ -1109,6 +1109,79 @@ def test_ragged_skewed_batches(hip, oracle, monkeypatch, n, d, force_flat):
         assert np.array_equal(sout[int(soff[b]) * dl:int(soff[b + 1]) * dl], want_s), b
 
 
+@pytest.mark.parametrize("n,d,batch", [(1247, 16, 1), (4096, 32, 5), (65, 4, 300)])
+def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, batch):
+    """csgn_circuit_*: a depth-9 add/multiply circuit with two decrypts, captured into a hipGraph and
+    run twice on different inputs, against the one-by-one C-ABI calls (every word, every bit) and
+    the oracle (element 0); plus the argument checks."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import CsgnError, check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 77)
+    dmask = hip.upload(hip.key_mask(n, key))
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    ins = [new(lib.csgn_circuit_input, 1) for _ in range(14)]
+    x, k, mid = ins[0], 1, None
+    for level in range(1, 10):
+        if level % 2:
+            x = new(lib.csgn_circuit_add, x, ins[k]); k += 1
+        else:
+            x = new(lib.csgn_circuit_mul, x, new(lib.csgn_circuit_add, ins[k], ins[k + 1])); k += 2
+        if level == 4:
+            mid = x
+    b_mid = new(lib.csgn_circuit_decrypt, mid, dmask.data_ptr())
+    b_end = new(lib.csgn_circuit_decrypt, x, dmask.data_ptr())
+    with pytest.raises(CsgnError):
+        new(lib.csgn_circuit_add, x, 999)                       # no such value
+    assert lib.csgn_circuit_value(c, x) is None                 # nothing allocated before build
+    with pytest.raises(CsgnError):
+        check(lib.csgn_circuit_run(c, hip.stream))              # not built
+    check(lib.csgn_circuit_build(c))
+    with pytest.raises(CsgnError):
+        new(lib.csgn_circuit_input, 1)                          # frozen after build
+    for rnd in range(2):
+        plain = np.random.default_rng(10 * rnd + batch).integers(0, 2, size=(14, batch)).astype(np.uint8)
+        fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), hip.upload(key), dmask, seed=rnd + 5)
+        inp = lambda i: fresh[i * batch * dl:(i + 1) * batch * dl]
+        for i in range(14):
+            check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, ins[i]), inp(i).data_ptr(), batch * dl * 8, hip.stream))
+        check(lib.csgn_circuit_run(c, hip.stream))
+        # the same circuit, one call at a time
+        y, yt, yb, k, y_mid, h = inp(0), 1, plain[0].copy(), 1, None, hip.download(inp(0))[:dl]
+        for level in range(1, 10):
+            if level % 2:
+                y = hip.add_uniform(n, batch, yt, 1, y, inp(k)); yt += 1; yb ^= plain[k]
+                h, _ = oracle.add(h, hip.download(inp(k))[:dl]); k += 1
+            else:
+                r = hip.add_uniform(n, batch, 1, 1, inp(k), inp(k + 1))
+                y = hip.mul_uniform(n, batch, yt, 2, y, r); yt *= 2; yb &= plain[k] ^ plain[k + 1]
+                hr, _ = oracle.add(hip.download(inp(k))[:dl], hip.download(inp(k + 1))[:dl])
+                h, _ = oracle.mul(n, h, hr); k += 2
+            if level == 4:
+                y_mid, yb_mid = y, yb.copy()
+        terms = int(lib.csgn_circuit_value_terms(c, x))
+        assert terms == yt == 47
+        got = hip.empty_words(batch * terms * dl)
+        check(lib.csgn_memcpy_d2d(got.data_ptr(), lib.csgn_circuit_value(c, x), batch * terms * dl * 8, hip.stream))
+        assert torch.equal(got, y[:batch * terms * dl])
+        assert np.array_equal(hip.download(got)[:terms * dl], h)
+        for bid, want in ((b_mid, yb_mid), (b_end, yb)):
+            gb = torch.empty(batch, dtype=torch.uint8, device=got.device)
+            check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+            if d > 1:
+                assert np.array_equal(hip.download(gb), want)
+        assert np.array_equal(hip.download(hip.decrypt_uniform(n, batch, yt, y, dmask)),
+                              hip.download(gb))
+    lib.csgn_circuit_destroy(c)
+
+
 def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
     """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
     ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
