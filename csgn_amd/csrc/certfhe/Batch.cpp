@@ -190,6 +190,24 @@ unsigned BatchCircuit::mul(unsigned a, unsigned b)
     return id;
 }
 
+unsigned BatchCircuit::permute(unsigned a, const Permutation &p)
+{
+    const uint64_t n = ctx.getN();
+    if (p.getLength() < n)
+        throw std::invalid_argument("certFHE::BatchCircuit::permute: permutation shorter than N");
+    // the kernel wants N uint32 entries: two per uploaded word
+    std::vector<uint64_t> packed((n + 1) / 2, 0);
+    const uint64_t *src = p.getPermutation();
+    for (uint64_t i = 0; i < n; ++i)
+        packed[i / 2] |= (uint64_t)(uint32_t)src[i] << (32 * (i % 2));
+    std::shared_ptr<DevicePayload> d = detail::uploadWords(packed.data(), packed.size());
+    masks.push_back(d);
+    uint32_t id = 0;
+    detail::check(csgn_circuit_permute(handle, a, reinterpret_cast<const uint32_t *>(d->data()), &id),
+                  "csgn_circuit_permute");
+    return id;
+}
+
 unsigned BatchCircuit::decrypt(unsigned a, const SecretKey &key)
 {
     key.ensureMask();

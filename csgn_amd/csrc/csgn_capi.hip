@@ -568,9 +568,9 @@ struct csgn_circuit {
         size_t offset;        // bytes into block
     };
     struct Op {
-        int kind;             // 0 add, 1 mul, 2 decrypt
+        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute
         uint32_t a, b, out;
-        const uint64_t *mask;
+        const void *mask;     // decrypt: key mask (u64 words); permute: permutation (u32 entries)
         size_t scratch, bits; // byte offsets (decrypt)
     };
     uint64_t n_bits = 0, batch = 0;
@@ -663,6 +663,19 @@ int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, ui
     return CSGN_OK;
 }
 
+int csgn_circuit_permute(csgn_circuit *c, uint32_t a, const uint32_t *d_perm, uint32_t *value)
+{
+    REQUIRE(c && value && d_perm && !c->exec, "null argument, or the circuit is already built");
+    REQUIRE(a < c->values.size(), "operand value does not exist");
+    // reference semantics (src/Ciphertext.cpp:7-82): the result is ONE term, the permuted first term
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    c->values.push_back({1, circuit_reserve(c, (size_t)(c->batch * dl * 8))});
+    const uint32_t out = (uint32_t)(c->values.size() - 1);
+    c->ops.push_back({3, a, 0, out, d_perm, 0, 0});
+    *value = out;
+    return CSGN_OK;
+}
+
 int csgn_circuit_build(csgn_circuit *c)
 {
     REQUIRE(c && !c->exec, "null circuit, or already built");
@@ -679,6 +692,10 @@ int csgn_circuit_build(csgn_circuit *c)
             const uint64_t t = c->values[op.a].terms;
             e = csgn::decrypt(c->n_bits, c->batch, t, c->batch * t, (const u64 *)A, nullptr, (const u64 *)op.mask,
                               base + op.bits, base + op.scratch, s);
+        } else if (op.kind == 3) {
+            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
+            e = csgn::permute(c->n_bits, c->batch, c->values[op.a].terms, false, (const u64 *)A,
+                              (const u32 *)op.mask, (u64 *)O, s);
         } else {
             const uint64_t *B = reinterpret_cast<const uint64_t *>(base + c->values[op.b].offset);
             uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);

@@ -14,6 +14,7 @@
 
 #include "Ciphertext.h"
 #include "Context.h"
+#include "Permutation.h"
 #include "SecretKey.h"
 
 struct csgn_circuit;   // include/csgn_hip.h (opaque)
@@ -72,7 +73,7 @@ class BatchCircuit {
     ::csgn_circuit *handle;
     Context ctx;
     uint64_t count_;
-    std::vector<std::shared_ptr<detail::DevicePayload> > masks;   // key masks the graph refers to
+    std::vector<std::shared_ptr<detail::DevicePayload> > masks;   // key masks / permutations the graph refers to
     BatchCircuit(const BatchCircuit &);
     BatchCircuit &operator=(const BatchCircuit &);
 
@@ -82,6 +83,7 @@ class BatchCircuit {
     unsigned input(uint64_t terms = 1);
     unsigned add(unsigned a, unsigned b);
     unsigned mul(unsigned a, unsigned b);
+    unsigned permute(unsigned a, const Permutation &p);   // applyPermutation: ONE term, the permuted first term
     unsigned decrypt(unsigned a, const SecretKey &key);   // returns the id for bits()
     void build();
     void set(unsigned input, const CiphertextBatch &batch);   // copies the batch into the input's buffer

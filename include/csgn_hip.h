@@ -271,6 +271,9 @@ int csgn_circuit_mul(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *va
 /* Decrypt value `a` under the key whose dL-word mask is d_mask (must stay valid); *bits_id
  * names a `batch`-byte result buffer. */
 int csgn_circuit_decrypt(csgn_circuit *circuit, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id);
+/* Ciphertext::applyPermutation on every element of value `a` (d_perm: N uint32 entries, must stay
+ * valid): as in the reference the result is ONE term, the permuted first term. */
+int csgn_circuit_permute(csgn_circuit *circuit, uint32_t a, const uint32_t *d_perm, uint32_t *value);
 int csgn_circuit_build(csgn_circuit *circuit);
 uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
 uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);

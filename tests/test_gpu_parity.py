@@ -1182,6 +1182,67 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("batch", [1, 3, 200])
+def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
+    """BASELINE config 5 as ONE hipGraph: Context(4096,32), a random Permutation applied to every
+    fresh input inside the graph, the depth-16 add/multiply circuit (766 terms), decrypt under the
+    permuted key.  Bits equal the circuit in the clear; words of element 0 equal the oracle's."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    n, d, levels = 4096, 32, 16
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 21)
+    perm = np.random.default_rng(22).permutation(n).astype(np.uint64)
+    pkey = oracle.permute_key(n, perm, key)
+    dmask, dpmask = hip.upload(hip.key_mask(n, key)), hip.upload(hip.key_mask(n, pkey))
+    dperm = hip.upload(perm.astype(np.uint32))
+    nin = 1 + levels // 2 + 2 * (levels // 2)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    raw = [new(lib.csgn_circuit_input, 1) for _ in range(nin)]
+    ins = [new(lib.csgn_circuit_permute, r, dperm.data_ptr()) for r in raw]
+    x, k = ins[0], 1
+    for level in range(1, levels + 1):
+        if level % 2:
+            x = new(lib.csgn_circuit_add, x, ins[k]); k += 1
+        else:
+            x = new(lib.csgn_circuit_mul, x, new(lib.csgn_circuit_add, ins[k], ins[k + 1])); k += 2
+    bid = new(lib.csgn_circuit_decrypt, x, dpmask.data_ptr())
+    check(lib.csgn_circuit_build(c))
+    plain = np.random.default_rng(batch).integers(0, 2, size=(nin, batch)).astype(np.uint8)
+    fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), hip.upload(key), dmask, seed=9)
+    for i in range(nin):
+        check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, raw[i]), fresh[i * batch * dl:].data_ptr(),
+                                  batch * dl * 8, hip.stream))
+    check(lib.csgn_circuit_run(c, hip.stream))
+    xb, k = plain[0].copy(), 1
+    hf = hip.download(fresh).reshape(nin, batch, dl)
+    h = oracle.permute_ciphertext(n, perm, hf[0, 0])
+    for level in range(1, levels + 1):
+        if level % 2:
+            xb ^= plain[k]
+            h, _ = oracle.add(h, oracle.permute_ciphertext(n, perm, hf[k, 0])); k += 1
+        else:
+            xb &= plain[k] ^ plain[k + 1]
+            r, _ = oracle.add(oracle.permute_ciphertext(n, perm, hf[k, 0]), oracle.permute_ciphertext(n, perm, hf[k + 1, 0]))
+            h, _ = oracle.mul(n, h, r); k += 2
+    assert int(lib.csgn_circuit_value_terms(c, x)) == 766
+    gb = torch.empty(batch, dtype=torch.uint8, device=fresh.device)
+    check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+    assert np.array_equal(hip.download(gb), xb)
+    got = hip.empty_words(766 * dl)
+    check(lib.csgn_memcpy_d2d(got.data_ptr(), lib.csgn_circuit_value(c, x), 766 * dl * 8, hip.stream))
+    assert np.array_equal(hip.download(got), h)
+    assert oracle.decrypt_canonical(n, pkey, h) == xb[0]
+    lib.csgn_circuit_destroy(c)
+
+
 def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
     """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
     ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
