@@ -251,7 +251,7 @@ def main():
     # the kernel(s) the library dispatches this shape to ("k_touch+k_mul_flat": the operand touch
     # pass is inside the timed launch and charged to it)
     pairs_per_launch = batch / launches_per_step
-    kernel_name = hip.lib.csgn_mul_uniform_kernel(N_BITS, int(pairs_per_launch), T, T).decode()
+    kernel_name = hip.lib.csgn_mul_uniform_kernel(N_BITS, batch, T, T).decode()
     achieved = pairs_per_launch * bytes_per_mul / avg_launch_s
 
     # ---- validity: the arena still holds the last `slots` products; check sampled ones ----

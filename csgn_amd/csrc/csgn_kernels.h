@@ -19,7 +19,7 @@ struct MulTuning {
     int xcd;    // CSGN_MUL_XCD: XCD-contiguous block order: 0 off, 1 flat kernel only (default), 2 both kernels
 };
 MulTuning mul_tuning();
-// name of the kernel(s) mul_uniform dispatches one launch of `pairs` pairs of this shape to
+// name of the kernel(s) a mul_uniform call of `pairs` pairs of this shape dispatches to
 // (16-byte aligned buffers assumed)
 const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2);
 

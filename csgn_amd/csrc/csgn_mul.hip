@@ -506,8 +506,8 @@ __global__ void __launch_bounds__(256) k_touch(const u32 *__restrict__ p, u64 li
 
 // One uniform chunk (pairs are contiguous in L, R and out).
 template <typename Unit>
-hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, const u64 *R, u64 *out,
-                             hipStream_t s)
+hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, const u64 *L, const u64 *R,
+                             u64 *out, hipStream_t s)
 {
     const Unit *Lu = reinterpret_cast<const Unit *>(L);
     const Unit *Ru = reinterpret_cast<const Unit *>(R);
@@ -530,7 +530,8 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u32 t1, u32 t2, const u64 *L, con
         }
         return hipSuccess;
     }
-    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2, pairs);
+    // the kernel choice looks at the whole call (a batch streamed through a small arena is still a stream)
+    const MulPlan plan = mul_plan(sizeof(Unit), U, t1, t2, call_pairs);
     if (plan.flat) {
         const int mf = plan.flat;
         // left-term prefetch from inside the kernel (only without the touch pass, only when a row
@@ -648,8 +649,8 @@ hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
         const u64 np = (batch - p0 < slots) ? batch - p0 : slots;
         const u64 *Lc = L + p0 * t1 * dL;
         const u64 *Rc = R + p0 * t2 * dL;
-        hipError_t e = wide ? mul_uniform_chunk<unit16>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s)
-                            : mul_uniform_chunk<unit8>(U, np, (u32)t1, (u32)t2, Lc, Rc, out, s);
+        hipError_t e = wide ? mul_uniform_chunk<unit16>(U, np, batch, (u32)t1, (u32)t2, Lc, Rc, out, s)
+                            : mul_uniform_chunk<unit8>(U, np, batch, (u32)t1, (u32)t2, Lc, Rc, out, s);
         if (e != hipSuccess)
             return e;
     }

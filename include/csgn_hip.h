@@ -116,7 +116,7 @@ int csgn_key_mask(uint64_t n_bits, const uint64_t *h_key, uint64_t d, uint64_t *
  * per pair.  With out_slots < batch the call is split into launches of <= out_slots pairs
  * in stream order so later pairs overwrite earlier ones deterministically.
  * Limits: dL*8 <= 16384 bytes per term; t1*t2*dL < 2^32 per pair.
- * The kernel is chosen per shape (csgn_mul_uniform_kernel names it): launches of >= 4 MB of
+ * The kernel is chosen per shape (csgn_mul_uniform_kernel names it): calls with >= 4 MB of
  * operands whose output is >= 4x the operands are preceded by a read-only pass over the
  * operands that leaves them in the GPU's memory-side cache, so the operands are READ twice;
  * nothing but d_out is written. */
@@ -280,10 +280,10 @@ uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);
 uint8_t *csgn_circuit_bits(csgn_circuit *circuit, uint32_t bits_id);          /* device pointer */
 int csgn_circuit_run(csgn_circuit *circuit, void *stream);
 
-/* Name of the kernel(s) csgn_mul_uniform dispatches ONE launch of `pairs` pairs of this shape to
- * ("k_and_stream", "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"; pairs = min(batch,
- * out_slots) of the call); a static string, no GPU needed.  Lets a profiler-driven harness
- * (bench.py) label its roofline with the kernel that really runs. */
+/* Name of the kernel(s) a csgn_mul_uniform call of `pairs` pairs (its `batch` argument) of this
+ * shape dispatches to ("k_and_stream", "k_mul_tiled", "k_mul_flat", "k_touch+k_mul_flat"); a
+ * static string, no GPU needed.  Lets a profiler-driven harness (bench.py) label its roofline
+ * with the kernel that really runs. */
 const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2);
 
 /* Debug hook: quotient n/d computed by the same division-by-invariant helper the kernels
