@@ -680,6 +680,10 @@ int csgn_circuit_build(csgn_circuit *c)
 {
     REQUIRE(c && !c->exec, "null circuit, or already built");
     REQUIRE(!c->ops.empty(), "the circuit has no operations");
+    if (c->block) {                     // an earlier build attempt failed after the allocation
+        (void)hipFree(c->block);
+        c->block = nullptr;
+    }
     HIP_TRY(hipMalloc(&c->block, c->bytes ? c->bytes : 256));
     hipStream_t s = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
