@@ -504,6 +504,34 @@ __global__ void __launch_bounds__(256) k_touch(const u32 *__restrict__ p, u64 li
     }
 }
 
+// The same for a slice of a ragged launch: the operands of the pairs that own output terms
+// [term_lo, term_hi) are looked up on the device (the host never sees the offsets) and touched,
+// unless they are too large a share of the slice's traffic (> 1/4 of its output) or more than the
+// memory-side cache will keep (96 MB).
+__global__ void __launch_bounds__(256) k_touch_ragged(const u32 *__restrict__ L, const u64 *__restrict__ offL,
+                                                      const u32 *__restrict__ R, const u64 *__restrict__ offR,
+                                                      const u64 *__restrict__ offOut, u32 batch, u64 term_lo,
+                                                      u64 term_hi, u64 term_bytes)
+{
+    const u32 p_lo = csr_find(offOut, 0u, batch, term_lo);          // uniform searches: loads broadcast
+    const u32 p_hi = csr_find(offOut, 0u, batch, term_hi - 1);
+    const u64 lb = offL[p_lo] * term_bytes, le = offL[p_hi + 1] * term_bytes;
+    const u64 rb = offR[p_lo] * term_bytes, re = offR[p_hi + 1] * term_bytes;
+    const u64 op = (le - lb) + (re - rb);
+    if (op > (96ull << 20) || op * 4 > (term_hi - term_lo) * term_bytes)
+        return;
+    const u64 stride = (u64)gridDim.x * 256u * 128u;
+    const u64 first = ((u64)blockIdx.x * 256u + threadIdx.x) * 128u;
+    for (u64 a = lb + first; a < le; a += stride) {
+        const u32 v = L[a >> 2];
+        asm volatile("" ::"v"(v));
+    }
+    for (u64 a = rb + first; a < re; a += stride) {
+        const u32 v = R[a >> 2];
+        asm volatile("" ::"v"(v));
+    }
+}
+
 // One uniform chunk (pairs are contiguous in L, R and out).
 template <typename Unit>
 hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, const u64 *L, const u64 *R,
@@ -710,10 +738,18 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const FastDiv dU = csgn_fastdiv_make(U);
     const int chunks = ragged_chunks(total_units);
     const u32 pf_pairs = (u32)env_int("CSGN_RAGGED_PF", 32);    // operand prefetch distance in pairs, 0 = off
-    const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
+    // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
+    // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
+    // an HBM miss under full write load, as in the uniform path.  CSGN_RAGGED_TOUCH=0 turns it off.
+    const bool touch = wide && total_units > (1ull << 26) && env_int("CSGN_RAGGED_TOUCH", 1) != 0;
+    const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
     for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
         const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
         const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+        if (touch)
+            k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
+                                               reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
+                                               u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
         if (wide)                                                                                   \

@@ -6,7 +6,7 @@ import numpy as np, torch
 from csgn_amd.batch import HipPath, check
 CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
-VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no prefetch',{'CSGN_RAGGED_PF':'0'}),('cold, C=1',{'CSGN_RAGGED_C':'1'}),('cold + pretouch',{'PRETOUCH':'1'})]
+VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no slice touch',{'CSGN_RAGGED_TOUCH':'0'}),('cold, no touch, no prefetch',{'CSGN_RAGGED_TOUCH':'0','CSGN_RAGGED_PF':'0'}),('same, no touch',{'NSETS':'1','CSGN_RAGGED_TOUCH':'0'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
@@ -38,7 +38,7 @@ for name,t1s,t2s in [
     sets=[(L,R)]+[(hip.synth_fill(10+k,n,0,int(offL[-1])*dl), hip.synth_fill(20+k,n,0,int(offR[-1])*dl)) for k in range(2)]
     row=[]
     for label,env in VARIANTS:
-        for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF"):
+        for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF","CSGN_RAGGED_TOUCH"):
             os.environ.pop(k,None)
         os.environ.update({k:v for k,v in env.items() if k.startswith('CSGN')})
         NSETS[0]=int(env.get('NSETS','3'))
@@ -58,7 +58,7 @@ for name,t1s,t2s in [
         else:
             t=timed(one, rounds=9)
         row.append(f"{label}: {alg/t/1e9:6.0f}")
-    for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF"):
+    for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF","CSGN_RAGGED_TOUCH"):
         os.environ.pop(k,None)
     print(f"   kernel only, GB/s   " + "  ".join(row), flush=True)
     del sets
