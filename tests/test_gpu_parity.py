@@ -1243,6 +1243,39 @@ def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     lib.csgn_circuit_destroy(c)
 
 
+def test_ragged_mul_sliced_with_operand_touch(hip, oracle, monkeypatch):
+    """A ragged product above 1 GiB (7 000 pairs of 20..44 x 20..44 terms, N=1247) goes in slices, each
+    preceded by the device-side operand touch; identical to the unsliced run, sampled pairs equal
+    the oracle, including pairs that straddle a slice boundary."""
+    import torch
+    n, dl = 1247, 20
+    rng = np.random.default_rng(8)
+    batch = 7000
+    t1s, t2s = rng.integers(20, 45, size=batch), rng.integers(20, 45, size=batch)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    total = int(np.sum(t1s * t2s))
+    assert total * 10 > (1 << 26)                               # more units than one slice
+    L = hip.synth_fill(51, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(52, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    monkeypatch.setenv("CSGN_RAGGED_FLAT", "1")
+    monkeypatch.setenv("CSGN_RAGGED_TOUCH", "0")
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+    ref = ref.clone()
+    monkeypatch.setenv("CSGN_RAGGED_TOUCH", "1")
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+    assert torch.equal(out, ref) and torch.equal(off, ref_off)
+    mo = hip.download(off)
+    assert np.array_equal(mo, csr((t1s * t2s).tolist()))
+    cut_term = (1 << 26) // 10                                  # first term of the second slice
+    straddler = int(np.searchsorted(mo, cut_term, side="right") - 1)
+    hl, hr = hip.download(L), hip.download(R)
+    for b in sorted({0, 1, batch - 1, straddler - 1, straddler, straddler + 1} | set(rng.integers(0, batch, 40).tolist())):
+        want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+        got = hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl])
+        assert np.array_equal(got, want), b
+
+
 def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
     """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
     ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
