@@ -86,6 +86,34 @@ CiphertextBatch CiphertextBatch::operator+(const CiphertextBatch &rhs) const
     return out;
 }
 
+namespace {
+// N uint32 permutation entries in HBM (two per uploaded word)
+std::shared_ptr<DevicePayload> uploadPermutation(const Permutation &p, uint64_t n, const char *who)
+{
+    if (p.getLength() < n)
+        throw std::invalid_argument(std::string(who) + ": permutation shorter than N");
+    std::vector<uint64_t> packed((n + 1) / 2, 0);
+    const uint64_t *src = p.getPermutation();
+    for (uint64_t i = 0; i < n; ++i)
+        packed[i / 2] |= (uint64_t)(uint32_t)src[i] << (32 * (i % 2));
+    return detail::uploadWords(packed.data(), packed.size());
+}
+} // namespace
+
+CiphertextBatch CiphertextBatch::applyPermutation(const Permutation &permutation) const
+{
+    CiphertextBatch out(ctx, count_, 1);
+    if (count_ == 0)
+        return out;
+    std::shared_ptr<DevicePayload> d = uploadPermutation(permutation, ctx.getN(), "certFHE::CiphertextBatch::applyPermutation");
+    detail::check(csgn_permute_uniform(ctx.getN(), count_, terms_, 0, deviceValues(),
+                                       reinterpret_cast<const uint32_t *>(d->data()), out.payload->data(),
+                                       detail::stream()),
+                  "csgn_permute_uniform");
+    detail::syncDevice();               // the permutation table is released on return
+    return out;
+}
+
 std::vector<unsigned char> CiphertextBatch::decrypt(const SecretKey &key) const
 {
     std::vector<unsigned char> bits(count_, 0);
@@ -192,16 +220,8 @@ unsigned BatchCircuit::mul(unsigned a, unsigned b)
 
 unsigned BatchCircuit::permute(unsigned a, const Permutation &p)
 {
-    const uint64_t n = ctx.getN();
-    if (p.getLength() < n)
-        throw std::invalid_argument("certFHE::BatchCircuit::permute: permutation shorter than N");
-    // the kernel wants N uint32 entries: two per uploaded word
-    std::vector<uint64_t> packed((n + 1) / 2, 0);
-    const uint64_t *src = p.getPermutation();
-    for (uint64_t i = 0; i < n; ++i)
-        packed[i / 2] |= (uint64_t)(uint32_t)src[i] << (32 * (i % 2));
-    std::shared_ptr<DevicePayload> d = detail::uploadWords(packed.data(), packed.size());
-    masks.push_back(d);
+    std::shared_ptr<DevicePayload> d = uploadPermutation(p, ctx.getN(), "certFHE::BatchCircuit::permute");
+    masks.push_back(d);                 // the graph holds the pointer: keep the block alive
     uint32_t id = 0;
     detail::check(csgn_circuit_permute(handle, a, reinterpret_cast<const uint32_t *>(d->data()), &id),
                   "csgn_circuit_permute");

@@ -43,6 +43,10 @@ class CiphertextBatch {
     CiphertextBatch operator*(const CiphertextBatch &rhs) const;   // element-wise product
     CiphertextBatch operator+(const CiphertextBatch &rhs) const;   // element-wise sum
 
+    // Ciphertext::applyPermutation on every element (as in the reference the result has ONE term:
+    // the permuted first term of each element).
+    CiphertextBatch applyPermutation(const Permutation &permutation) const;
+
     // One plaintext bit per element.
     std::vector<unsigned char> decrypt(const SecretKey &key) const;
     // Dec(this[i] * rhs[i]) / Dec(this[i] + rhs[i]) without materialising the results.

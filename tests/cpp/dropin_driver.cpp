@@ -455,6 +455,23 @@ static int cmd_batch(int count)
     EXPECT(b3.getLen() == e.getLen());
     for (uint64_t i = 0; i < e.getLen(); ++i)
         EXPECT(b3.getValues()[i] == e.getValues()[i]);
+    // batch-level applyPermutation = the per-object one on every element; the permuted key decrypts it
+    {
+        Permutation perm(ctx);
+        SecretKey psk = sk.applyPermutation(perm);
+        CiphertextBatch pb = in[1].applyPermutation(perm);
+        EXPECT(pb.terms() == 1 && pb.size() == (uint64_t)count);
+        EXPECT(pb.decrypt(psk) == bits[1]);
+        CiphertextBatch px = x.applyPermutation(perm);          // multi-term input: ONE term, the permuted first
+        EXPECT(px.terms() == 1);
+        for (int i = 0; i < count; i += (count > 5 ? count / 5 : 1)) {
+            Ciphertext a1 = pb.at(i), b1 = in[1].at(i).applyPermutation(perm);
+            Ciphertext a2 = px.at(i), b2 = x.at(i).applyPermutation(perm);
+            EXPECT(a1.getLen() == b1.getLen() && a2.getLen() == b2.getLen());
+            for (uint64_t w = 0; w < a1.getLen(); ++w)
+                EXPECT(a1.getValues()[w] == b1.getValues()[w] && a2.getValues()[w] == b2.getValues()[w]);
+        }
+    }
     // pack() round trip
     std::vector<Ciphertext> singles;
     for (int i = 0; i < 5; ++i)
