@@ -127,15 +127,14 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
 // decrypt, pass 2: XOR over the terms of each ciphertext = parity of the popcount of its
 // bit range (src/SecretKey.cpp:139, `_dec = (dec + _dec) % 2`).  G lanes per ciphertext:
 // 1 for small term counts, a whole wave (with a __ballot/__popcll fold) for large ones.
-// MODE 0: every ciphertext; 1: only those of at most kLongTerms terms; 2: only the longer ones
-// (ragged batches run a lane-per-ciphertext pass for the short ones and a wave-per-ciphertext
-// pass for the long ones, so one huge ciphertext among many small ones costs neither).
+// MODE 0: every ciphertext; 1: only those of at most kLongTerms terms, the longer ones are queued
+// for k_hits_parity_long (ragged batches: one huge ciphertext among many small ones costs neither).
 constexpr u64 kLongTerms = 4096;
 
 template <int G, int MODE>
 __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hits,
                                                      const u64 *__restrict__ off, u64 T, u64 batch,
-                                                     uint8_t *__restrict__ bits)
+                                                     uint8_t *__restrict__ bits, u32 *__restrict__ work)
 {
     const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
     const u64 b = gid / G;
@@ -144,10 +143,10 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
         return;
     const u64 s = off ? off[b] : b * T;
     const u64 e = off ? off[b + 1] : s + T;
-    if (MODE == 1 && e - s > kLongTerms)
+    if (MODE == 1 && e - s > kLongTerms) {
+        work[1u + atomicAdd(work, 1u)] = (u32)b;    // left to k_hits_parity_long: work = [count][indices]
         return;
-    if (MODE == 2 && e - s <= kLongTerms)
-        return;                                     // whole wave leaves (G == 64: one ciphertext per wave)
+    }
     u32 par = 0;
     if (e > s) {
         const u64 w0 = s >> 6, w1 = (e - 1) >> 6;
@@ -166,6 +165,43 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
         const u64 odd = __ballot(par & 1u);
         if (lane == 0)
             bits[b] = (uint8_t)(__popcll(odd) & 1);
+    }
+}
+
+// decrypt, pass 2 of a ragged batch, the long ciphertexts: one workgroup per work-list entry (the
+// list is filled by the lane-per-ciphertext pass above), workgroups stride over the list, so a
+// batch of a million short ciphertexts does not pay for a million idle waves.
+__global__ void __launch_bounds__(256) k_hits_parity_long(const u64 *__restrict__ hits,
+                                                          const u64 *__restrict__ off,
+                                                          const u32 *__restrict__ work,
+                                                          uint8_t *__restrict__ bits)
+{
+    __shared__ u32 odd_waves;
+    const u32 lane = threadIdx.x & (kWave - 1);
+    const u32 n = work[0];
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {      // one workgroup per queued ciphertext
+        if (threadIdx.x == 0)
+            odd_waves = 0;
+        __syncthreads();
+        const u32 b = work[1u + i];
+        const u64 s = off[b], e = off[b + 1];
+        const u64 w0 = s >> 6, w1 = (e - 1) >> 6;
+        u32 par = 0;
+        for (u64 w = w0 + threadIdx.x; w <= w1; w += 256u) {
+            u64 x = hits[w];
+            if (w == w0)
+                x &= ~0ull << (s & 63);
+            if (w == w1 && (e & 63))
+                x &= (1ull << (e & 63)) - 1;
+            par ^= (u32)__popcll(x);
+        }
+        const u64 odd = __ballot(par & 1u);
+        if (lane == 0 && (__popcll(odd) & 1))
+            atomicXor(&odd_waves, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            bits[b] = (uint8_t)(odd_waves & 1u);
+        __syncthreads();
     }
 }
 
@@ -295,14 +331,19 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
             return e;
     }
     if (off) {
-        // ragged: short ciphertexts one lane each, long ones one wave each
-        if (batch * 64 > kMaxBlocks256 * 256u)
+        // ragged: short ciphertexts one lane each; the long ones are queued and take one wave each
+        if (batch >= (1ull << 32))
             return hipErrorInvalidValue;
-        k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits);
+        u32 *work = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
+                                            decrypt_bitmap_bytes(total_terms));      // [count][batch indices]
+        hipError_t e = hipMemsetAsync(work, 0, 4, s);
+        if (e != hipSuccess)
+            return e;
+        k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits, work);
         if (total_terms > kLongTerms)
-            k_hits_parity<64, 2><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, off, 0, batch, bits);
+            k_hits_parity_long<<<(u32)std::min<u64>(4096, batch), 256, 0, s>>>(hits, off, work, bits);
     } else if (terms_uniform <= kLongTerms) {
-        k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits);
+        k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, nullptr);
     } else if (batch * ((terms_uniform + 65535) / 65536) <= kMaxBlocks256) {
         // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
         u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
@@ -316,7 +357,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     } else {
         if (batch * 64 > kMaxBlocks256 * 256u)
             return hipErrorInvalidValue;
-        k_hits_parity<64, 0><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits);
+        k_hits_parity<64, 0><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, nullptr);
     }
     return hipGetLastError();
 }
