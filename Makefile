@@ -7,7 +7,7 @@ CXX     ?= g++
 CSRC    := csgn_amd/csrc
 LIBDIR  := csgn_amd/lib
 HIP_SRC := $(addprefix $(CSRC)/,csgn_capi.hip csgn_mul.hip csgn_add.hip csgn_decrypt.hip csgn_encrypt.hip \
-                                csgn_permute.hip csgn_compact.hip csgn_harness.hip)
+                                csgn_permute.hip csgn_compact.hip csgn_harness.hip csgn_tuning.cpp)
 HIP_HDR := $(wildcard $(CSRC)/*.h) include/csgn_hip.h
 CLS_SRC := $(sort $(wildcard $(CSRC)/certfhe/*.cpp))
 CLS_HDR := $(wildcard include/certfhe/*.h) $(wildcard $(CSRC)/certfhe/*.h)

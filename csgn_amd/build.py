@@ -22,8 +22,8 @@ HIP_LIB = os.path.join(LIBDIR, "libcsgn_hip.so")
 CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
 
 HIP_SOURCES = ["csgn_capi.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
-               "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip"]
-HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h"]
+               "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip", "csgn_tuning.cpp"]
+HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h", "csgn_tuning.h"]
 
 
 def _hipcc() -> str:

@@ -81,6 +81,10 @@ SIGNATURES = {
     "csgn_circuit_bits": (vp, [vp, C.c_uint32]),
     "csgn_circuit_run": (C.c_int, [vp, vp]),
     "csgn_mul_uniform_kernel": (C.c_char_p, [u64, u64, u64, u64]),
+    "csgn_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "csgn_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "csgn_reset_tuning": (None, []),
+    "csgn_tuning_name": (C.c_char_p, [C.c_int]),
     "csgn_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
 }
 
@@ -130,3 +134,34 @@ def check(rc: int) -> None:
     if rc != CSGN_OK:
         msg = load_library().csgn_last_error()
         raise CsgnError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+# -- tuning knobs (csgn_set_tuning; csgn_amd/csrc/csgn_tuning.h) ---------------------------------
+def _knob(name: str) -> bytes:
+    """'mul_flat' or the environment-style 'CSGN_MUL_FLAT'."""
+    n = name[5:] if name.upper().startswith("CSGN_") else name
+    return n.lower().encode()
+
+
+def set_tuning(name: str, value) -> None:
+    check(load_library().csgn_set_tuning(_knob(name), int(value)))
+
+
+def get_tuning(name: str) -> int:
+    v = C.c_int(0)
+    check(load_library().csgn_get_tuning(_knob(name), C.byref(v)))
+    return v.value
+
+
+def reset_tuning() -> None:
+    load_library().csgn_reset_tuning()
+
+
+def tuning_names():
+    lib, out, i = load_library(), [], 0
+    while True:
+        n = lib.csgn_tuning_name(i)
+        if not n:
+            return out
+        out.append(n.decode())
+        i += 1

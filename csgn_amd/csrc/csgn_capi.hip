@@ -3,6 +3,7 @@
 // csgn_{mul,add,decrypt,encrypt,permute,compact,harness}.hip.  There is deliberately no CPU fallback anywhere in this library.
 #include "csgn_hip.h"
 #include "csgn_kernels.h"
+#include "csgn_tuning.h"
 
 #include <cstdarg>
 #include <vector>
@@ -44,6 +45,16 @@ int hip_fail(hipError_t e, const char *what)
     } while (0)
 
 inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
+
+// a*b*c < limit, evaluated without wrapping (operands may be anything up to 2^64-1)
+bool product_below(uint64_t a, uint64_t b, uint64_t c, uint64_t limit)
+{
+    unsigned long long ab, abc;
+    if (__builtin_mul_overflow((unsigned long long)a, (unsigned long long)b, &ab) ||
+        __builtin_mul_overflow(ab, (unsigned long long)c, &abc))
+        return false;
+    return abc < limit;
+}
 
 // Shape limits shared by every compute entry point.
 int check_n(uint64_t n_bits)
@@ -291,9 +302,11 @@ int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
         return CSGN_OK;
     REQUIRE(d_left && d_right && d_out, "null device pointer");
     const uint64_t dl = csgn_default_len(n_bits);
-    if (t1 >= (1ull << 31) || t2 >= (1ull << 31) || t1 * t2 * dl >= (1ull << 32))
+    if (t1 >= (1ull << 31) || t2 >= (1ull << 31) || !product_below(t1, t2, dl, 1ull << 32))
         return fail(CSGN_ERR_UNSUPPORTED, "pair product of %llu x %llu terms exceeds 2^32 words",
                     (unsigned long long)t1, (unsigned long long)t2);
+    if (!product_below(batch, t1 + t2, dl, 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu pairs: operand size overflows", (unsigned long long)batch);
     HIP_TRY(csgn::mul_uniform(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
                               (u64 *)d_out, out_slots, S(stream)));
     return CSGN_OK;
@@ -350,7 +363,7 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
         return CSGN_OK;
     REQUIRE(d_left && d_right && d_out && d_off_left && d_off_right && d_off_out, "null device pointer");
     const uint64_t dl = csgn_default_len(n_bits);
-    if (max_t1 >= (1ull << 31) || max_t2 >= (1ull << 31) || max_t1 * max_t2 * dl >= (1ull << 32))
+    if (max_t1 >= (1ull << 31) || max_t2 >= (1ull << 31) || !product_below(max_t1, max_t2, dl, 1ull << 32))
         return fail(CSGN_ERR_UNSUPPORTED, "pair product of %llu x %llu terms exceeds 2^32 words",
                     (unsigned long long)max_t1, (unsigned long long)max_t2);
     hipError_t e = csgn::mul_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
@@ -367,13 +380,15 @@ int csgn_add_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
 {
     if (int rc = check_n(n_bits))
         return rc;
+    const uint64_t dl = csgn_default_len(n_bits);
+    if (t1 >= (1ull << 31) || t2 >= (1ull << 31) || (t1 + t2) * dl >= (1ull << 31))
+        return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu + %llu terms exceeds 2^31 words per pair",
+                    (unsigned long long)t1, (unsigned long long)t2);
     if (batch == 0 || t1 + t2 == 0)
         return CSGN_OK;
     REQUIRE(d_out && (d_left || t1 == 0) && (d_right || t2 == 0), "null device pointer");
-    const uint64_t dl = csgn_default_len(n_bits);
-    if ((t1 + t2) * dl >= (1ull << 31))
-        return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu + %llu terms exceeds 2^31 words per pair",
-                    (unsigned long long)t1, (unsigned long long)t2);
+    if (!product_below(batch, t1 + t2, dl, 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu pairs: size overflows", (unsigned long long)batch);
     HIP_TRY(csgn::add_uniform(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
                               (u64 *)d_out, S(stream)));
     return CSGN_OK;
@@ -411,6 +426,9 @@ int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,
     if (batch == 0)
         return CSGN_OK;
     REQUIRE(d_mask && d_bits && d_scratch && (d_terms || terms == 0), "null device pointer");
+    if (!product_below(batch, terms, csgn_default_len(n_bits), 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu x %llu terms: size overflows",
+                    (unsigned long long)batch, (unsigned long long)terms);
     HIP_TRY(csgn::decrypt(n_bits, batch, terms, batch * terms, (const u64 *)d_terms, nullptr,
                           (const u64 *)d_mask, d_bits, d_scratch, S(stream)));
     return CSGN_OK;
@@ -446,6 +464,9 @@ int csgn_decrypt_product_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, u
         return CSGN_OK;
     REQUIRE(d_mask && d_bits && d_scratch && (d_left || t1 == 0) && (d_right || t2 == 0),
             "null device pointer");
+    if (!product_below(batch, t1, csgn_default_len(n_bits), 1ull << 60) ||
+        !product_below(batch, t2, csgn_default_len(n_bits), 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)batch);
     HIP_TRY(csgn::decrypt_combined(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
                                    (const u64 *)d_mask, true, d_bits, d_scratch, S(stream)));
     return CSGN_OK;
@@ -461,6 +482,9 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
         return CSGN_OK;
     REQUIRE(d_mask && d_bits && d_scratch && (d_left || t1 == 0) && (d_right || t2 == 0),
             "null device pointer");
+    if (!product_below(batch, t1, csgn_default_len(n_bits), 1ull << 60) ||
+        !product_below(batch, t2, csgn_default_len(n_bits), 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)batch);
     HIP_TRY(csgn::decrypt_combined(n_bits, batch, t1, t2, (const u64 *)d_left, (const u64 *)d_right,
                                    (const u64 *)d_mask, false, d_bits, d_scratch, S(stream)));
     return CSGN_OK;
@@ -624,6 +648,9 @@ int csgn_circuit_input(csgn_circuit *c, uint64_t terms, uint32_t *value)
     REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
     REQUIRE(terms > 0, "an input needs at least one term");
     const uint64_t dl = csgn_default_len(c->n_bits);
+    if (!product_below(c->batch, terms, dl, 1ull << 57))
+        return fail(CSGN_ERR_UNSUPPORTED, "input of %llu x %llu terms: size overflows",
+                    (unsigned long long)c->batch, (unsigned long long)terms);
     c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
     *value = (uint32_t)(c->values.size() - 1);
     return CSGN_OK;
@@ -636,11 +663,14 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
     const uint64_t dl = csgn_default_len(c->n_bits);
     const uint64_t ta = c->values[a].terms, tb = c->values[b].terms;
     const uint64_t terms = kind ? ta * tb : ta + tb;
-    if (kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || ta * tb * dl >= (1ull << 32)))
+    if (kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || !product_below(ta, tb, dl, 1ull << 32)))
         return fail(CSGN_ERR_UNSUPPORTED, "product of %llu x %llu terms exceeds 2^32 words",
                     (unsigned long long)ta, (unsigned long long)tb);
-    if (!kind && terms * dl >= (1ull << 31))
+    if (!kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || terms * dl >= (1ull << 31)))
         return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu terms exceeds 2^31 words", (unsigned long long)terms);
+    if (!product_below(c->batch, terms, dl, 1ull << 57))
+        return fail(CSGN_ERR_UNSUPPORTED, "value of %llu x %llu terms: size overflows",
+                    (unsigned long long)c->batch, (unsigned long long)terms);
     c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
     const uint32_t out = (uint32_t)(c->values.size() - 1);
     c->ops.push_back({kind, a, b, out, nullptr, 0, 0});
@@ -680,13 +710,24 @@ int csgn_circuit_build(csgn_circuit *c)
 {
     REQUIRE(c && !c->exec, "null circuit, or already built");
     REQUIRE(!c->ops.empty(), "the circuit has no operations");
-    if (c->block) {                     // an earlier build attempt failed after the allocation
+    if (c->graph) {                     // an earlier build attempt failed at instantiation
+        (void)hipGraphDestroy(c->graph);
+        c->graph = nullptr;
+    }
+    if (c->block) {                     // ... or after the allocation
         (void)hipFree(c->block);
         c->block = nullptr;
     }
     HIP_TRY(hipMalloc(&c->block, c->bytes ? c->bytes : 256));
     hipStream_t s = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    {
+        const hipError_t es = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (es != hipSuccess) {
+            (void)hipFree(c->block);
+            c->block = nullptr;
+            return hip_fail(es, "hipStreamCreateWithFlags");
+        }
+    }
     unsigned char *base = static_cast<unsigned char *>(c->block);
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
@@ -716,8 +757,13 @@ int csgn_circuit_build(csgn_circuit *c)
             (void)hipGraphDestroy(g);
         return hip_fail(e != hipSuccess ? e : e2, "csgn_circuit_build (stream capture)");
     }
+    const hipError_t e3 = hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0);
+    if (e3 != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        c->exec = nullptr;
+        return hip_fail(e3, "hipGraphInstantiate");
+    }
     c->graph = g;
-    HIP_TRY(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
     return CSGN_OK;
 }
 
@@ -746,6 +792,28 @@ int csgn_circuit_run(csgn_circuit *c, void *stream)
     HIP_TRY(hipGraphLaunch(c->exec, S(stream)));
     return CSGN_OK;
 }
+
+/* ------------------------------------------------------------------ tuning ---- */
+
+int csgn_set_tuning(const char *key, int value)
+{
+    REQUIRE(key, "key is null");
+    if (!csgn::tune_set(key, value))
+        return fail(CSGN_ERR_INVALID, "csgn_set_tuning: no knob named '%s'", key);
+    return CSGN_OK;
+}
+
+int csgn_get_tuning(const char *key, int *h_value)
+{
+    REQUIRE(key && h_value, "null argument");
+    if (!csgn::tune_get(key, h_value))
+        return fail(CSGN_ERR_INVALID, "csgn_get_tuning: no knob named '%s'", key);
+    return CSGN_OK;
+}
+
+void csgn_reset_tuning(void) { csgn::tune_reset(); }
+
+const char *csgn_tuning_name(int index) { return csgn::tune_name(index); }
 
 /* debug hook used by the CPU tests to pin the division-by-invariant helper */
 uint32_t csgn_debug_fastdiv(uint32_t n, uint32_t d)

@@ -166,7 +166,8 @@ hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, con
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0)
         return hipSuccess;
-    if (batch >= (1ull << 31) || total_terms > kMaxBlocks256 * 256u - 256u)
+    // slot indices (2*off[b]+slot, up to 2*total_terms) are kept in 32 bits
+    if (batch >= (1ull << 31) || total_terms >= (1ull << 31))
         return hipErrorInvalidValue;
     auto up = [](uintptr_t x) { return (x + 255) & ~(uintptr_t)255; };
     unsigned char *p = reinterpret_cast<unsigned char *>(up(reinterpret_cast<uintptr_t>(scratch)));

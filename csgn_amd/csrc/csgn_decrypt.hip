@@ -287,7 +287,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
                     k_seg = k;
                     break;
                 }
-        if (k_seg && env_int("CSGN_DEC_LOOP", 0) == 0) {
+        if (k_seg && tune(TUNE_DEC_LOOP) == 0) {
             const u32 tb = 256u * k_seg / U;
             const u64 nblk = (total_terms + tb - 1) / tb;
             if (nblk > kMaxBlocks256)

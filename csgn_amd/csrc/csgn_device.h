@@ -1,7 +1,7 @@
 // csgn_device.h -- helpers shared by the kernel translation units (csgn_mul.hip, csgn_add.hip,
 // csgn_decrypt.hip, csgn_encrypt.hip, csgn_permute.hip, csgn_compact.hip, csgn_harness.hip):
 // 16-/8-byte unit access, the XCD-contiguous block order, CSR pair search, launch limits and the
-// environment knobs.  Everything has internal linkage (one copy per translation unit).
+// knob-dependent launch choices (csgn_tuning.h).  Everything has internal linkage (one copy per translation unit).
 //
 // Common shape of the data path: lanes own consecutive 16-byte units so every wave-level
 // load/store is one global_{load,store}_dwordx4 covering 1 KiB of contiguous, 128-B-aligned
@@ -11,8 +11,7 @@
 #pragma once
 
 #include "csgn_kernels.h"
-
-#include <cstdlib>
+#include "csgn_tuning.h"
 
 namespace csgn {
 
@@ -115,18 +114,12 @@ inline bool aligned16(const T *p)
     return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-inline int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 // Block order of the one-unit-per-lane stream kernels (1x1 multiply, uniform add): XCD-contiguous
 // once a launch is large (measured +3-5 % from 32 M units = 512 MB per stream up, -1-2 % at
-// 10 M units).  CSGN_STREAM_XCD = 0 / 1 forces it.
+// 10 M units).  Knob stream_xcd = 0 / 1 forces it.
 inline u32 stream_xcd(u64 units)
 {
-    const int forced = env_int("CSGN_STREAM_XCD", -1);
+    const int forced = tune(TUNE_STREAM_XCD);
     if (forced == 0 || forced == 1)
         return (u32)forced;
     return units >= (1ull << 25) ? 1u : 0u;
@@ -134,10 +127,10 @@ inline u32 stream_xcd(u64 units)
 
 // 4 KiB chunks per workgroup of the flat ragged kernels: as many as 8 (the workgroup's first search
 // is paid once per C chunks) while the grid still has >= 8192 workgroups to fill the chip with.
-// CSGN_RAGGED_C = 1, 2, 4, 8, 16 overrides.
+// Knob ragged_c = 1, 2, 4, 8, 16 overrides.
 inline int ragged_chunks(u64 total_units)
 {
-    const int forced = env_int("CSGN_RAGGED_C", 0);
+    const int forced = tune(TUNE_RAGGED_C);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16)
         return forced;
     int c = 1;

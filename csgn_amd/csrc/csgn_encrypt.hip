@@ -281,7 +281,7 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
                     k_seg = k;
                     break;
                 }
-        if (k_seg && env_int("CSGN_ENC_LDS", 0) == 0) {
+        if (k_seg && tune(TUNE_ENC_LDS) == 0) {
             const u32 tb = 256u * k_seg / U;
             const u64 nblk = (batch + tb - 1) / tb;
             if (nblk > kMaxBlocks256)

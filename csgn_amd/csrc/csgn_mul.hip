@@ -473,7 +473,7 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
     MulPlan p = {0, 0};
     if (PU >= (1ull << 31) || tune.flat == -1)
         return p;
-    const int touch_env = env_int("CSGN_MUL_TOUCH", -1);
+    const int touch_env = csgn::tune(TUNE_MUL_TOUCH);
     if (tune.flat > 0) {
         p.flat = tune.flat;
         p.touch = touch_env > 0 ? (touch_env & 3) : 0;
@@ -566,7 +566,8 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
         // fills a workgroup): ~6 MB of output ahead per XCD stream
         u32 pfr = 0;
         if (!plan.touch && (u64)t2 * U >= 256u) {
-            const u64 ahead = (u64)env_int("CSGN_MUL_PF_KB", tune.xcd ? 6144 : 49152) << 10;
+            const int pf_kb = csgn::tune(TUNE_MUL_PF_KB);
+            const u64 ahead = (u64)(pf_kb >= 0 ? pf_kb : (tune.xcd ? 6144 : 49152)) << 10;
             const u64 row_bytes = (u64)t2 * U * sizeof(Unit);
             pfr = (u32)((ahead + row_bytes - 1) / row_bytes);
         }
@@ -634,20 +635,20 @@ MulTuning mul_tuning()
     // (4 KiB row segments), one column unit per lane, 4 left terms per tile, non-temporal
     // stores.  Short-lived workgroups keep the chip-wide write front dense in address space,
     // which is what HBM rewards; long-lived tiles (TI=64) lose ~20 % to the scattered store pattern.
-    t.m = env_int("CSGN_MUL_M", 0);          // 0 = auto: 1 column unit per lane (2 for 8-byte units)
+    t.m = tune(TUNE_MUL_M);          // 0 = auto: 1 column unit per lane (2 for 8-byte units)
     if (t.m != 1 && t.m != 2 && t.m != 4 && t.m != 8)
         t.m = 0;
-    t.ti = env_int("CSGN_MUL_TI", 4);
+    t.ti = tune(TUNE_MUL_TI);
     if (t.ti < 1)
         t.ti = 1;
-    t.nt = env_int("CSGN_MUL_NT", 1) ? 1 : 0;
-    t.flat = env_int("CSGN_MUL_FLAT", 0);   // 0 = auto (mul_plan); >0 = flat with that unroll; -1 = always tiled
+    t.nt = tune(TUNE_MUL_NT) ? 1 : 0;
+    t.flat = tune(TUNE_MUL_FLAT);   // 0 = auto (mul_plan); >0 = flat with that unroll; -1 = always tiled
     if (t.flat != -1 && t.flat != 1 && t.flat != 2 && t.flat != 4 && t.flat != 8)
         t.flat = 0;
-    t.xcd = env_int("CSGN_MUL_XCD", 1);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both
+    t.xcd = tune(TUNE_MUL_XCD);      // 0 = dispatch order, 1 = remap flat kernel, 2 = remap both
     if (t.xcd < 0 || t.xcd > 2)
         t.xcd = 1;
-    t.bs = env_int("CSGN_MUL_BS", 0);
+    t.bs = tune(TUNE_MUL_BS);
     if (t.bs % 64 != 0 || t.bs < 64 || t.bs > 512)
         t.bs = 0;
     return t;
@@ -720,7 +721,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // Nearly uniform batches of large products keep the LDS-tiled kernel (one grid sized for the
     // largest shape); anything skewed or small goes through the flat ragged kernel, whose grid
     // is the real output.
-    const bool tiled = env_int("CSGN_RAGGED_FLAT", 0) == 0 && max_t1 * max_t2 * U > 8192 &&
+    const bool tiled = csgn::tune(TUNE_RAGGED_FLAT) == 0 && max_t1 * max_t2 * U > 8192 &&
                        batch * max_t1 * max_t2 <= 2 * total_out_terms;
     if (tiled) {
         MulArgs a = {};
@@ -737,11 +738,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
     const int chunks = ragged_chunks(total_units);
-    const u32 pf_pairs = (u32)env_int("CSGN_RAGGED_PF", 32);    // operand prefetch distance in pairs, 0 = off
+    const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
     // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
     // an HBM miss under full write load, as in the uniform path.  CSGN_RAGGED_TOUCH=0 turns it off.
-    const bool touch = wide && total_units > (1ull << 26) && env_int("CSGN_RAGGED_TOUCH", 1) != 0;
+    const bool touch = wide && total_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
     const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
     for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
         const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;

@@ -379,7 +379,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     {
         const u64 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
         const size_t lds = ((size_t)64 * (dLp | 1) + dLp * 64 + 1) * 8 + dLp * 64 * 2;
-        if (terms_in != 0 && out_terms >= 16 && dL <= 64 && lds <= 160 * 1024 && !env_int("CSGN_PERM_BALLOT", 0)) {
+        if (terms_in != 0 && out_terms >= 16 && dL <= 64 && lds <= 160 * 1024 && !tune(TUNE_PERM_BALLOT)) {
             const u64 groups = (out_terms + 63) / 64;
             // persistent waves: as many as the chip holds at once, equal group counts per wave
             int cus = 256;
@@ -390,7 +390,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
             }
             // 16-byte staging accesses when every term starts 16-byte aligned
             const bool wide = dL % 2 == 0 && stride % 2 == 0 && (((uintptr_t)terms | (uintptr_t)out) & 15) == 0 &&
-                              !env_int("CSGN_PERM_NARROW", 0);
+                              !tune(TUNE_PERM_NARROW);
             const u32 Ud = (u32)(wide ? dL / 2 : dL);
             const FastDiv dUd = csgn_fastdiv_make(Ud);
 #define CSGN_PLANES_LAUNCH(LQ, PIPE, UW)                                                            \
@@ -417,7 +417,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         }                                                                                           \
         int per_cu = asked_per_cu;                                                                  \
         per_cu = std::max(1, std::min(per_cu, (int)(160 * 1024 / ((lds + 1023) / 1024 * 1024))));   \
-        if (const int cap = env_int("CSGN_PERM_WAVES", 0))                                          \
+        if (const int cap = tune(TUNE_PERM_WAVES))                                          \
             per_cu = std::min(per_cu, cap);                                                         \
         const u64 resident = (u64)cus * (u64)per_cu;                                                \
         const u64 rounds = (groups + resident - 1) / resident;                                      \

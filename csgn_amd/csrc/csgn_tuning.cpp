@@ -1,0 +1,91 @@
+// csgn_tuning.cpp -- storage of the tuning knobs (csgn_tuning.h).  Host code only.
+#include "csgn_tuning.h"
+
+#include <atomic>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace csgn {
+
+namespace {
+
+struct Knob {
+    const char *name;
+    int dflt;
+};
+
+// order = enum TuneKey
+const Knob kKnobs[TUNE_COUNT] = {
+    {"mul_m", 0},        {"mul_ti", 4},        {"mul_nt", 1},        {"mul_flat", 0},
+    {"mul_bs", 0},       {"mul_xcd", 1},       {"mul_touch", -1},    {"mul_pf_kb", -1},
+    {"stream_xcd", -1},  {"ragged_c", 0},      {"ragged_flat", 0},   {"ragged_pf", 32},
+    {"ragged_touch", 1}, {"ragged_table", 1},  {"perm_ballot", 0},   {"perm_narrow", 0},
+    {"perm_waves", 0},   {"perm_v1", 0},       {"dec_loop", 0},      {"enc_lds", 0},
+    {"enc_wave", 1},
+};
+
+std::atomic<int> g_value[TUNE_COUNT];
+int g_env_value[TUNE_COUNT];
+bool g_env_set[TUNE_COUNT];
+
+// The one place the environment is read: when the library is loaded, before any entry point can
+// be called.
+struct EnvSnapshot {
+    EnvSnapshot()
+    {
+        for (int k = 0; k < TUNE_COUNT; ++k) {
+            std::string env = "CSGN_";
+            for (const char *p = kKnobs[k].name; *p; ++p)
+                env += (char)toupper((unsigned char)*p);
+            const char *v = getenv(env.c_str());
+            g_env_set[k] = v && *v;
+            g_env_value[k] = g_env_set[k] ? atoi(v) : 0;
+        }
+        tune_reset();
+    }
+};
+EnvSnapshot g_snapshot;
+
+int find(const char *name)
+{
+    if (!name)
+        return -1;
+    for (int k = 0; k < TUNE_COUNT; ++k)
+        if (strcmp(kKnobs[k].name, name) == 0)
+            return k;
+    return -1;
+}
+
+} // namespace
+
+int tune(TuneKey k) { return g_value[k].load(std::memory_order_relaxed); }
+
+const char *tune_name(int k) { return (k >= 0 && k < TUNE_COUNT) ? kKnobs[k].name : nullptr; }
+
+bool tune_set(const char *name, int value)
+{
+    const int k = find(name);
+    if (k < 0)
+        return false;
+    g_value[k].store(value, std::memory_order_relaxed);
+    return true;
+}
+
+bool tune_get(const char *name, int *value)
+{
+    const int k = find(name);
+    if (k < 0)
+        return false;
+    *value = g_value[k].load(std::memory_order_relaxed);
+    return true;
+}
+
+void tune_reset()
+{
+    for (int k = 0; k < TUNE_COUNT; ++k)
+        g_value[k].store(g_env_set[k] ? g_env_value[k] : kKnobs[k].dflt, std::memory_order_relaxed);
+}
+
+} // namespace csgn

@@ -1,0 +1,43 @@
+// csgn_tuning.h -- the library's tuning knobs (kernel choice and sweep parameters).
+//
+// Every knob is one process-wide atomic int.  Its start value is the built-in default, or the
+// value of the environment variable CSGN_<KEY IN CAPITALS> sampled ONCE when libcsgn_hip.so is
+// loaded; after that only csgn_set_tuning()/csgn_reset_tuning() (include/csgn_hip.h) change it.
+// No compute entry point reaches getenv.  Knobs select among kernels that compute the same
+// words: results never depend on them (tests/test_gpu_parity.py drives every form through them).
+#pragma once
+
+namespace csgn {
+
+enum TuneKey {
+    TUNE_MUL_M,          // tiled multiply: column units per lane, 0 = auto
+    TUNE_MUL_TI,         // tiled multiply: left terms per LDS tile
+    TUNE_MUL_NT,         // tiled multiply: 1 = non-temporal stores
+    TUNE_MUL_FLAT,       // 0 = choose per shape; k > 0 = flat kernel, k units per lane; -1 = tiled kernel
+    TUNE_MUL_BS,         // tiled multiply: block size override (0 = auto)
+    TUNE_MUL_XCD,        // XCD-contiguous block order: 0 off, 1 flat kernel, 2 both kernels
+    TUNE_MUL_TOUCH,      // operand touch pass: -1 = per shape, 0..3 = bit 0 left, bit 1 right operand
+    TUNE_MUL_PF_KB,      // flat multiply without touch: left-term prefetch distance in KiB, -1 = auto
+    TUNE_STREAM_XCD,     // 1x1 multiply / uniform add block order: -1 = by size, 0 / 1 forced
+    TUNE_RAGGED_C,       // flat ragged kernels: 4 KiB chunks per workgroup, 0 = auto
+    TUNE_RAGGED_FLAT,    // 1 = never use the tiled kernel for ragged batches
+    TUNE_RAGGED_PF,      // ragged multiply: operand prefetch distance in pairs, 0 = off
+    TUNE_RAGGED_TOUCH,   // ragged multiply: 1 = touch pass per 1 GiB output slice
+    TUNE_RAGGED_TABLE,   // ragged multiply: 1 = per-chunk (pair, i, j) side table from the plan step, 0 = search per lane
+    TUNE_PERM_BALLOT,    // 1 = ballot bit-gather permutation kernel instead of the bit-plane kernel
+    TUNE_PERM_NARROW,    // 1 = 8-byte staging accesses in the bit-plane kernel
+    TUNE_PERM_WAVES,     // cap on bit-plane waves per CU, 0 = occupancy query
+    TUNE_PERM_V1,        // 1 = round-1 bit-plane kernel (LDS row staging) instead of the round-2 one
+    TUNE_DEC_LOOP,       // 1 = looping 256-term decrypt pass 1 instead of the segment form
+    TUNE_ENC_LDS,        // 1 = LDS-staged encrypt kernel instead of the segment form
+    TUNE_ENC_WAVE,       // device-RNG encrypt: 1 = wave-local kernel (default), 0 = segment kernel
+    TUNE_COUNT
+};
+
+int tune(TuneKey k);                      // relaxed atomic load
+const char *tune_name(int k);             // "mul_m", ... (nullptr past the end)
+bool tune_set(const char *name, int value);
+bool tune_get(const char *name, int *value);
+void tune_reset();                        // defaults, then the environment snapshot taken at load
+
+} // namespace csgn

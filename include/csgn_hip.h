@@ -286,6 +286,20 @@ int csgn_circuit_run(csgn_circuit *circuit, void *stream);
  * with the kernel that really runs. */
 const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2);
 
+/* ------------------------------------------------------------------- tuning ---- */
+
+/* Kernel-choice and sweep knobs ("mul_flat", "mul_touch", "ragged_c", "perm_ballot", ...;
+ * csgn_tuning_name(i) enumerates them, NULL past the end; csgn_amd/csrc/csgn_tuning.h documents
+ * each).  A knob's start value is its built-in default or the environment variable
+ * CSGN_<KEY IN CAPITALS>, sampled ONCE when the library is loaded: no compute entry point reads
+ * the environment.  Knobs choose among kernels that produce the same words; results never depend
+ * on them.  They are process-wide atomics: set them before launching work from other threads.
+ * A circuit (csgn_circuit_build) bakes in the values current at build time. */
+int csgn_set_tuning(const char *key, int value);
+int csgn_get_tuning(const char *key, int *h_value);
+void csgn_reset_tuning(void);            /* defaults + the environment snapshot taken at load */
+const char *csgn_tuning_name(int index);
+
 /* Debug hook: quotient n/d computed by the same division-by-invariant helper the kernels
  * use (csgn_amd/csrc/csgn_common.h); lets the CPU tests pin it without a GPU. */
 uint32_t csgn_debug_fastdiv(uint32_t n, uint32_t d);

@@ -34,3 +34,32 @@ def ref():
     if r is None:
         pytest.skip("oracle/_ref/libcsgn_ref.so not built (reference sources absent)")
     return r
+
+
+class _Knobs:
+    """Tuning knobs of libcsgn_hip.so for one test (csgn_set_tuning): set()/unset() take the knob
+    name ('mul_flat') or its environment spelling ('CSGN_MUL_FLAT'); everything is restored at
+    teardown.  The library never reads the environment after it is loaded."""
+
+    def __init__(self):
+        from csgn_amd import capi
+        self.capi = capi
+        self.saved = {n: capi.get_tuning(n) for n in capi.tuning_names()}
+
+    def set(self, name, value):
+        self.capi.set_tuning(name, int(value))
+
+    def unset(self, name):
+        key = name[5:].lower() if name.upper().startswith("CSGN_") else name
+        self.capi.set_tuning(key, self.saved[key])
+
+    def restore(self):
+        for n, v in self.saved.items():
+            self.capi.set_tuning(n, v)
+
+
+@pytest.fixture
+def knobs():
+    k = _Knobs()
+    yield k
+    k.restore()

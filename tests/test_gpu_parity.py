@@ -89,9 +89,9 @@ def test_mul_uniform_matches_oracle(hip, oracle, n, d, t1, t2, batch):
 
 
 @pytest.mark.parametrize("flat,xcd", [(0, 1), (0, 0), (2, 1), (4, 0), (8, 1)])
-def test_mul_flat_variants_do_not_change_results(hip, oracle, monkeypatch, flat, xcd):
-    monkeypatch.setenv("CSGN_MUL_FLAT", str(flat))
-    monkeypatch.setenv("CSGN_MUL_XCD", str(xcd))
+def test_mul_flat_variants_do_not_change_results(hip, oracle, knobs, flat, xcd):
+    knobs.set("CSGN_MUL_FLAT", str(flat))
+    knobs.set("CSGN_MUL_XCD", str(xcd))
     n, dl = 1247, 20
     for (t1, t2, batch) in [(100, 77, 2), (64, 128, 3), (257, 33, 1), (3, 5, 7), (1, 9, 5)]:
         L = oracle.synth(5, n, 0, batch * t1 * dl)
@@ -105,9 +105,9 @@ def test_mul_flat_variants_do_not_change_results(hip, oracle, monkeypatch, flat,
 
 @pytest.mark.parametrize("n,d", CONTEXTS)
 @pytest.mark.parametrize("t1,t2", [(1, 2), (3, 5), (33, 65), (5, 300), (129, 130)])
-def test_mul_tiled_kernel_matches_oracle(hip, oracle, monkeypatch, n, d, t1, t2):
+def test_mul_tiled_kernel_matches_oracle(hip, oracle, knobs, n, d, t1, t2):
     """The LDS-tiled kernel (CSGN_MUL_FLAT=-1; also the ragged path) on every context."""
-    monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
+    knobs.set("CSGN_MUL_FLAT", "-1")
     dl = oracle.default_len(n)
     batch = 2
     L = oracle.synth(1000 + t1, n, 0, batch * t1 * dl)
@@ -121,11 +121,11 @@ def test_mul_tiled_kernel_matches_oracle(hip, oracle, monkeypatch, n, d, t1, t2)
 
 @pytest.mark.parametrize("n,d", CONTEXTS)
 @pytest.mark.parametrize("touch", [0, 1, 3])
-def test_mul_flat_kernel_with_touch_matches_oracle(hip, oracle, monkeypatch, n, d, touch):
+def test_mul_flat_kernel_with_touch_matches_oracle(hip, oracle, knobs, n, d, touch):
     """The flat kernel forced on every context, with and without the operand touch pass (which
     only reads: results cannot depend on it)."""
-    monkeypatch.setenv("CSGN_MUL_FLAT", "1")
-    monkeypatch.setenv("CSGN_MUL_TOUCH", str(touch))
+    knobs.set("CSGN_MUL_FLAT", "1")
+    knobs.set("CSGN_MUL_TOUCH", str(touch))
     dl = oracle.default_len(n)
     batch = 2
     for (t1, t2) in [(1, 2), (3, 5), (33, 65), (5, 300), (129, 130)]:
@@ -174,7 +174,7 @@ def test_mul_streaming_launches_default_dispatch(hip, oracle, n, t1, t2, batch):
         assert np.array_equal(ho[b * per:(b + 1) * per], want), (n, t1, t2, b)
 
 
-def test_mul_kernel_forms_fuzz(hip, oracle, monkeypatch):
+def test_mul_kernel_forms_fuzz(hip, oracle, knobs):
     """80 random (N, t1, t2, batch, arena slots) cases: the default dispatch, the LDS-tiled kernel
     and the flat kernel with and without the touch pass must produce identical words; every eighth
     case is also compared with the oracle."""
@@ -194,9 +194,9 @@ def test_mul_kernel_forms_fuzz(hip, oracle, monkeypatch):
         for env in ({}, {"CSGN_MUL_FLAT": "-1"}, {"CSGN_MUL_FLAT": "1", "CSGN_MUL_TOUCH": "3"},
                     {"CSGN_MUL_FLAT": "2", "CSGN_MUL_TOUCH": "0", "CSGN_MUL_XCD": "0"}):
             for k in ("CSGN_MUL_FLAT", "CSGN_MUL_TOUCH", "CSGN_MUL_XCD"):
-                monkeypatch.delenv(k, raising=False)
+                knobs.unset(k)
             for k, v in env.items():
-                monkeypatch.setenv(k, v)
+                knobs.set(k, v)
             outs.append(hip.mul_uniform(n, batch, t1, t2, L, R, out_slots=slots).clone())
         for o in outs[1:]:
             assert torch.equal(outs[0], o), (n, t1, t2, batch, slots)
@@ -209,11 +209,11 @@ def test_mul_kernel_forms_fuzz(hip, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("m,ti,nt", [(1, 64, 0), (2, 16, 1), (4, 7, 0), (8, 64, 1), (4, 1000, 1)])
-def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, monkeypatch, m, ti, nt):
-    monkeypatch.setenv("CSGN_MUL_FLAT", "-1")
-    monkeypatch.setenv("CSGN_MUL_M", str(m))
-    monkeypatch.setenv("CSGN_MUL_TI", str(ti))
-    monkeypatch.setenv("CSGN_MUL_NT", str(nt))
+def test_mul_tiled_tuning_knobs_do_not_change_results(hip, oracle, knobs, m, ti, nt):
+    knobs.set("CSGN_MUL_FLAT", "-1")
+    knobs.set("CSGN_MUL_M", str(m))
+    knobs.set("CSGN_MUL_TI", str(ti))
+    knobs.set("CSGN_MUL_NT", str(nt))
     n = 1247
     dl = 20
     for (t1, t2) in [(100, 77), (64, 128), (257, 33)]:
@@ -629,12 +629,12 @@ def test_permute_all_word_counts(hip, oracle, n):
 
 @pytest.mark.parametrize("n", [1, 31, 63, 64, 65, 130, 1247, 1280, 4096, 4100, 8192, 10000])
 @pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot"])
-def test_permute_kernel_forms(hip, oracle, monkeypatch, n, form):
+def test_permute_kernel_forms(hip, oracle, knobs, n, form):
     """Bit-plane form (64 terms per wave, 64x64 bit transposes; 16- and 8-byte staging) against
     the ballot form and the oracle, on batches that leave ragged last waves; strided first-term
     input and per-term mode."""
-    monkeypatch.setenv("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
-    monkeypatch.setenv("CSGN_PERM_NARROW", "1" if form == "planes-narrow" else "0")
+    knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
+    knobs.set("CSGN_PERM_NARROW", "1" if form == "planes-narrow" else "0")
     dl = oracle.default_len(n)
     rng = np.random.default_rng(1000 + n)
     perm = rng.permutation(n).astype(np.uint64)
@@ -657,7 +657,7 @@ def test_permute_kernel_forms(hip, oracle, monkeypatch, n, form):
     assert np.array_equal(hip.download(hip.permute_uniform(n, 128, 1, once, inv)), w)
 
 
-def test_permute_forms_fuzz(hip, oracle, monkeypatch):
+def test_permute_forms_fuzz(hip, oracle, knobs):
     """120 random (N, batch, terms per input, per-term mode) cases, some with out-of-range
     permutation entries ("no source"): the bit-plane kernel with 16- and 8-byte staging and the
     ballot kernel must agree word for word; every tenth case is also checked against the oracle."""
@@ -676,8 +676,8 @@ def test_permute_forms_fuzz(hip, oracle, monkeypatch):
         W = hip.synth_fill(it, n, 0, batch * terms_in * dl)
         outs = []
         for form in ("planes", "narrow", "ballot"):
-            monkeypatch.setenv("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
-            monkeypatch.setenv("CSGN_PERM_NARROW", "1" if form == "narrow" else "0")
+            knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
+            knobs.set("CSGN_PERM_NARROW", "1" if form == "narrow" else "0")
             outs.append(hip.permute_uniform(n, batch, terms_in, W, dperm, per_term=per_term).clone())
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (n, batch, terms_in, per_term)
         if it % 10 == 3:                              # a true permutation (it % 5 != 0): oracle too
@@ -691,10 +691,10 @@ def test_permute_forms_fuzz(hip, oracle, monkeypatch):
 
 @pytest.mark.parametrize("n,d", [(8320, 8), (8250, 5), (1247, 16), (193, 6), (704, 9), (1088, 7)])
 @pytest.mark.parametrize("loop", [0, 1])
-def test_decrypt_kernel_forms(hip, oracle, monkeypatch, n, d, loop):
+def test_decrypt_kernel_forms(hip, oracle, knobs, n, d, loop):
     """Both pass-1 forms (one-unit-per-lane workgroups of whole terms; looping 256-term
     workgroups for term sizes that do not pack into <=1024 lanes) on awkward term sizes."""
-    monkeypatch.setenv("CSGN_DEC_LOOP", str(loop))
+    knobs.set("CSGN_DEC_LOOP", str(loop))
     key = make_key(n, d, 13)
     dmask = hip.upload(hip.key_mask(n, key))
     for terms in (1, 7, 8, 9, 63, 64, 65, 300, 1031):
@@ -772,7 +772,7 @@ def test_largest_supported_term_and_rejection(hip, oracle):
 
 
 @pytest.mark.parametrize("flat", ["-1", "1"])
-def test_largest_single_product_index_edges(hip, monkeypatch, flat):
+def test_largest_single_product_index_edges(hip, knobs, flat):
     """One 16384 x 13107-term product at N=1247: 4 294 901 760 output words (34 GB), just under the
     documented 2^32-word limit and 2 147 450 880 sixteen-byte units, just under 2^31 -- the
     index arithmetic of both all-pairs kernels at its edge.  Sixty-odd whole rows (ends, rows at the
@@ -780,7 +780,7 @@ def test_largest_single_product_index_edges(hip, monkeypatch, flat):
     bitwise_and (independent of the kernels); one more left term is refused."""
     import torch
     from csgn_amd.capi import CsgnError
-    monkeypatch.setenv("CSGN_MUL_FLAT", flat)
+    knobs.set("CSGN_MUL_FLAT", flat)
     n, dl, t1, t2 = 1247, 20, 16384, 13107
     assert t1 * t2 * dl < 2**32 <= (t1 + 1) * t2 * dl
     L = hip.synth_fill(31, n, 0, t1 * dl)
@@ -954,14 +954,14 @@ ENC_FORMS = {"seg": {}, "lds": {"CSGN_ENC_LDS": "1"}}
 
 
 @pytest.mark.parametrize("form", sorted(ENC_FORMS))
-def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, monkeypatch, form):
+def test_encrypt_kernel_forms_reproduce_reference(hip, oracle, kat, knobs, form):
     """Both encrypt kernels (register/ballot segments; LDS-staged general form) against the genuine
     reference's fresh ciphertexts, plus agreement of their device-RNG streams on several contexts
     (even and odd dL, term sizes that do and do not pack into segments)."""
     def use(f):
-        monkeypatch.delenv("CSGN_ENC_LDS", raising=False)
+        knobs.unset("CSGN_ENC_LDS")
         for k, v in ENC_FORMS[f].items():
-            monkeypatch.setenv(k, v)
+            knobs.set(k, v)
     use(form)
     test_encrypt_explicit_reproduces_reference_ciphertexts(hip, oracle, kat)
     for n, d in [(1247, 16), (4096, 32), (65, 4), (63, 4), (130, 5), (8192, 8)]:
@@ -1078,10 +1078,10 @@ def test_fuzz_random_operation_sequences(hip, oracle, n, d, seed):
 
 @pytest.mark.parametrize("n,d", [(1247, 16), (63, 4), (4096, 32)])
 @pytest.mark.parametrize("force_flat", [0, 1])
-def test_ragged_skewed_batches(hip, oracle, monkeypatch, n, d, force_flat):
+def test_ragged_skewed_batches(hip, oracle, knobs, n, d, force_flat):
     """Skewed CSR batches (one large pair among many tiny and empty ones, runs of empty pairs
     longer than a workgroup) through both ragged multiply kernels and the ragged add."""
-    monkeypatch.setenv("CSGN_RAGGED_FLAT", str(force_flat))
+    knobs.set("CSGN_RAGGED_FLAT", str(force_flat))
     dl = oracle.default_len(n)
     rng = np.random.default_rng(n + force_flat)
     t1s = [1, 0, 0, 90, 1] + [0] * 300 + [2, 3] + [1] * 40 + [0, 7]
@@ -1243,7 +1243,7 @@ def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     lib.csgn_circuit_destroy(c)
 
 
-def test_ragged_mul_sliced_with_operand_touch(hip, oracle, monkeypatch):
+def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     """A ragged product above 1 GiB (7 000 pairs of 20..44 x 20..44 terms, N=1247) goes in slices, each
     preceded by the device-side operand touch; identical to the unsliced run, sampled pairs equal
     the oracle, including pairs that straddle a slice boundary."""
@@ -1258,11 +1258,11 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, monkeypatch):
     L = hip.synth_fill(51, n, 0, int(offL[-1]) * dl)
     R = hip.synth_fill(52, n, 0, int(offR[-1]) * dl)
     dOL, dOR = hip.upload(offL), hip.upload(offR)
-    monkeypatch.setenv("CSGN_RAGGED_FLAT", "1")
-    monkeypatch.setenv("CSGN_RAGGED_TOUCH", "0")
+    knobs.set("CSGN_RAGGED_FLAT", "1")
+    knobs.set("CSGN_RAGGED_TOUCH", "0")
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
     ref = ref.clone()
-    monkeypatch.setenv("CSGN_RAGGED_TOUCH", "1")
+    knobs.set("CSGN_RAGGED_TOUCH", "1")
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
     mo = hip.download(off)
@@ -1276,7 +1276,7 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, monkeypatch):
         assert np.array_equal(got, want), b
 
 
-def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
+def test_ragged_forms_fuzz(hip, oracle, knobs):
     """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
     ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
     prefetch off / 32 / 5000 pairs ahead, and through the default dispatch: identical words; every
@@ -1305,9 +1305,9 @@ def test_ragged_forms_fuzz(hip, oracle, monkeypatch):
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "8", "CSGN_RAGGED_PF": "32"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "16", "CSGN_RAGGED_PF": "5000"}):
             for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF"):
-                monkeypatch.delenv(k, raising=False)
+                knobs.unset(k)
             for k, v in env.items():
-                monkeypatch.setenv(k, v)
+                knobs.set(k, v)
             m, moff = hip.mul_ragged(n, L, dOL, R, dOR)
             a, aoff = hip.add_ragged(n, L, dOL, R, dOR, total_terms_out=tot_add)
             if ref_mul is None:

@@ -4,6 +4,7 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from csgn_amd.batch import HipPath
+from csgn_amd import capi
 hip = HipPath(0)
 def timed(fn, rounds=9):
     fn(); torch.cuda.synchronize(); ts=[]
@@ -20,7 +21,7 @@ for n,d in [(1247,16),(4096,32)]:
         res={}
         for rnd in range(2):
             for form in ("0","1"):
-                os.environ["CSGN_DEC_LOOP"]=form
+                capi.set_tuning("dec_loop", form)
                 t=timed(lambda: hip.decrypt_uniform(n,batch,terms,W,dmask))
                 res.setdefault(form,[]).append(batch*terms*8*dl/t/1e9)
         print(f"N={n} T={terms} batch={batch}: seg {res['0']} GB/s | loop {res['1']} GB/s", flush=True)

@@ -5,6 +5,7 @@ import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from csgn_amd.batch import HipPath
+from csgn_amd import capi
 
 hip = HipPath(0)
 
@@ -23,8 +24,8 @@ for n, batch in [(1247, 1 << 20), (1247, 1 << 16), (4096, 1 << 18), (130, 1 << 2
     perm = hip.upload(np.random.default_rng(3).permutation(n).astype(np.uint32))
     row = []
     for form in ("planes", "narrow", "ballot") * 2:
-        os.environ["CSGN_PERM_BALLOT"] = "1" if form == "ballot" else "0"
-        os.environ["CSGN_PERM_NARROW"] = "1" if form == "narrow" else "0"
+        capi.set_tuning("perm_ballot", form == "ballot")
+        capi.set_tuning("perm_narrow", form == "narrow")
         t = timed(lambda: hip.permute_uniform(n, batch, 1, W, perm))
         row.append("%s %.0f" % (form, batch * 2 * 8 * dl / t / 1e9))
     print(f"N={n} batch={batch}: " + " | ".join(row), flush=True)

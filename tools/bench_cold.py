@@ -8,6 +8,7 @@ import argparse, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from csgn_amd.batch import HipPath
+from csgn_amd import capi
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="FLAT=-1;FLAT=-1,TOUCH=1;FLAT=1,PF_KB=0;FLAT=1,TOUCH=1,PF_KB=0;FLAT=1,TOUCH=3,PF_KB=0")
@@ -19,12 +20,11 @@ KNOBS = ("FLAT", "TOUCH", "PF_KB", "XCD", "M", "TI")
 
 
 def setenv(variant):
-    for k in KNOBS:
-        os.environ.pop("CSGN_MUL_" + k, None)
+    capi.reset_tuning()
     for kv in variant.split(","):
         if kv:
             k, v = kv.split("=")
-            os.environ["CSGN_MUL_" + k] = v
+            capi.set_tuning("mul_" + k, v)
 
 
 for shape in args.shapes.split(";"):

@@ -4,6 +4,7 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from csgn_amd.batch import HipPath, check
+from csgn_amd import capi
 CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
 VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no slice touch',{'CSGN_RAGGED_TOUCH':'0'}),('cold, no touch, no prefetch',{'CSGN_RAGGED_TOUCH':'0','CSGN_RAGGED_PF':'0'}),('same, no touch',{'NSETS':'1','CSGN_RAGGED_TOUCH':'0'})]
@@ -38,9 +39,9 @@ for name,t1s,t2s in [
     sets=[(L,R)]+[(hip.synth_fill(10+k,n,0,int(offL[-1])*dl), hip.synth_fill(20+k,n,0,int(offR[-1])*dl)) for k in range(2)]
     row=[]
     for label,env in VARIANTS:
-        for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF","CSGN_RAGGED_TOUCH"):
-            os.environ.pop(k,None)
-        os.environ.update({k:v for k,v in env.items() if k.startswith('CSGN')})
+        capi.reset_tuning()
+        for k,v in env.items():
+            if k.startswith('CSGN'): capi.set_tuning(k, v)
         NSETS[0]=int(env.get('NSETS','3'))
         turn=[0]
         def one():
@@ -58,8 +59,7 @@ for name,t1s,t2s in [
         else:
             t=timed(one, rounds=9)
         row.append(f"{label}: {alg/t/1e9:6.0f}")
-    for k in ("CSGN_RAGGED_C","CSGN_RAGGED_PF","CSGN_RAGGED_TOUCH"):
-        os.environ.pop(k,None)
+    capi.reset_tuning()
     print(f"   kernel only, GB/s   " + "  ".join(row), flush=True)
     del sets
     del out
@@ -67,7 +67,7 @@ for name,t1s,t2s in [
     tot=int(offL[-1]+offR[-1])
     row=[]
     for ch in CHUNKS:
-        os.environ["CSGN_RAGGED_C"]=str(ch)
+        capi.set_tuning("ragged_c", ch)
         t=timed(lambda: hip.add_ragged(n,L,dL_,R,dR_, total_terms_out=tot))
         row.append(f"C={ch}: {alg/t/1e9:6.0f}")
     print(f"add_ragged {name:<32} GB/s (alloc + kernel)   " + "  ".join(row), flush=True)

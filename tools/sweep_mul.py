@@ -14,7 +14,7 @@ import statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from csgn_amd.batch import HipPath
-from csgn_amd.capi import check
+from csgn_amd.capi import check, set_tuning
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=256)
@@ -50,13 +50,9 @@ def timed(fn):
 
 
 def run_mul(m, ti, nt, flat=0, bs=0, xcd=1, pfkb=-1):
-    if pfkb >= 0:
-        os.environ["CSGN_MUL_PF_KB"] = str(pfkb)
-    else:
-        os.environ.pop("CSGN_MUL_PF_KB", None)
-    os.environ["CSGN_MUL_XCD"] = str(xcd)
-    os.environ["CSGN_MUL_M"], os.environ["CSGN_MUL_TI"], os.environ["CSGN_MUL_NT"] = str(m), str(ti), str(nt)
-    os.environ["CSGN_MUL_FLAT"], os.environ["CSGN_MUL_BS"] = str(flat), str(bs)
+    for k, v in (("mul_pf_kb", pfkb), ("mul_xcd", xcd), ("mul_m", m), ("mul_ti", ti), ("mul_nt", nt),
+                 ("mul_flat", flat), ("mul_bs", bs)):
+        set_tuning(k, v)
     hip.mul_uniform(n, args.pairs, T, T, L, R, out=arena, out_slots=args.slots)
 
 
