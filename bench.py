@@ -13,8 +13,15 @@ HBM when the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, every rank owns `batch` pairs (weak scaling) and its own arena;
-the only exchange is an all_gather (RCCL over xGMI) of the per-pair result term counts at the
-end of every step, inside the timed region.
+the only exchange is an all-gather (RCCL over xGMI) of the per-pair result term counts at the
+end of every step, inside the timed region.  `python bench.py --gpus N` with no WORLD_SIZE in the
+environment starts the N ranks itself: the parent makes no GPU call, checks that N devices are
+visible (exit 2 otherwise -- never a silent fall back to fewer GPUs) and runs
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a child process.  Under an
+external torchrun, --gpus must equal WORLD_SIZE (exit 2 otherwise).
+The gather goes through the native C ABI (csgn_comm_gather_counts of libcsgn_shard.so ->
+ncclAllGather, include/csgn_shard.h) on the launch stream; if that communicator cannot be formed
+the same gather runs through torch.distributed's RCCL backend, and `config.collective` says which.
 
 Rank 0 prints ONE JSON line (contract in the task description), including
   "roofline":     algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak
@@ -57,7 +64,37 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise RCCL and run the term-count all-gather even with one rank "
                          "(exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--collective", choices=["native", "torch"], default="native",
+                    help="native: csgn_comm_gather_counts (libcsgn_shard.so, ncclAllGather called directly); "
+                         "torch: torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the rank processes through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--verify-slots", type=int, default=8, help="arena slots compared with the oracle after timing")
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """Parent of an N-rank run: no GPU call is made here (torch.cuda.device_count() does not
+    initialise the device on this image); the ranks are fresh child processes."""
+    import socket
+    import subprocess
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but {visible} device(s) visible; refusing to run "
+              f"on fewer GPUs than asked", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("# bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(terms: int, budget_s: float):
@@ -147,20 +184,33 @@ def cpu_baseline_all_cores(terms: int, per_core_rate: float, budget_s: float):
     }
 
 
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) of the multiply kernels' source: ties a PMC capture to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("csgn_mul.hip", "csgn_device.h", "csgn_common.h"):
+        with open(os.path.join(ROOT, "csgn_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel: str, terms: int, pairs_per_launch: float):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile
-    (profiles/traffic_current.json, produced by tools/prof_pmc.sh + tools/pmc_summary.py).
-    Returned only when it was measured on this exact launch shape; otherwise None."""
+    (profiles/traffic_current.json, produced by tools/prof_pmc.sh + tools/pmc_summary.py: separate
+    rocprofv3 --pmc passes for WRITE_SIZE and FETCH_SIZE).  Counters cannot be read from inside the
+    process being timed, so this is a recorded measurement; it is returned only when it was taken on
+    this exact launch shape AND on the kernel source this run was built from, otherwise None."""
     path = os.path.join(ROOT, "profiles", "traffic_current.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     if (t.get("kernel") == kernel and t.get("n_bits") == N_BITS and t.get("terms") == terms
-            and t.get("pairs_per_launch") == pairs_per_launch):
-        return t.get("hbm_bytes_per_launch")
-    return None
+            and t.get("pairs_per_launch") == pairs_per_launch
+            and t.get("kernel_source_sha16") == kernel_source_hash()):
+        return t.get("hbm_bytes_per_launch"), t.get("captured", "profiles/traffic_current.json")
+    return None, None
 
 
 def main():
@@ -168,26 +218,37 @@ def main():
         _cpu_worker((int(sys.argv[2]), int(sys.argv[3])))
         return
     args = parse_args()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from csgn_amd.batch import HipPath
-    from csgn_amd.shard import gather_term_counts, shard_range
-
+    in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not in_rank and (args.gpus > 1 or args.spawn):
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}; refusing to run",
+                  file=sys.stderr)
+        sys.exit(2)
+    import ctypes
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csgn_amd import capi
+    from csgn_amd.batch import HipPath
+    from csgn_amd.shard import gather_term_counts, shard_range
+
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     use_dist = world > 1 or args.force_collective
     if use_dist:
-        if world == 1:
+        if not in_rank:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     hip = HipPath(local_rank)
     dev = hip.device
@@ -209,30 +270,82 @@ def main():
     left = hip.synth_fill(SEED + 1, N_BITS, lo * words_per_operand, batch * words_per_operand)
     right = hip.synth_fill(SEED + 2, N_BITS, lo * words_per_operand, batch * words_per_operand)
     arena = hip.empty_words(slots * words_per_product)
-    counts = torch.full((batch,), T * T, dtype=torch.int64, device=dev)   # result term counts
+    counts = hip.empty_words(batch)                       # result term counts of this shard
     gathered = torch.empty((total_pairs,), dtype=torch.int64, device=dev) if use_dist else None
+
+    # ---- the one exchange: all-gather of per-pair result term counts.  Native = the C ABI's own
+    # RCCL communicator (libcsgn_shard.so); the 128-byte ncclUniqueId travels over the process
+    # group torchrun already set up. ----
+    collective = "none"
+    comm = None
+    shard_lib = None
+    if use_dist:
+        collective = "torch.distributed.all_gather_into_tensor(result term counts) [RCCL]"
+        if args.collective == "native":
+            try:
+                shard_lib = capi.load_shard_library()
+                ident = [None]
+                if rank == 0:
+                    buf = ctypes.create_string_buffer(capi.CSGN_COMM_ID_BYTES)
+                    capi.check_shard(shard_lib.csgn_comm_unique_id(buf))
+                    ident = [bytes(buf.raw)]
+                dist.broadcast_object_list(ident, src=0, device=dev)
+                h = ctypes.c_void_p()
+                capi.check_shard(shard_lib.csgn_comm_init_rank(ident[0], rank, world, local_rank, ctypes.byref(h)))
+                comm = h
+                collective = "csgn_comm_gather_counts -> ncclAllGather(result term counts) [RCCL, native C ABI]"
+            except Exception as e:           # a second RCCL path exists: say so and use it
+                print(f"# rank {rank}: native communicator unavailable ({e!r}); using torch.distributed", file=sys.stderr)
+                comm = None
+        ok_native = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok_native, op=dist.ReduceOp.MIN)      # all ranks must take the same path
+        if int(ok_native.item()) == 0 and comm is not None:
+            shard_lib.csgn_comm_destroy(comm)
+            comm = None
+        if comm is None:
+            collective = "torch.distributed.all_gather_into_tensor(result term counts) [RCCL]"
     torch.cuda.synchronize()
 
-    def step():
-        hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
-        if use_dist:
+    def gather():
+        if comm is not None:
+            capi.check_shard(shard_lib.csgn_comm_gather_counts(comm, counts.data_ptr(), total_pairs,
+                                                               gathered.data_ptr(), hip.stream))
+        else:
             gather_term_counts(counts, total_pairs, out=gathered, force=True)
+
+    def product_counts():
+        # per-pair result term counts of this step's products (newlen/dL, src/Ciphertext.cpp:146)
+        if shard_lib is not None:
+            capi.check_shard(shard_lib.csgn_shard_product_counts(batch, None, None, T, T, counts.data_ptr(), hip.stream))
+        else:
+            counts.fill_(T * T)
+
+    def step(e_mul=None, e_step=None):
+        if e_step:
+            e_step[0].record()
+        if e_mul:
+            e_mul[0].record()
+        hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
+        if e_mul:
+            e_mul[1].record()
+        if use_dist:
+            product_counts()
+            gather()
+        if e_step:
+            e_step[1].record()
 
     for _ in range(args.warmup):
         step()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev_mul = [mk() for _ in range(args.steps)]
+    ev_step = [mk() for _ in range(args.steps)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        hip.mul_uniform(N_BITS, batch, T, T, left, right, out=arena, out_slots=slots)
-        ev[k][1].record()
-        if use_dist:
-            gather_term_counts(counts, total_pairs, out=gathered, force=True)
+        step(ev_mul[k], ev_step[k])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -245,7 +358,9 @@ def main():
 
     # kernel time from HIP events on the launch stream: each bracket holds launches_per_step
     # back-to-back launches of the all-pairs kernel
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev)
+    mul_ms = [a.elapsed_time(b) for a, b in ev_mul]
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev_step)       # this rank's whole steps (mul + exchange)
+    kernel_ms = sum(mul_ms)
     n_launches = launches_per_step * args.steps
     avg_launch_s = kernel_ms / 1e3 / n_launches
     # the kernel(s) the library dispatches this shape to ("k_touch+k_mul_flat": the operand touch
@@ -254,20 +369,30 @@ def main():
     kernel_name = hip.lib.csgn_mul_uniform_kernel(N_BITS, batch, T, T).decode()
     achieved = pairs_per_launch * bytes_per_mul / avg_launch_s
 
-    # ---- validity: the arena still holds the last `slots` products; check sampled ones ----
+    # ---- validity: the arena still holds the last `slots` products; compare slots spread over the
+    # whole arena (first, last and evenly spaced ones) with the oracle ----
     verified = None
+    verified_slots = []
     if not args.no_verify and rank == 0:
         from oracle.binding import Oracle
         orc = Oracle()
         ok = True
         first_of_last = (launches_per_step - 1) * slots
-        for slot in sorted({0, (batch - first_of_last) - 1}):
-            p = lo + first_of_last + slot                      # global pair index
+        live = batch - first_of_last                           # slots rewritten by the last launch
+        want_n = max(1, min(args.verify_slots, slots))
+        picks = sorted({int(round(i * (slots - 1) / max(1, want_n - 1))) for i in range(want_n)} | {0, slots - 1})
+        for slot in picks:
+            # the pair that wrote this slot last: in the last launch if it reached the slot, else one launch earlier
+            p_local = first_of_last + slot if slot < live else first_of_last - slots + slot
+            if p_local < 0:
+                continue
+            p = lo + p_local                                   # global pair index
             a = orc.synth(SEED + 1, N_BITS, p * words_per_operand, words_per_operand)
             b = orc.synth(SEED + 2, N_BITS, p * words_per_operand, words_per_operand)
             want, _ = orc.mul(N_BITS, a, b)
             got = hip.digest(arena[slot * words_per_product:(slot + 1) * words_per_product])
             ok = ok and (got == orc.digest(want))
+            verified_slots.append(slot)
         if use_dist:
             ok = ok and bool((gathered == T * T).all().item()) and gathered.numel() == world * batch
         verified = bool(ok)
@@ -277,6 +402,7 @@ def main():
     if rank == 0:
         total_mults = world * batch * args.steps
         value = total_mults / elapsed
+        traffic, traffic_src = measured_traffic(kernel_name, T, pairs_per_launch)
         out = {
             "metric": f"ciphertext-mults/sec (N={N_BITS}, {T}-term operands)",
             "value": value,
@@ -297,8 +423,12 @@ def main():
                 "n_bits": N_BITS, "terms": T, "batch_per_gpu": batch, "arena_slots": slots,
                 "pairs_per_launch": pairs_per_launch, "seed": SEED,
                 "bytes_per_mult": bytes_per_mul,
-                "collective": "all_gather(result term counts)" if use_dist else "none",
+                "collective": collective,
                 "verified_vs_oracle": verified,
+                "verified_slots": verified_slots,
+                "step_ms_rank0": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1],
+                                  "n": len(step_ms)},
+                "value_from_median_step": world * batch / (step_ms[len(step_ms) // 2] / 1e3),
             },
             "roofline": {
                 "bound": "hbm",
@@ -306,11 +436,14 @@ def main():
                 "peak": HBM_PEAK_BPS / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_BPS,
-                "traffic": measured_traffic(kernel_name, T, pairs_per_launch),
-                "traffic_unit": "bytes/launch (PMC, profiles/traffic_current.json)",
+                "traffic": traffic,
+                "traffic_unit": "bytes/launch (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes: %s)" % traffic_src
+                                if traffic is not None else None,
                 "algorithmic_bytes_per_launch": pairs_per_launch * bytes_per_mul,
                 "kernel": kernel_name,
                 "avg_launch_ms": avg_launch_s * 1e3,
+                "launch_ms": {"median": sorted(mul_ms)[len(mul_ms) // 2] / launches_per_step,
+                              "min": min(mul_ms) / launches_per_step, "max": max(mul_ms) / launches_per_step},
                 "launches": n_launches,
             },
         }
@@ -324,6 +457,8 @@ def main():
                     out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
 
+    if comm is not None:
+        shard_lib.csgn_comm_destroy(comm)
     if use_dist:
         dist.destroy_process_group()
 

@@ -1,6 +1,6 @@
 """Build the in-tree native libraries for gfx950.
 
-    python -m csgn_amd.build            # libcsgn_hip.so (+ libcertFHE.so once present)
+    python -m csgn_amd.build            # libcsgn_hip.so, libcsgn_shard.so, libcertFHE.so
 
 hipcc cross-compiles without a GPU; the .so files land in csgn_amd/lib/ (git-ignored, but
 they travel to the GPU box with the gpurun snapshot).
@@ -20,6 +20,7 @@ INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(LIBDIR, "libcsgn_hip.so")
 CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
+SHARD_LIB = os.path.join(LIBDIR, "libcsgn_shard.so")
 
 HIP_SOURCES = ["csgn_capi.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
                "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip", "csgn_tuning.cpp"]
@@ -53,6 +54,23 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return HIP_LIB
 
 
+def build_shard(force: bool = False, verbose: bool = False) -> str:
+    """libcsgn_shard.so (include/csgn_shard.h): batch partition + the RCCL all-gather of result term
+    counts.  Links librccl directly; kept apart from libcsgn_hip.so so that single-GPU users do
+    not map the 570 MB RCCL image."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, "csgn_shard.hip")
+    deps = [src, os.path.join(INCLUDE, "csgn_shard.h"), os.path.join(INCLUDE, "csgn_hip.h")]
+    if force or _stale(SHARD_LIB, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE,
+               "-o", SHARD_LIB, src, "-L" + rocm_lib, "-lrccl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SHARD_LIB
+
+
 def build_certfhe(force: bool = False, verbose: bool = False):
     """The drop-in certFHE:: C++ classes over the C ABI (csgn_amd/csrc/certfhe/*.cpp)."""
     src_dir = os.path.join(CSRC, "certfhe")
@@ -73,7 +91,7 @@ def build_certfhe(force: bool = False, verbose: bool = False):
 
 
 def build_all(force: bool = False, verbose: bool = False):
-    out = [build_hip(force, verbose)]
+    out = [build_hip(force, verbose), build_shard(force, verbose)]
     c = build_certfhe(force, verbose)
     if c:
         out.append(c)

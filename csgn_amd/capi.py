@@ -165,3 +165,56 @@ def tuning_names():
             return out
         out.append(n.decode())
         i += 1
+
+
+# -- libcsgn_shard.so (include/csgn_shard.h): partition + RCCL all-gather of term counts ---------
+_SHARD_LIB_PATH = os.path.join(PKG, "lib", "libcsgn_shard.so")
+CSGN_COMM_ID_BYTES = 128
+
+SHARD_SIGNATURES = {
+    "csgn_shard_last_error": (C.c_char_p, []),
+    "csgn_shard_range": (C.c_int, [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]),
+    "csgn_shard_owner": (C.c_int, [u64, u64, C.c_int]),
+    "csgn_comm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "csgn_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    "csgn_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "csgn_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "csgn_comm_destroy": (C.c_int, [vp]),
+    "csgn_comm_rank": (C.c_int, [vp]),
+    "csgn_comm_world": (C.c_int, [vp]),
+    "csgn_comm_device": (C.c_int, [vp]),
+    "csgn_comm_stream": (vp, [vp]),
+    "csgn_comm_gather_counts": (C.c_int, [vp, vp, u64, vp, vp]),
+    "csgn_comm_gather_bytes": (C.c_int, [vp, vp, u64, vp, vp]),
+    "csgn_comm_barrier": (C.c_int, [vp, vp]),
+    "csgn_shard_product_counts": (C.c_int, [u64, vp, vp, u64, u64, vp, vp]),
+}
+
+_shard_lib: Optional[C.CDLL] = None
+
+
+def load_shard_library() -> C.CDLL:
+    """Load libcsgn_shard.so (once).  It pulls in librccl; import torch first so that both bind to
+    the one RCCL / HIP runtime torch ships."""
+    global _shard_lib
+    if _shard_lib is not None:
+        return _shard_lib
+    if not os.path.exists(_SHARD_LIB_PATH):
+        raise FileNotFoundError(f"{_SHARD_LIB_PATH} is missing (python -m csgn_amd.build)")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(_SHARD_LIB_PATH)
+    for name, (res, args) in SHARD_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _shard_lib = lib
+    return lib
+
+
+def check_shard(rc: int) -> None:
+    if rc != CSGN_OK:
+        msg = load_shard_library().csgn_shard_last_error()
+        raise CsgnError(rc, msg.decode("utf-8", "replace") if msg else "")

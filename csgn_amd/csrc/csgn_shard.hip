@@ -1,0 +1,275 @@
+// csgn_shard.hip -- libcsgn_shard.so (include/csgn_shard.h): contiguous batch partition across the
+// GPUs of a node and the RCCL-over-xGMI all-gather of per-pair result term counts.  Links librccl
+// directly; no torch, no MPI.  One communicator per GPU, driven by one host thread (or process)
+// each.  Nothing here touches ciphertext words: products stay on the GPU that computed them.
+#include "csgn_shard.h"
+#include "csgn_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static_assert(CSGN_COMM_ID_BYTES == sizeof(ncclUniqueId), "id buffer must hold an ncclUniqueId");
+
+struct csgn_comm {
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1, device = 0;
+    int *d_flag = nullptr;          // 1-element buffer of the barrier all-reduce
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(e_ == hipErrorNoDevice ? CSGN_ERR_NO_DEVICE : CSGN_ERR_HIP,    \
+                        "%s: %s", #expr, hipGetErrorString(e_));                       \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                 \
+    do {                                                                               \
+        ncclResult_t r_ = (expr);                                                      \
+        if (r_ != ncclSuccess)                                                         \
+            return fail(CSGN_ERR_HIP, "%s: %s", #expr, ncclGetErrorString(r_));        \
+    } while (0)
+
+#define REQUIRE(cond, ...)                               \
+    do {                                                 \
+        if (!(cond))                                     \
+            return fail(CSGN_ERR_INVALID, __VA_ARGS__);  \
+    } while (0)
+
+inline uint64_t ceil_mul_div(uint64_t a, uint64_t b, uint64_t d)
+{
+    // ceil(a*b/d) with a 128-bit product (a = rank <= world = d, b = total pairs)
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    return (uint64_t)((p + d - 1) / d);
+}
+
+int finish_comm(csgn_comm *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&c->d_flag, sizeof(int)));
+    HIP_TRY(hipMemset(c->d_flag, 0, sizeof(int)));
+    return CSGN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_product_counts(uint64_t batch, const uint64_t *__restrict__ offL,
+                                                        const uint64_t *__restrict__ offR, uint64_t uniform,
+                                                        uint64_t *__restrict__ counts)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (b < batch)
+        counts[b] = offL ? (offL[b + 1] - offL[b]) * (offR[b + 1] - offR[b]) : uniform;
+}
+
+template <typename T>
+int gather(csgn_comm *c, const T *d_local, uint64_t total, T *d_all, ncclDataType_t dt, void *stream)
+{
+    REQUIRE(c && c->nccl, "null communicator");
+    if (total == 0)
+        return CSGN_OK;
+    REQUIRE(d_all, "d_all is null");
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    uint64_t lo = 0, hi = 0;
+    csgn_shard_range(total, c->rank, c->world, &lo, &hi);
+    REQUIRE(d_local || hi == lo, "d_local is null");
+    if (total % (uint64_t)c->world == 0) {
+        // equal shards: the slices of d_all are exactly the all-gather layout
+        NCCL_TRY(ncclAllGather(d_local, d_all, (size_t)(hi - lo), dt, c->nccl, s));
+        return CSGN_OK;
+    }
+    // uneven shards: rank r broadcasts its hi_r - lo_r counts into d_all[lo_r..hi_r); one group
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        uint64_t rlo = 0, rhi = 0;
+        csgn_shard_range(total, r, c->world, &rlo, &rhi);
+        if (rhi == rlo)
+            continue;
+        const ncclResult_t res = ncclBroadcast(r == c->rank ? (const void *)d_local : (const void *)(d_all + rlo),
+                                               d_all + rlo, (size_t)(rhi - rlo), dt, r, c->nccl, s);
+        if (res != ncclSuccess) {
+            (void)ncclGroupEnd();
+            return fail(CSGN_ERR_HIP, "ncclBroadcast: %s", ncclGetErrorString(res));
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return CSGN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *csgn_shard_last_error(void) { return g_err; }
+
+int csgn_shard_range(uint64_t total_pairs, int rank, int world, uint64_t *lo, uint64_t *hi)
+{
+    REQUIRE(lo && hi, "null output");
+    *lo = *hi = 0;
+    REQUIRE(world > 0 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    const uint64_t l = ceil_mul_div((uint64_t)rank, total_pairs, (uint64_t)world);
+    uint64_t h = ceil_mul_div((uint64_t)rank + 1, total_pairs, (uint64_t)world);
+    if (h > total_pairs)
+        h = total_pairs;
+    *lo = l;
+    *hi = h;
+    return CSGN_OK;
+}
+
+int csgn_shard_owner(uint64_t pair, uint64_t total_pairs, int world)
+{
+    if (world <= 0 || pair >= total_pairs)
+        return -1;
+    // the rank r with ceil(r*B/G) <= p < ceil((r+1)*B/G)  <=>  r = floor(p*G/B)
+    return (int)(((unsigned __int128)pair * (uint64_t)world) / total_pairs);
+}
+
+int csgn_comm_device_count(int *h_count)
+{
+    REQUIRE(h_count, "h_count is null");
+    *h_count = 0;
+    HIP_TRY(hipGetDeviceCount(h_count));
+    return CSGN_OK;
+}
+
+int csgn_comm_init_all(int ndev, const int *devices, csgn_comm **comms)
+{
+    REQUIRE(comms && ndev > 0, "bad arguments");
+    int have = 0;
+    HIP_TRY(hipGetDeviceCount(&have));
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        devs[i] = devices ? devices[i] : i;
+        REQUIRE(devs[i] >= 0 && devs[i] < have, "device %d not visible (have %d)", devs[i], have);
+        comms[i] = nullptr;
+    }
+    std::vector<ncclComm_t> nc(ndev, nullptr);
+    NCCL_TRY(ncclCommInitAll(nc.data(), ndev, devs.data()));
+    for (int i = 0; i < ndev; ++i) {
+        csgn_comm *c = new csgn_comm();
+        c->nccl = nc[i];
+        c->rank = i;
+        c->world = ndev;
+        c->device = devs[i];
+        comms[i] = c;
+        if (int rc = finish_comm(c))
+            return rc;
+    }
+    return CSGN_OK;
+}
+
+int csgn_comm_unique_id(unsigned char h_id[CSGN_COMM_ID_BYTES])
+{
+    REQUIRE(h_id, "h_id is null");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(h_id, &id, sizeof(id));
+    return CSGN_OK;
+}
+
+int csgn_comm_init_rank(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
+                        csgn_comm **comm)
+{
+    REQUIRE(h_id && comm, "null argument");
+    *comm = nullptr;
+    REQUIRE(world > 0 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+    int have = 0;
+    HIP_TRY(hipGetDeviceCount(&have));
+    REQUIRE(device >= 0 && device < have, "device %d not visible (have %d)", device, have);
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(&id, h_id, sizeof(id));
+    ncclComm_t nc = nullptr;
+    NCCL_TRY(ncclCommInitRank(&nc, world, id, rank));
+    csgn_comm *c = new csgn_comm();
+    c->nccl = nc;
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    if (int rc = finish_comm(c)) {
+        csgn_comm_destroy(c);
+        return rc;
+    }
+    *comm = c;
+    return CSGN_OK;
+}
+
+int csgn_comm_destroy(csgn_comm *c)
+{
+    if (!c)
+        return CSGN_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->nccl)
+        (void)ncclCommDestroy(c->nccl);
+    if (c->d_flag)
+        (void)hipFree(c->d_flag);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CSGN_OK;
+}
+
+int csgn_comm_rank(const csgn_comm *c) { return c ? c->rank : -1; }
+int csgn_comm_world(const csgn_comm *c) { return c ? c->world : 0; }
+int csgn_comm_device(const csgn_comm *c) { return c ? c->device : -1; }
+void *csgn_comm_stream(const csgn_comm *c) { return c ? c->stream : nullptr; }
+
+int csgn_comm_gather_counts(csgn_comm *c, const uint64_t *d_local, uint64_t total_pairs, uint64_t *d_all,
+                            void *stream)
+{
+    return gather<uint64_t>(c, d_local, total_pairs, d_all, ncclUint64, stream);
+}
+
+int csgn_comm_gather_bytes(csgn_comm *c, const uint8_t *d_local, uint64_t total_pairs, uint8_t *d_all,
+                           void *stream)
+{
+    return gather<uint8_t>(c, d_local, total_pairs, d_all, ncclUint8, stream);
+}
+
+int csgn_comm_barrier(csgn_comm *c, void *stream)
+{
+    REQUIRE(c && c->nccl, "null communicator");
+    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    NCCL_TRY(ncclAllReduce(c->d_flag, c->d_flag, 1, ncclInt32, ncclSum, c->nccl, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return CSGN_OK;
+}
+
+int csgn_shard_product_counts(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
+                              uint64_t t1, uint64_t t2, uint64_t *d_counts, void *stream)
+{
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_counts, "d_counts is null");
+    REQUIRE((d_off_left == nullptr) == (d_off_right == nullptr), "pass both offset arrays or neither");
+    REQUIRE(batch < (1ull << 40), "batch too large");
+    const uint64_t blocks = (batch + 255) / 256;
+    REQUIRE(blocks < (1ull << 24), "batch too large for one launch");
+    k_product_counts<<<(unsigned)blocks, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        batch, d_off_left, d_off_right, t1 * t2, d_counts);
+    HIP_TRY(hipGetLastError());
+    return CSGN_OK;
+}
+
+} // extern "C"

@@ -546,6 +546,43 @@ def test_golden_large_product_digests(hip, oracle, kat):
         assert np.array_equal(host[1], words(case["last_words"]))
 
 
+def test_timed_kernel_pair_at_the_timed_shape(hip, oracle, kat):
+    """The kernels bench.py times (k_touch + k_mul_flat), at the timed shape (1024x1024 terms,
+    N=1247), streamed through an arena smaller than the batch as bench.py does: 16 pairs (5.2 MB of
+    operands, so the default dispatch IS the touch + flat pair), 6 slots, so the call is cut into
+    launches of 6, 6 and 4 pairs and slots wrap.  EVERY surviving product is compared with the
+    oracle's digest, and one of them is the golden 1024x1024 product of the genuine reference
+    (tests/golden/csgn_kat.json digest[2]).  Reference: src/Ciphertext.cpp:146-163."""
+    n, t, dl, B, slots = 1247, 1024, 20, 16, 6
+    assert hip.lib.csgn_mul_uniform_kernel(n, B, t, t).decode() == "k_touch+k_mul_flat"
+    case = [c for c in kat["digest"] if c["t1"] == 1024 and c["t2"] == 1024 and c["n"] == n][0]
+    opw, per = t * dl, t * t * dl
+    L = hip.synth_fill(31, n, 0, B * opw)
+    R = hip.synth_fill(32, n, 0, B * opw)
+    gq = 13                                                   # this pair is the golden one
+    L[gq * opw:(gq + 1) * opw] = hip.synth_fill(case["seed_a"], n, 0, opw)
+    R[gq * opw:(gq + 1) * opw] = hip.synth_fill(case["seed_b"], n, 0, opw)
+    arena = hip.empty_words(slots * per)
+    arena.fill_(-1)
+    hip.mul_uniform(n, B, t, t, L, R, out=arena, out_slots=slots)
+    hl, hr = hip.download(L), hip.download(R)
+    # launches: pairs 0-5, 6-11, 12-15 -> slots 0..3 hold pairs 12..15, slots 4, 5 still hold 10, 11
+    survivors = {0: 12, 1: 13, 2: 14, 3: 15, 4: 10, 5: 11}
+    for slot, q in survivors.items():
+        want, _ = oracle.mul(n, hl[q * opw:(q + 1) * opw], hr[q * opw:(q + 1) * opw])
+        got = arena[slot * per:(slot + 1) * per]
+        assert hip.digest(got) == oracle.digest(want), (slot, q)
+        if q == gq:
+            assert "%016x" % hip.digest(got) == case["digest"]
+            assert np.array_equal(hip.download(got[:4]), words(case["first_words"]))
+            assert np.array_equal(hip.download(got[-4:]), words(case["last_words"]))
+    # and word for word for two of them (first and wrapped slot)
+    for slot in (0, 5):
+        q = survivors[slot]
+        want, _ = oracle.mul(n, hl[q * opw:(q + 1) * opw], hr[q * opw:(q + 1) * opw])
+        assert np.array_equal(hip.download(arena[slot * per:(slot + 1) * per]), want)
+
+
 # ------------------------------------------------------- full-size, size-independent checks
 
 def test_full_size_product_row_structure_and_decrypt_homomorphism(hip, oracle):
