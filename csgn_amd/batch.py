@@ -186,6 +186,28 @@ class HipPath:
                                                seed & (2**64 - 1), _ptr(out), self.stream))
         return out[: batch * self.default_len(n_bits)]
 
+    def rng_from_seed(self, seed: int, rounds: int = 8) -> "capi.CsgnRng":
+        r = capi.CsgnRng()
+        check(self.lib.csgn_rng_from_seed(C.byref(r), seed & (2**64 - 1), rounds))
+        return r
+
+    def rng_from_os(self, rounds: int = 8) -> "capi.CsgnRng":
+        r = capi.CsgnRng()
+        check(self.lib.csgn_rng_from_os(C.byref(r), rounds))
+        return r
+
+    def encrypt_keyed(self, n_bits: int, d: int, plain: torch.Tensor, key: torch.Tensor, mask: torch.Tensor,
+                      rng: "capi.CsgnRng", first_ciphertext: int = 0,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Keyed (ChaCha) device-generator encrypt; ciphertext i draws stream position first_ciphertext + i."""
+        batch = plain.numel()
+        dl = self.default_len(n_bits)
+        if out is None:
+            out = self.empty_words(max(batch * dl, 1))
+        check(self.lib.csgn_encrypt_keyed(n_bits, d, batch, first_ciphertext, _ptr(plain), _ptr(key), _ptr(mask),
+                                          C.byref(rng), _ptr(out), self.stream))
+        return out[: batch * dl]
+
     # -- permutation --------------------------------------------------------------------
     def permute_uniform(self, n_bits: int, batch: int, terms_in: int, words: torch.Tensor,
                         perm: torch.Tensor, per_term: bool = False) -> torch.Tensor:

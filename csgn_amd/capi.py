@@ -64,6 +64,10 @@ SIGNATURES = {
     "csgn_compact_scratch_bytes": (C.c_size_t, [u64]),
     "csgn_compact_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_explicit": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp, vp]),
+    "csgn_rng_from_os": (C.c_int, [vp, C.c_uint32]),
+    "csgn_rng_from_seed": (C.c_int, [vp, u64, C.c_uint32]),
+    "csgn_encrypt_keyed_layout": (C.c_int, [u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "csgn_encrypt_keyed": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_device_rng": (C.c_int, [u64, u64, u64, vp, vp, vp, u64, vp, vp]),
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
     "csgn_synth_fill": (C.c_int, [u64, u64, u64, u64, vp, vp]),
@@ -87,6 +91,11 @@ SIGNATURES = {
     "csgn_tuning_name": (C.c_char_p, [C.c_int]),
     "csgn_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
 }
+
+
+class CsgnRng(C.Structure):
+    """csgn_rng of include/csgn_hip.h: ChaCha key / nonce / rounds of the keyed device generator."""
+    _fields_ = [("key", C.c_uint32 * 8), ("nonce", C.c_uint64), ("rounds", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CsgnError(RuntimeError):

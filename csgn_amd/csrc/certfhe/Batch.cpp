@@ -3,6 +3,8 @@
 
 #include "runtime.h"
 
+#include <cstring>
+
 namespace certFHE {
 
 using detail::DevicePayload;
@@ -23,29 +25,63 @@ CiphertextBatch::CiphertextBatch(const Context &c, uint64_t count, uint64_t term
 
 const uint64_t *CiphertextBatch::deviceValues() const { return payload ? payload->data() : nullptr; }
 
-CiphertextBatch CiphertextBatch::encrypt(const SecretKey &key, const std::vector<unsigned char> &bits,
-                                         uint64_t seed)
+namespace {
+// encrypt `bits` under `key` with the keyed device generator (csgn_encrypt_keyed)
+void encryptInto(uint64_t n_bits, uint64_t d, const uint64_t *key_indices, const uint64_t *device_mask,
+                 const std::vector<unsigned char> &bits, const csgn_rng &rng, uint64_t first, uint64_t *d_out)
 {
-    if (!key.certFHEContext)
-        throw std::logic_error("certFHE::CiphertextBatch::encrypt: key has no Context");
-    const Context &c = *key.certFHEContext;
-    key.ensureMask();
-    const uint64_t d = (uint64_t)key.length, count = bits.size();
-    CiphertextBatch out(c, count, 1);
-    if (count == 0)
-        return out;
+    const uint64_t count = bits.size();
     // staging: [key indices (d words)][plaintext bytes]
     std::vector<uint64_t> stage(d + (count + 7) / 8, 0);
     for (uint64_t i = 0; i < d; ++i)
-        stage[i] = key.s[i];
+        stage[i] = key_indices[i];
     memcpy(stage.data() + d, bits.data(), count);
     std::shared_ptr<DevicePayload> dstage = detail::uploadWords(stage.data(), stage.size());
-    detail::check(csgn_encrypt_device_rng(c.getN(), d, count,
-                                          reinterpret_cast<const uint8_t *>(dstage->data() + d),
-                                          dstage->data(), key.device_mask->data(), seed,
-                                          out.payload->data(), detail::stream()),
-                  "csgn_encrypt_device_rng");
+    detail::check(csgn_encrypt_keyed(n_bits, d, count, first,
+                                     reinterpret_cast<const uint8_t *>(dstage->data() + d), dstage->data(),
+                                     device_mask, &rng, d_out, detail::stream()),
+                  "csgn_encrypt_keyed");
+    // the staging block held the secret indices: wipe it before it returns to the block cache, and
+    // the host copy too (~SecretKey zeroises its own copies the same way, src/SecretKey.cpp:354-372)
+    detail::check(csgn_memset(dstage->ptr, 0, stage.size() * 8, detail::stream()), "csgn_memset");
     detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");
+    volatile uint64_t *wipe = stage.data();
+    for (size_t i = 0; i < stage.size(); ++i)
+        wipe[i] = 0;
+}
+} // namespace
+
+CiphertextBatch CiphertextBatch::encrypt(const SecretKey &key, const std::vector<unsigned char> &bits)
+{
+    if (!key.certFHEContext)
+        throw std::logic_error("certFHE::CiphertextBatch::encrypt: key has no Context");
+    key.ensureMask();
+    CiphertextBatch out(*key.certFHEContext, bits.size(), 1);
+    if (bits.empty())
+        return out;
+    csgn_rng rng;                      // fresh 256-bit generator key + nonce from the OS for every batch
+    detail::check(csgn_rng_from_os(&rng, 8), "csgn_rng_from_os");
+    encryptInto(key.certFHEContext->getN(), (uint64_t)key.length, key.s, key.device_mask->data(), bits, rng, 0,
+                out.payload->data());
+    volatile uint32_t *wipe = rng.key;
+    for (int i = 0; i < 8; ++i)
+        wipe[i] = 0;
+    return out;
+}
+
+CiphertextBatch CiphertextBatch::encrypt(const SecretKey &key, const std::vector<unsigned char> &bits,
+                                         uint64_t seed, uint64_t first_ciphertext)
+{
+    if (!key.certFHEContext)
+        throw std::logic_error("certFHE::CiphertextBatch::encrypt: key has no Context");
+    key.ensureMask();
+    CiphertextBatch out(*key.certFHEContext, bits.size(), 1);
+    if (bits.empty())
+        return out;
+    csgn_rng rng;
+    detail::check(csgn_rng_from_seed(&rng, seed, 8), "csgn_rng_from_seed");
+    encryptInto(key.certFHEContext->getN(), (uint64_t)key.length, key.s, key.device_mask->data(), bits, rng,
+                first_ciphertext, out.payload->data());
     return out;
 }
 

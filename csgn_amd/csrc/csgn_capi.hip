@@ -5,6 +5,9 @@
 #include "csgn_kernels.h"
 #include "csgn_tuning.h"
 
+#include <sys/random.h>
+
+#include <cerrno>
 #include <cstdarg>
 #include <vector>
 #include <cstdio>
@@ -521,8 +524,78 @@ int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
         return CSGN_OK;
     REQUIRE(d >= 1, "d must be >= 1");
     REQUIRE(d_plain && d_rnd && d_chosen && d_last && d_mask && d_out, "null device pointer");
-    HIP_TRY(csgn::encrypt(n_bits, d, batch, d_plain, (const u64 *)d_rnd, d_chosen, d_last, nullptr,
-                          (const u64 *)d_mask, 0, false, (u64 *)d_out, S(stream)));
+    HIP_TRY(csgn::encrypt(n_bits, d, batch, d_plain, (const u64 *)d_rnd, d_chosen, d_last,
+                          (const u64 *)d_mask, (u64 *)d_out, S(stream)));
+    return CSGN_OK;
+}
+
+int csgn_rng_from_os(csgn_rng *h_rng, uint32_t rounds)
+{
+    REQUIRE(h_rng, "h_rng is null");
+    REQUIRE(rounds == 8 || rounds == 12 || rounds == 20, "rounds must be 8, 12 or 20");
+    unsigned char buf[40];
+    size_t got = 0;
+    while (got < sizeof(buf)) {
+        const ssize_t r = getrandom(buf + got, sizeof(buf) - got, 0);
+        if (r < 0) {
+            if (errno == EINTR)
+                continue;
+            return fail(CSGN_ERR_INVALID, "getrandom failed: %s", strerror(errno));
+        }
+        got += (size_t)r;
+    }
+    memcpy(h_rng->key, buf, 32);
+    memcpy(&h_rng->nonce, buf + 32, 8);
+    h_rng->rounds = rounds;
+    h_rng->reserved = 0;
+    memset(buf, 0, sizeof(buf));
+    return CSGN_OK;
+}
+
+int csgn_rng_from_seed(csgn_rng *h_rng, uint64_t seed, uint32_t rounds)
+{
+    REQUIRE(h_rng, "h_rng is null");
+    REQUIRE(rounds == 8 || rounds == 12 || rounds == 20, "rounds must be 8, 12 or 20");
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t w = csgn_splitmix64(seed + CSGN_GOLDEN * (uint64_t)(i + 1));
+        h_rng->key[2 * i] = (uint32_t)w;
+        h_rng->key[2 * i + 1] = (uint32_t)(w >> 32);
+    }
+    h_rng->nonce = csgn_splitmix64(seed ^ 0xD1B54A32D192ED03ull);
+    h_rng->rounds = rounds;
+    h_rng->reserved = 0;
+    return CSGN_OK;
+}
+
+int csgn_encrypt_keyed_layout(uint64_t n_bits, uint32_t *h_units, uint32_t *h_passes, uint32_t *h_group)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(h_units && h_passes && h_group, "null output");
+    csgn::encrypt_keyed_layout(n_bits, h_units, h_passes, h_group);
+    return CSGN_OK;
+}
+
+int csgn_encrypt_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t first_ciphertext,
+                       const uint8_t *d_plain, const uint64_t *d_key, const uint64_t *d_mask,
+                       const csgn_rng *h_rng, uint64_t *d_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(h_rng, "h_rng is null");
+    REQUIRE(h_rng->rounds == 8 || h_rng->rounds == 12 || h_rng->rounds == 20, "rng rounds must be 8, 12 or 20");
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
+    REQUIRE(d_plain && d_key && d_mask && d_out, "null device pointer");
+    REQUIRE(first_ciphertext + batch >= first_ciphertext && first_ciphertext + batch < (1ull << 56),
+            "ciphertext index range too large");
+    hipError_t e = csgn::encrypt_keyed(n_bits, d, batch, first_ciphertext, d_plain, (const u64 *)d_key,
+                                       (const u64 *)d_mask, h_rng->key, h_rng->nonce, h_rng->rounds, nullptr,
+                                       (u64 *)d_out, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "batch too large for one launch");
+    HIP_TRY(e);
     return CSGN_OK;
 }
 
@@ -530,15 +603,10 @@ int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,
                             const uint8_t *d_plain, const uint64_t *d_key,
                             const uint64_t *d_mask, uint64_t seed, uint64_t *d_out, void *stream)
 {
-    if (int rc = check_n(n_bits))
+    csgn_rng rng;
+    if (int rc = csgn_rng_from_seed(&rng, seed, 8))
         return rc;
-    if (batch == 0)
-        return CSGN_OK;
-    REQUIRE(d >= 1, "d must be >= 1");
-    REQUIRE(d_plain && d_key && d_mask && d_out, "null device pointer");
-    HIP_TRY(csgn::encrypt(n_bits, d, batch, d_plain, nullptr, nullptr, nullptr, (const u64 *)d_key,
-                          (const u64 *)d_mask, seed, true, (u64 *)d_out, S(stream)));
-    return CSGN_OK;
+    return csgn_encrypt_keyed(n_bits, d, batch, 0, d_plain, d_key, d_mask, &rng, d_out, stream);
 }
 
 int csgn_permute_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms_in, int per_term,

@@ -21,12 +21,6 @@ __host__ __device__ inline u64 csgn_splitmix64(u64 z)
     return z ^ (z >> 31);
 }
 
-// Device-RNG word of the throughput encrypt mode (NOT the parity path, which takes its
-// randomness as an argument): 64 bits for (seed, word index).  Measured: a generator of two
-// 32-bit PCG hashes is no faster here and even a single multiply only lifts the kernel from 3.3 to
-// 4.0 TB/s, so the generator is not what bounds it.
-__host__ __device__ inline u64 csgn_rng_word(u64 seed, u64 idx) { return csgn_splitmix64(seed + CSGN_GOLDEN * (idx + 1)); }
-
 // Division of a 32-bit numerator by a launch-invariant divisor without the ~30-instruction
 // emulated udiv: q = (t + ((n - t) >> 1)) >> shift with t = mulhi(n, magic)
 // (round-up method of Granlund & Montgomery in its branch-free 32-bit form).

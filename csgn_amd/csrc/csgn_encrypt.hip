@@ -1,4 +1,4 @@
-// csgn_encrypt.hip -- encrypt: explicit-randomness (parity) and device-RNG (throughput) forms.
+// csgn_encrypt.hip -- encrypt: explicit-randomness (parity) form and keyed device-generator (ChaCha, throughput) form.
 // Hand-written CDNA4 (gfx950) HIP; shared helpers in csgn_device.h, design notes in DESIGN.md.
 #include "csgn_device.h"
 
@@ -14,25 +14,12 @@ namespace {
 // secret slot came out 1, else give it the spare random bit), then all lanes write the
 // tile out coalesced, OR-ing the key mask into plaintext-1 ciphertexts.
 // ---------------------------------------------------------------------------------------
-// Device-RNG draws of one ciphertext with plaintext 0 (throughput mode only): which of the D secret
-// positions is the chosen one (src/SecretKey.cpp:51) and the spare coin of :76.  One splitmix64
-// word: the high half picks the position by multiply-shift range reduction (no 64-bit modulo), the
-// low bit is the coin.
-__device__ inline void enc_draw(u64 seed, u64 c, const u64 *__restrict__ key, u64 D, u32 &pos, u32 &spare)
-{
-    const u64 r = csgn_splitmix64((seed ^ 0xD1B54A32D192ED03ull) + CSGN_GOLDEN * (c + 1));
-    pos = (u32)key[__umulhi((u32)(r >> 32), (u32)D)];
-    spare = (u32)r & 1u;
-}
-
-template <bool DEVRNG>
 __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 batch, u32 CB,
                                                  FastDiv ddL, const uint8_t *__restrict__ plain,
                                                  const u64 *__restrict__ rnd,
                                                  const u32 *__restrict__ chosen,
                                                  const uint8_t *__restrict__ last,
-                                                 const u64 *__restrict__ key,
-                                                 const u64 *__restrict__ mask, u64 seed,
+                                                 const u64 *__restrict__ mask,
                                                  u64 *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -50,7 +37,7 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
         const u32 c = csgn_fastdiv(u, ddL);
         const u32 k = u - c * dL;
         const u64 gw = c0 * dL + u;
-        u64 w = DEVRNG ? csgn_rng_word(seed, gw) : rnd[gw];
+        u64 w = rnd[gw];
         if (k == dL - 1)
             w &= tail;
         tile[u] = w;
@@ -61,16 +48,8 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
 
     if (tid < nc && !(plain[c0 + tid] & 1u)) {
         const u64 c = c0 + tid;
-        u64 pos;
-        u32 spare;
-        if (DEVRNG) {
-            u32 p32;
-            enc_draw(seed, c, key, D, p32, spare);
-            pos = p32;
-        } else {
-            pos = chosen[c];
-            spare = last[c] & 1u;
-        }
+        const u64 pos = chosen[c];
+        const u32 spare = last[c] & 1u;
         if (pos < n_bits) {
             const u32 wsel = (u32)(pos >> 6), bsel = 63u - (u32)(pos & 63);
             u64 *mine = tile + (size_t)tid * dL;
@@ -124,14 +103,13 @@ __global__ void __launch_bounds__(256) k_encrypt(u64 n_bits, u32 dL, u64 D, u64 
 // ciphertext hold 1?" (src/SecretKey.cpp:60-76) -- is decided from two __ballot bit strings in
 // LDS exactly like a decrypt verdict.  No staging of the words through LDS, 16-byte stores.
 
-template <typename Unit, int K, bool DEVRNG>
+template <typename Unit, int K>
 __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, FastDiv dU, u64 D, u64 batch,
                                                      u32 TB, const uint8_t *__restrict__ plain,
                                                      const Unit *__restrict__ rnd,
                                                      const u32 *__restrict__ chosen,
                                                      const uint8_t *__restrict__ last,
-                                                     const u64 *__restrict__ key,
-                                                     const Unit *__restrict__ mask, u64 seed,
+                                                     const Unit *__restrict__ mask,
                                                      Unit *__restrict__ out)
 {
     constexpr int VEC = sizeof(Unit) / 8;
@@ -152,14 +130,8 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
             const u64 c = c0 + tid;
             pl = plain[c] & 1u;
             if (!pl) {
-                if (DEVRNG) {
-                    u32 coin;
-                    enc_draw(seed, c, key, D, pos, coin);
-                    sp = (unsigned char)coin;
-                } else {
-                    pos = chosen[c];
-                    sp = last[c] & 1u;
-                }
+                pos = chosen[c];
+                sp = last[c] & 1u;
                 if (pos >= n_bits)
                     pos = 0xFFFFFFFFu;                         // invalid input: leave the words alone
             }
@@ -184,13 +156,7 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
         tk[j] = (t << 16) | k;
         m[j] = unit_to_words(mask[k]);
         const u64 g = min(c0 * U + local, last_unit);          // global unit index (clamped)
-        if (DEVRNG) {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q)
-                w[j].w[q] = csgn_rng_word(seed, g * VEC + q);
-        } else {
-            w[j] = unit_to_words(rnd[g]);
-        }
+        w[j] = unit_to_words(rnd[g]);
         if (k == U - 1)
             w[j].w[VEC - 1] &= tail;                           // padding bits of the last word stay 0
     }
@@ -256,23 +222,304 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Keyed device generator: ChaCha (D. J. Bernstein's block function, 64-bit counter + 64-bit nonce
+// layout, ROUNDS = 8, 12 or 20) in counter mode under a 256-bit SECRET key.  The output cannot be
+// inverted to the key or to other outputs (the round-1 generator, splitmix64 of seed + index, was a
+// bijection of its state: one mask-free ciphertext word gave away the seed and with it the secret
+// positions -- ADVICE r1).  Pure 32-bit add / xor / rotate: every instruction is full rate on the
+// CDNA4 VALU (v_add_u32, v_xor_b32, v_alignbit_b32), no quarter-rate multiplies.
+//
+// Keystream layout (restated independently in oracle/csgn_oracle.c): a ciphertext is U = ceil(dL/2)
+// 16-byte units; P = U / gcd(U, 256) and Gc = 256*P/U, so that a GROUP of Gc ciphertexts is exactly
+// P*256 units.  Unit j of ciphertext c (a GLOBAL index: shards of a batch see the same stream) is
+//     g = c / Gc,  r = (c % Gc)*U + j,  p = r / 256,  q = (r % 256) / 64,  L = r % 64
+//     32-bit words 4q..4q+3 of ChaCha(key, nonce, counter = (g*P + p)*64 + L)
+// i.e. the keystream is dealt out in 4 KiB tiles, lane L of a wave computes block L of the tile and
+// its four quarters are four consecutive coalesced 1 KiB stores.
+// ---------------------------------------------------------------------------------------
+struct EncKeyed {
+    u32 key[8];
+    u32 nonce_lo, nonce_hi;
+};
+
+__device__ inline u32 rotl32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+
+#define CSGN_QR(a, b, c, d)     \
+    a += b; d ^= a; d = rotl32(d, 16); \
+    c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  \
+    c += d; b ^= c; b = rotl32(b, 7)
+
+template <int ROUNDS>
+__device__ inline void chacha_block(const EncKeyed &k, u32 nonce_lo, u32 nonce_hi, u32 ctr_lo, u32 ctr_hi,
+                                    u32 (&x)[16])
+{
+    const u32 c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;   // "expand 32-byte k"
+    x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        x[4 + i] = k.key[i];
+    x[12] = ctr_lo; x[13] = ctr_hi; x[14] = nonce_lo; x[15] = nonce_hi;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r += 2) {
+        CSGN_QR(x[0], x[4], x[8], x[12]);
+        CSGN_QR(x[1], x[5], x[9], x[13]);
+        CSGN_QR(x[2], x[6], x[10], x[14]);
+        CSGN_QR(x[3], x[7], x[11], x[15]);
+        CSGN_QR(x[0], x[5], x[10], x[15]);
+        CSGN_QR(x[1], x[6], x[11], x[12]);
+        CSGN_QR(x[2], x[7], x[8], x[13]);
+        CSGN_QR(x[3], x[4], x[9], x[14]);
+    }
+    x[0] += c0; x[1] += c1; x[2] += c2; x[3] += c3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        x[4 + i] += k.key[i];
+    x[12] += ctr_lo; x[13] += ctr_hi; x[14] += nonce_lo; x[15] += nonce_hi;
+}
+#undef CSGN_QR
+
+// The draw of src/SecretKey.cpp:51 for ciphertext c in keyed mode: a separate ChaCha stream (nonce
+// with its top bit flipped), block counter = c, first output word range-reduced to [0, D).
+constexpr u32 kDrawDomain = 0x80000000u;
+
+template <int ROUNDS>
+__device__ inline u32 keyed_draw_pos(const EncKeyed &k, u32 nonce_lo, u32 nonce_hi, u64 c,
+                                     const u64 *__restrict__ key_idx, u32 D)
+{
+    u32 x[16];
+    chacha_block<ROUNDS>(k, nonce_lo, nonce_hi ^ kDrawDomain, (u32)c, (u32)(c >> 32), x);
+    return (u32)key_idx[__umulhi(x[0], D)];
+}
+
+struct EncWaveArgs {
+    EncKeyed rng;
+    const u64 *epoch;             // optional device word added to the nonce (circuits: bumped per replay)
+    const uint8_t *plain;         // batch bytes
+    const u64 *key_idx;           // D secret indices
+    const unit16 *mask;           // U units
+    unit16 *out;                  // batch*U units
+    u64 first_ct, batch;          // global index of plain[0] / out[0], ciphertext count
+    u64 group0, ngroups;          // first group and number of groups the launch covers
+    u32 U, Gc, D;
+    u32 tail_lo, tail_hi;         // the last word's valid-bit mask
+    FastDiv dU;
+};
+
+// One wave = one group of Gc ciphertexts = P passes of 256 units.  FULL: every ciphertext of the
+// group is inside [first_ct, first_ct + batch) (all but the first and last group of a launch).
+template <int ROUNDS, int P, bool FULL>
+__device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *lmask, u64 *cover, u32 lane, u64 group,
+                                     u32 nonce_lo, u32 nonce_hi)
+{
+    const u32 U = a.U;
+    const u64 cbase = group * a.Gc;                        // first ciphertext of the group (global index)
+    // valid ciphertexts of the group, as local indices [cl_lo, cl_hi)
+    u32 cl_lo = 0, cl_hi = a.Gc;
+    if (!FULL) {
+        cl_lo = cbase < a.first_ct ? (u32)(a.first_ct - cbase) : 0u;
+        const u64 end = a.first_ct + a.batch;
+        cl_hi = cbase + a.Gc > end ? (u32)(end - cbase) : a.Gc;
+    }
+    // out / plain addressed from the group's own origin (may lie before the buffers for a partial
+    // first group; only in-range elements are touched)
+    const long long origin = (long long)cbase - (long long)a.first_ct;
+    unit16 *outg = a.out + origin * (long long)U;
+    const uint8_t *plaing = a.plain + origin;
+
+    u32 cl = csgn_fastdiv(lane, a.dU), j = lane - cl * U;   // unit r = lane of pass 0, quarter 0
+    const u32 step_c = csgn_fastdiv(64u, a.dU), step_j = 64u - step_c * U;
+    const u64 blk0 = group * (u64)P * 64u + lane;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const u64 ctr = blk0 + (u64)p * 64u;
+        u32 x[16];
+        chacha_block<ROUNDS>(a.rng, nonce_lo, nonce_hi, (u32)ctr, (u32)(ctr >> 32), x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 r = (u32)p * 256u + (u32)q * 64u + lane;
+            const unit16 m = lmask[j];
+            const bool inr = FULL || (cl - cl_lo < cl_hi - cl_lo);
+            const u32 pl = plaing[FULL ? cl : min(max(cl, cl_lo), cl_hi - 1u)] & 1u;
+            unit16 v;
+            v.x = x[4 * q];
+            v.y = x[4 * q + 1];
+            v.z = x[4 * q + 2];
+            v.w = x[4 * q + 3];
+            if (j == U - 1u) {                              // padding bits of the last word stay 0
+                v.z &= a.tail_lo;
+                v.w &= a.tail_hi;
+            }
+            const bool cov = unit_covers(v, m);             // all secret positions of this unit came out 1
+            const u64 b = __ballot(cov);
+            if (lane == 0)
+                cover[p * 4 + q] = b;
+            const u32 pm = 0u - pl;                         // plaintext 1: OR the key mask in (src/SecretKey.cpp:44-45)
+            v.x |= m.x & pm;
+            v.y |= m.y & pm;
+            v.z |= m.z & pm;
+            v.w |= m.w & pm;
+            if (inr)
+                unit_store<unit16, true>(outg + r, v);
+            // the next unit of this lane is 64 further on
+            j += step_j;
+            cl += step_c;
+            if (j >= U) {
+                j -= U;
+                cl += 1u;
+            }
+        }
+    }
+}
+
+template <int ROUNDS, int P>
+__global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unit16 *lmask = reinterpret_cast<unit16 *>(smem_raw);                      // U units
+    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (size_t)a.U * 16u);    // 4 waves x (P*4 + 1) words
+
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (u32 k = tid; k < a.U; k += 256u)
+        lmask[k] = a.mask[k];
+    u64 *cover = cover_all + wave * (P * 4 + 1);
+    if (lane == 0)
+        cover[P * 4] = 0;                                   // pad word for the straddling shift
+    __syncthreads();
+
+    const u64 gi = (u64)blockIdx.x * 4u + wave;             // group of this wave, relative to group0
+    const bool active = gi < a.ngroups;
+    const u64 group = a.group0 + gi;
+    u32 nonce_lo = a.rng.nonce_lo, nonce_hi = a.rng.nonce_hi;
+    if (a.epoch) {
+        const u64 nn = (((u64)nonce_hi << 32) | nonce_lo) + *a.epoch;
+        nonce_lo = (u32)nn;
+        nonce_hi = (u32)(nn >> 32);
+    }
+    const u64 cbase = group * a.Gc;
+    const bool full = cbase >= a.first_ct && cbase + a.Gc <= a.first_ct + a.batch;
+    if (active) {
+        if (full)
+            encrypt_group<ROUNDS, P, true>(a, lmask, cover, lane, group, nonce_lo, nonce_hi);
+        else
+            encrypt_group<ROUNDS, P, false>(a, lmask, cover, lane, group, nonce_lo, nonce_hi);
+    }
+    __syncthreads();
+    if (!active)
+        return;
+    // src/SecretKey.cpp:51-76 for plaintext 0: if ALL D secret positions came out 1 the chosen one is
+    // cleared (the reference draws the chosen position first and forces it to 0 when the others are
+    // all 1; drawing every position and clearing the chosen one afterwards is the same distribution).
+    // Probability 2^-D per ciphertext, so this branch is almost never taken.
+    const u32 U = a.U;
+    for (u32 cl = lane; cl < a.Gc; cl += kWave) {
+        const u64 c = cbase + cl;
+        if (c < a.first_ct || c >= a.first_ct + a.batch)
+            continue;
+        bool all = true;
+        for (u32 bit = cl * U, left = U; left && all;) {
+            const u32 w = bit >> 6, sh = bit & 63u, take = min(left, 64u - sh);
+            const u64 need = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
+            all = ((cover[w] >> sh) & need) == need;
+            bit += take;
+            left -= take;
+        }
+        if (!all || (a.plain[c - a.first_ct] & 1u))
+            continue;
+        // with a single distinct secret position there are no "other" positions and the reference
+        // never clears (its v stays 0, src/SecretKey.cpp:55-76)
+        u32 secret_bits = 0;
+        for (u32 k = 0; k < 2u * U; ++k)
+            secret_bits += (u32)__popcll(reinterpret_cast<const u64 *>(a.mask)[k]);
+        if (secret_bits < 2u)
+            continue;
+        const u32 pos = keyed_draw_pos<ROUNDS>(a.rng, nonce_lo, nonce_hi, c, a.key_idx, a.D);
+        __threadfence();                                    // this wave's stores of the word have landed
+        u64 *word = reinterpret_cast<u64 *>(a.out) + (c - a.first_ct) * (u64)(2u * U) + (pos >> 6);
+        atomicAnd(reinterpret_cast<unsigned long long *>(word), ~(1ull << (63u - (pos & 63u))));
+    }
+}
+
+// General form of the keyed encrypt (any dL, any alignment): one lane per ciphertext walks its units
+// and evaluates the SAME keystream definition unit by unit (a whole ChaCha block per 16-byte unit,
+// so 4x the generator work of the wave kernel).  Used for term sizes whose group would need more
+// than 5 passes, for odd dL, and as the A/B partner of the wave kernel (knob enc_wave = 0).
+template <int ROUNDS>
+__global__ void __launch_bounds__(256) k_encrypt_keyed_ct(EncKeyed rng, const u64 *__restrict__ epoch,
+                                                          const uint8_t *__restrict__ plain,
+                                                          const u64 *__restrict__ key_idx,
+                                                          const u64 *__restrict__ mask, u64 *__restrict__ out,
+                                                          u64 first_ct, u64 batch, u32 dL, u32 U, u32 P, u32 Gc,
+                                                          u32 D, u64 tail)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= batch)
+        return;
+    u32 nonce_lo = rng.nonce_lo, nonce_hi = rng.nonce_hi;
+    if (epoch) {
+        const u64 nn = (((u64)nonce_hi << 32) | nonce_lo) + *epoch;
+        nonce_lo = (u32)nn;
+        nonce_hi = (u32)(nn >> 32);
+    }
+    const u64 c = first_ct + i, g = c / Gc;
+    const u32 r0 = (u32)(c - g * Gc) * U;
+    const u32 pl = plain[i] & 1u;
+    const u64 pm = pl ? ~0ull : 0ull;
+    u64 *o = out + i * dL;
+    bool all = true;
+    u32 secret_bits = 0;
+    for (u32 j = 0; j < U; ++j) {
+        const u32 r = r0 + j, p = r >> 8, q = (r >> 6) & 3u, L = r & 63u;
+        const u64 ctr = (g * P + p) * 64u + L;
+        u32 x[16];
+        chacha_block<ROUNDS>(rng, nonce_lo, nonce_hi, (u32)ctr, (u32)(ctr >> 32), x);
+        u64 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)                   // static register indices only
+                if ((u32)qq == q) {
+                    lo = x[4 * qq + 2 * h];
+                    hi = x[4 * qq + 2 * h + 1];
+                }
+            w[h] = ((u64)hi << 32) | lo;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 k = 2u * j + (u32)h;
+            if (k >= dL)
+                continue;
+            u64 v = w[h];
+            if (k == dL - 1u)
+                v &= tail;
+            const u64 m = mask[k];
+            secret_bits += (u32)__popcll(m);
+            all = all && ((v & m) == m);
+            o[k] = v | (m & pm);
+        }
+    }
+    if (!pl && all && secret_bits >= 2u) {     // one distinct position: the reference never clears
+        const u32 pos = keyed_draw_pos<ROUNDS>(rng, nonce_lo, nonce_hi, c, key_idx, D);
+        o[pos >> 6] &= ~(1ull << (63u - (pos & 63u)));     // same lane wrote the word: program order holds
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------ public
 
 hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
-                   const u32 *chosen, const uint8_t *last, const u64 *key, const u64 *mask, u64 seed,
-                   bool device_rng, u64 *out, hipStream_t s)
+                   const u32 *chosen, const uint8_t *last, const u64 *mask, u64 *out, hipStream_t s)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0)
         return hipSuccess;
     // fast form: K aligned 4 KiB segments = TB whole ciphertexts per workgroup, one lane per unit
-    // (a wave-local variant -- whole ciphertexts per wave, ballots only, no LDS or barrier -- measured
-    // slower: 2.6 vs 3.3 TB/s device-RNG at N=1247; its 960-byte wave stores lose more than the
-    // barriers cost)
     {
-        const bool wide = (dL % 2 == 0) && aligned16(out) && aligned16(mask) && (device_rng || aligned16(rnd));
+        const bool wide = (dL % 2 == 0) && aligned16(out) && aligned16(mask) && aligned16(rnd);
         const u32 U = (u32)(wide ? dL / 2 : dL);
         int k_seg = 0;
         if (U <= 64u)
@@ -287,17 +534,11 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
             if (nblk > kMaxBlocks256)
                 return hipErrorInvalidValue;
             const FastDiv dU = csgn_fastdiv_make(U);
-#define CSGN_ENC_SEG(UNIT, K)                                                                           \
-    do {                                                                                                \
-        if (device_rng)                                                                                 \
-            k_encrypt_seg<UNIT, K, true><<<(u32)nblk, 256, 0, s>>>(                                      \
-                n_bits, (u32)dL, U, dU, d, batch, tb, plain, reinterpret_cast<const UNIT *>(rnd), chosen, \
-                last, key, reinterpret_cast<const UNIT *>(mask), seed, reinterpret_cast<UNIT *>(out));   \
-        else                                                                                            \
-            k_encrypt_seg<UNIT, K, false><<<(u32)nblk, 256, 0, s>>>(                                     \
-                n_bits, (u32)dL, U, dU, d, batch, tb, plain, reinterpret_cast<const UNIT *>(rnd), chosen, \
-                last, key, reinterpret_cast<const UNIT *>(mask), seed, reinterpret_cast<UNIT *>(out));   \
-    } while (0)
+#define CSGN_ENC_SEG(UNIT, K)                                                                       \
+    k_encrypt_seg<UNIT, K><<<(u32)nblk, 256, 0, s>>>(n_bits, (u32)dL, U, dU, d, batch, tb, plain,   \
+                                                     reinterpret_cast<const UNIT *>(rnd), chosen, last, \
+                                                     reinterpret_cast<const UNIT *>(mask),              \
+                                                     reinterpret_cast<UNIT *>(out))
 #define CSGN_ENC_SEG_K(UNIT)                                       \
     switch (k_seg) {                                               \
     case 1: CSGN_ENC_SEG(UNIT, 1); break;                          \
@@ -328,12 +569,108 @@ hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64
     if (blocks64 > kMaxBlocks256)
         return hipErrorInvalidValue;
     const FastDiv ddL = csgn_fastdiv_make((u32)dL);
-    if (device_rng)
-        k_encrypt<true><<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, d, batch, cb, ddL, plain, rnd,
-                                                        chosen, last, key, mask, seed, out);
+    k_encrypt<<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, d, batch, cb, ddL, plain, rnd, chosen, last, mask, out);
+    return hipGetLastError();
+}
+
+} // namespace csgn
+
+namespace csgn {
+
+namespace {
+u32 gcd_u32(u32 a, u32 b)
+{
+    while (b) {
+        const u32 t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+} // namespace
+
+void encrypt_keyed_layout(u64 n_bits, u32 *U, u32 *P, u32 *Gc)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    *U = (u32)((dL + 1) / 2);
+    *P = *U / gcd_u32(*U, 256u);
+    *Gc = 256u * *P / *U;
+}
+
+hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain, const u64 *key_idx,
+                         const u64 *mask, const u32 rng_key[8], u64 nonce, u32 rounds,
+                         const u64 *d_epoch, u64 *out, hipStream_t s)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (rounds != 8 && rounds != 12 && rounds != 20)
+        return hipErrorInvalidValue;
+    const u64 dL = (n_bits + 63) / 64;
+    u32 U, P, Gc;
+    encrypt_keyed_layout(n_bits, &U, &P, &Gc);
+    const u32 rem = (u32)(n_bits & 63);
+    const u64 tail = rem ? ~0ull << (64 - rem) : ~0ull;
+    EncKeyed rk;
+    for (int i = 0; i < 8; ++i)
+        rk.key[i] = rng_key[i];
+    rk.nonce_lo = (u32)nonce;
+    rk.nonce_hi = (u32)(nonce >> 32);
+    const bool wave_ok = dL % 2 == 0 && P <= 5 && aligned16(out) && aligned16(mask) && tune(TUNE_ENC_WAVE) != 0;
+    if (wave_ok) {
+        EncWaveArgs a;
+        a.rng = rk;
+        a.epoch = d_epoch;
+        a.plain = plain;
+        a.key_idx = key_idx;
+        a.mask = reinterpret_cast<const unit16 *>(mask);
+        a.out = reinterpret_cast<unit16 *>(out);
+        a.first_ct = first_ct;
+        a.batch = batch;
+        a.group0 = first_ct / Gc;
+        a.ngroups = (first_ct + batch - 1) / Gc - a.group0 + 1;
+        a.U = U;
+        a.Gc = Gc;
+        a.D = (u32)d;
+        a.tail_lo = (u32)tail;
+        a.tail_hi = (u32)(tail >> 32);
+        a.dU = csgn_fastdiv_make(U);
+        const u64 blocks = (a.ngroups + 3) / 4;
+        if (blocks > kMaxBlocks256)
+            return hipErrorInvalidValue;
+        const size_t lds = (size_t)U * 16u + 4u * (P * 4u + 1u) * 8u;
+#define CSGN_ENC_WAVE(R, PP) k_encrypt_wave<R, PP><<<(u32)blocks, 256, lds, s>>>(a)
+#define CSGN_ENC_WAVE_P(R)                  \
+    switch (P) {                            \
+    case 1: CSGN_ENC_WAVE(R, 1); break;     \
+    case 2: CSGN_ENC_WAVE(R, 2); break;     \
+    case 3: CSGN_ENC_WAVE(R, 3); break;     \
+    case 4: CSGN_ENC_WAVE(R, 4); break;     \
+    default: CSGN_ENC_WAVE(R, 5); break;    \
+    }
+        if (rounds == 8) {
+            CSGN_ENC_WAVE_P(8)
+        } else if (rounds == 12) {
+            CSGN_ENC_WAVE_P(12)
+        } else {
+            CSGN_ENC_WAVE_P(20)
+        }
+#undef CSGN_ENC_WAVE_P
+#undef CSGN_ENC_WAVE
+        return hipGetLastError();
+    }
+    const u64 blocks = (batch + 255) / 256;
+    if (blocks > kMaxBlocks256)
+        return hipErrorInvalidValue;
+#define CSGN_ENC_CT(R)                                                                                       \
+    k_encrypt_keyed_ct<R><<<(u32)blocks, 256, 0, s>>>(rk, d_epoch, plain, key_idx, mask, out, first_ct, batch, \
+                                                      (u32)dL, U, P, Gc, (u32)d, tail)
+    if (rounds == 8)
+        CSGN_ENC_CT(8);
+    else if (rounds == 12)
+        CSGN_ENC_CT(12);
     else
-        k_encrypt<false><<<(u32)blocks64, 256, lds, s>>>(n_bits, (u32)dL, d, batch, cb, ddL, plain, rnd,
-                                                         chosen, last, key, mask, seed, out);
+        CSGN_ENC_CT(20);
+#undef CSGN_ENC_CT
     return hipGetLastError();
 }
 

@@ -41,8 +41,12 @@ size_t compact_scratch_bytes(u64 total_terms);
 hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, const u64 *off, u64 *out,
                    u64 *off_out, void *scratch, hipStream_t s);
 hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
-                   const u32 *chosen, const uint8_t *last, const u64 *key, const u64 *mask, u64 seed,
-                   bool device_rng, u64 *out, hipStream_t s);
+                   const u32 *chosen, const uint8_t *last, const u64 *mask, u64 *out, hipStream_t s);
+// Keyed (ChaCha) device-RNG encrypt; keystream layout in csgn_encrypt.hip.
+void encrypt_keyed_layout(u64 n_bits, u32 *U, u32 *P, u32 *Gc);
+hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain, const u64 *key_idx,
+                         const u64 *mask, const u32 rng_key[8], u64 nonce, u32 rounds,
+                         const u64 *d_epoch, u64 *out, hipStream_t s);
 hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64 *terms,
                    const u32 *perm, u64 *out, hipStream_t s);
 hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);

@@ -33,10 +33,15 @@ class CiphertextBatch {
     CiphertextBatch(const Context &c, uint64_t count, uint64_t terms);
 
   public:
-    // Encrypts bits[i] under `key` with the device's counter-based generator (same
-    // distribution as SecretKey::encrypt, not the libc rand() stream); `seed` selects the stream.
+    // Encrypts bits[i] under `key` on the device: same distribution as SecretKey::encrypt
+    // (src/SecretKey.cpp:35-80), randomness from a keyed ChaCha generator (csgn_encrypt_keyed) whose
+    // 256-bit key and nonce come fresh from the operating system for every call.
+    static CiphertextBatch encrypt(const SecretKey &key, const std::vector<unsigned char> &bits);
+    // REPRODUCIBLE form for tests and benchmarks: generator key expanded from a 64-bit seed
+    // (csgn_rng_from_seed) -- not for ciphertexts that have to stay secret.  Element i draws stream
+    // position first_ciphertext + i, so shards of one logical batch agree with the whole.
     static CiphertextBatch encrypt(const SecretKey &key, const std::vector<unsigned char> &bits,
-                                   uint64_t seed);
+                                   uint64_t seed, uint64_t first_ciphertext = 0);
     // Packs existing single ciphertexts (all with the same term count) into a batch.
     static CiphertextBatch pack(const std::vector<Ciphertext> &items);
 

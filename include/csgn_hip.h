@@ -221,9 +221,41 @@ int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
                           const uint8_t *d_plain, const uint64_t *d_rnd,
                           const uint32_t *d_chosen, const uint8_t *d_last,
                           const uint64_t *d_mask, uint64_t *d_out, void *stream);
-/* Throughput form: same construction, randomness from a counter-based generator on the
- * device (splitmix64 of (seed, ciphertext, word)); d_key holds the D indices.  Same
- * distribution as the reference, not the same bits. */
+/* Throughput form: same construction, randomness generated on the device by a KEYED generator:
+ * ChaCha (64-bit block counter, 64-bit nonce; 8, 12 or 20 rounds) in counter mode under a 256-bit
+ * secret key.  Outputs do not reveal the key or one another (a ciphertext word that carries no
+ * secret position IS raw generator output, so an invertible generator would leak the stream and
+ * with it the secret positions).  Same distribution as the reference, not the same bits: every
+ * position is drawn; plaintext 1 ORs the key mask in; for plaintext 0, if all D secret positions
+ * came out 1, position s[draw % D] is cleared (equivalent to src/SecretKey.cpp:51-76: draw the
+ * position first, force it to 0 when all the others are 1) -- unless the key has a single distinct
+ * position, which the reference never clears either.
+ *   h_rng              key/nonce/rounds (host struct; fill with csgn_rng_from_os for real use)
+ *   first_ciphertext   GLOBAL index of d_plain[0] / d_out[0] in the (key, nonce) stream: ciphertext
+ *                      c always draws the same words whatever batch or shard it is encrypted in
+ *                      (csgn_shard.h).  Never encrypt two different plaintexts under the same
+ *                      (key, nonce, index): advance first_ciphertext or change the nonce.
+ *   d_key              the D secret indices (device), d_mask their dL-word mask (csgn_key_mask).
+ * Keystream layout (csgn_encrypt_keyed_layout reports U, P, Gc): U = ceil(dL/2) 16-byte units per
+ * ciphertext, P = U/gcd(U,256), Gc = 256*P/U; unit j of ciphertext c is words 4q..4q+3 of ChaCha
+ * block (g*P + p)*64 + L with g = c/Gc, r = (c%Gc)*U + j, p = r/256, q = (r%256)/64, L = r%64. */
+typedef struct csgn_rng {
+    uint32_t key[8];      /* 256-bit generator key: SECRET */
+    uint64_t nonce;       /* stream id */
+    uint32_t rounds;      /* 8, 12 or 20 */
+    uint32_t reserved;
+} csgn_rng;
+/* key and nonce from the operating system's entropy source (getrandom). */
+int csgn_rng_from_os(csgn_rng *h_rng, uint32_t rounds);
+/* REPRODUCIBLE stream for tests and benchmarks: key and nonce expanded from a 64-bit seed.  Sixty-four
+ * bits of entropy at most -- not for ciphertexts that have to stay secret. */
+int csgn_rng_from_seed(csgn_rng *h_rng, uint64_t seed, uint32_t rounds);
+int csgn_encrypt_keyed_layout(uint64_t n_bits, uint32_t *h_units, uint32_t *h_passes, uint32_t *h_group);
+int csgn_encrypt_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t first_ciphertext,
+                       const uint8_t *d_plain, const uint64_t *d_key, const uint64_t *d_mask,
+                       const csgn_rng *h_rng, uint64_t *d_out, void *stream);
+/* = csgn_encrypt_keyed with csgn_rng_from_seed(seed, 8 rounds) and first_ciphertext 0: the
+ * reproducible test/benchmark form (see csgn_rng_from_seed: NOT for secrets). */
 int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,
                             const uint8_t *d_plain, const uint64_t *d_key,
                             const uint64_t *d_mask, uint64_t seed, uint64_t *d_out, void *stream);

@@ -111,6 +111,14 @@ class Oracle:
         L.csgn_oracle_key_mask.argtypes = [u64, u64p, u64, u64p]
         L.csgn_oracle_encrypt.restype = i64
         L.csgn_oracle_encrypt.argtypes = [u64, u64, u64p, C.c_uint, i32p, u64, u64p]
+        L.csgn_oracle_chacha_block.restype = None
+        L.csgn_oracle_chacha_block.argtypes = [C.c_void_p, u64, u64, C.c_uint, C.c_void_p]
+        L.csgn_oracle_rng_from_seed.restype = None
+        L.csgn_oracle_rng_from_seed.argtypes = [u64, C.c_void_p, C.POINTER(u64)]
+        L.csgn_oracle_keyed_layout.restype = None
+        L.csgn_oracle_keyed_layout.argtypes = [u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.csgn_oracle_encrypt_keyed.restype = None
+        L.csgn_oracle_encrypt_keyed.argtypes = [u64, u64, u64p, u64, u64, C.c_void_p, C.c_void_p, u64, C.c_uint, u64p]
         L.csgn_oracle_decrypt.restype = C.c_uint
         L.csgn_oracle_decrypt.argtypes = [u64, u64, u64p, u64p, u64, u64p]
         L.csgn_oracle_decrypt_canonical.restype = C.c_uint
@@ -209,6 +217,38 @@ class Oracle:
             out[i * dl:(i + 1) * dl] = ct
             pos += used
         return out, pos
+
+    # -- keyed device generator (definitions shared with the HIP side) --------------
+    def chacha_block(self, key_words, nonce: int, counter: int, rounds: int) -> np.ndarray:
+        k = np.ascontiguousarray(np.asarray(key_words, dtype=np.uint32))
+        assert k.size == 8
+        out = np.zeros(16, dtype=np.uint32)
+        self.lib.csgn_oracle_chacha_block(k.ctypes.data, nonce & (2**64 - 1), counter & (2**64 - 1), rounds,
+                                          out.ctypes.data)
+        return out
+
+    def rng_from_seed(self, seed: int):
+        """(key[8] as uint32, nonce) of csgn_rng_from_seed."""
+        k = np.zeros(8, dtype=np.uint32)
+        nonce = u64(0)
+        self.lib.csgn_oracle_rng_from_seed(seed & (2**64 - 1), k.ctypes.data, C.byref(nonce))
+        return k, int(nonce.value)
+
+    def keyed_layout(self, n_bits: int):
+        a, b, c = u64(0), u64(0), u64(0)
+        self.lib.csgn_oracle_keyed_layout(n_bits, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
+    def encrypt_keyed(self, n_bits: int, key, plain, rng_key, nonce: int, rounds: int = 8,
+                      first_ciphertext: int = 0) -> np.ndarray:
+        key = as_u64(key)
+        plain = np.ascontiguousarray(np.asarray(plain, dtype=np.uint8))
+        rk = np.ascontiguousarray(np.asarray(rng_key, dtype=np.uint32))
+        out = np.zeros(plain.size * self.default_len(n_bits), dtype=np.uint64)
+        self.lib.csgn_oracle_encrypt_keyed(n_bits, key.size, _p64(key), plain.size, first_ciphertext,
+                                           plain.ctypes.data, rk.ctypes.data, nonce & (2**64 - 1), rounds,
+                                           _p64(out))
+        return out
 
     def decrypt(self, n_bits: int, key, v, bitlen=None) -> int:
         key, v = as_u64(key), as_u64(v)

@@ -296,6 +296,126 @@ int64_t csgn_oracle_encrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
     return ok ? (int64_t)used : -1;
 }
 
+/* ---- keyed device generator (definition shared with the HIP side, NOT reference code) ----
+ * csgn_encrypt_keyed (include/csgn_hip.h) draws its randomness from ChaCha in counter mode.  This
+ * is an independent restatement of that definition: the ChaCha block function as published by
+ * D. J. Bernstein ("ChaCha, a variant of Salsa20", 2008; 64-bit counter in state words 12-13,
+ * 64-bit nonce in 14-15), checked in tests/test_oracle_golden.py against the RFC 8439 section
+ * 2.3.2 known-answer block; the keystream layout and the plaintext rule follow the comment in
+ * include/csgn_hip.h.  The plaintext-0 rule is proven distribution-identical to
+ * src/SecretKey.cpp:51-76 by exhaustive enumeration in tests/test_oracle_golden.py. */
+#define ROTL32(x, n) (((x) << (n)) | ((x) >> (32 - (n))))
+#define QR(a, b, c, d)                    \
+    a += b; d ^= a; d = ROTL32(d, 16);    \
+    c += d; b ^= c; b = ROTL32(b, 12);    \
+    a += b; d ^= a; d = ROTL32(d, 8);     \
+    c += d; b ^= c; b = ROTL32(b, 7)
+
+void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t counter,
+                              unsigned rounds, uint32_t out[16])
+{
+    uint32_t in[16], x[16];
+    in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+    for (int i = 0; i < 8; ++i)
+        in[4 + i] = key[i];
+    in[12] = (uint32_t)counter;
+    in[13] = (uint32_t)(counter >> 32);
+    in[14] = (uint32_t)nonce;
+    in[15] = (uint32_t)(nonce >> 32);
+    memcpy(x, in, sizeof(x));
+    for (unsigned r = 0; r < rounds; r += 2) {
+        QR(x[0], x[4], x[8], x[12]);
+        QR(x[1], x[5], x[9], x[13]);
+        QR(x[2], x[6], x[10], x[14]);
+        QR(x[3], x[7], x[11], x[15]);
+        QR(x[0], x[5], x[10], x[15]);
+        QR(x[1], x[6], x[11], x[12]);
+        QR(x[2], x[7], x[8], x[13]);
+        QR(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; ++i)
+        out[i] = x[i] + in[i];
+}
+#undef QR
+#undef ROTL32
+
+void csgn_oracle_rng_from_seed(uint64_t seed, uint32_t key[8], uint64_t *nonce)
+{
+    for (int i = 0; i < 4; ++i) {
+        uint64_t w = splitmix64(seed + GOLDEN * (uint64_t)(i + 1));
+        key[2 * i] = (uint32_t)w;
+        key[2 * i + 1] = (uint32_t)(w >> 32);
+    }
+    *nonce = splitmix64(seed ^ 0xD1B54A32D192ED03ull);
+}
+
+static uint64_t gcd_u64(uint64_t a, uint64_t b)
+{
+    while (b) {
+        uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+void csgn_oracle_keyed_layout(uint64_t n_bits, uint64_t *units, uint64_t *passes, uint64_t *group)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits);
+    *units = (dl + 1) / 2;
+    *passes = *units / gcd_u64(*units, 256);
+    *group = 256 * *passes / *units;
+}
+
+/* random word k of ciphertext c (global index) */
+static uint64_t keyed_word(const uint32_t key[8], uint64_t nonce, unsigned rounds, uint64_t U,
+                           uint64_t P, uint64_t Gc, uint64_t c, uint64_t k)
+{
+    uint64_t j = k / 2, g = c / Gc, r = (c % Gc) * U + j;
+    uint64_t p = r / 256, q = (r % 256) / 64, L = r % 64;
+    uint32_t x[16];
+    csgn_oracle_chacha_block(key, nonce, (g * P + p) * 64 + L, rounds, x);
+    uint64_t base = 4 * q + 2 * (k % 2);
+    return ((uint64_t)x[base + 1] << 32) | x[base];
+}
+
+void csgn_oracle_encrypt_keyed(uint64_t n_bits, uint64_t d, const uint64_t *key_idx, uint64_t batch,
+                               uint64_t first_ciphertext, const uint8_t *plain,
+                               const uint32_t rng_key[8], uint64_t nonce, unsigned rounds,
+                               uint64_t *out)
+{
+    uint64_t dl = csgn_oracle_default_len(n_bits), U, P, Gc;
+    csgn_oracle_keyed_layout(n_bits, &U, &P, &Gc);
+    uint64_t *mask = (uint64_t *)calloc(dl ? dl : 1, sizeof(uint64_t));
+    csgn_oracle_key_mask(n_bits, key_idx, d, mask);
+    unsigned rem = (unsigned)(n_bits % WORD_BITS);
+    uint64_t tail = rem ? ~0ull << (WORD_BITS - rem) : ~0ull;
+    uint64_t secret_bits = 0;
+    for (uint64_t k = 0; k < dl; ++k)
+        secret_bits += (uint64_t)__builtin_popcountll(mask[k]);
+    for (uint64_t i = 0; i < batch; ++i) {
+        uint64_t c = first_ciphertext + i, *o = out + i * dl;
+        int all = 1;
+        for (uint64_t k = 0; k < dl; ++k) {
+            uint64_t v = keyed_word(rng_key, nonce, rounds, U, P, Gc, c, k);
+            if (k == dl - 1)
+                v &= tail;
+            if ((v & mask[k]) != mask[k])
+                all = 0;
+            o[k] = (plain[i] & 1u) ? (v | mask[k]) : v;
+        }
+        if (!(plain[i] & 1u) && all && secret_bits >= 2) {
+            /* all D secret positions came out 1: clear s[draw % D], draw = first word of the
+             * block (counter = c) of the stream whose nonce has its top bit flipped */
+            uint32_t x[16];
+            csgn_oracle_chacha_block(rng_key, nonce ^ 0x8000000000000000ull, c, rounds, x);
+            uint64_t pos = key_idx[((uint64_t)x[0] * d) >> 32];
+            o[pos / WORD_BITS] &= ~(1ull << (WORD_BITS - 1u - (unsigned)(pos % WORD_BITS)));
+        }
+    }
+    free(mask);
+}
+
 /* ------------------------------------------------------------------ decrypt ---- */
 
 unsigned csgn_oracle_decrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,

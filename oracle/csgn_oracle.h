@@ -73,6 +73,19 @@ int64_t csgn_oracle_encrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
                             unsigned bit, const int32_t *draws, uint64_t n_draws,
                             uint64_t *out);
 
+/* ---- keyed device generator: definitions shared with the HIP side (NOT reference code) ----
+ * ChaCha block function (Bernstein 2008; 64-bit counter, 64-bit nonce), the seed expansion of
+ * csgn_rng_from_seed, the keystream layout and the whole of csgn_encrypt_keyed
+ * (include/csgn_hip.h), restated independently of the kernels. */
+void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t counter,
+                              unsigned rounds, uint32_t out[16]);
+void csgn_oracle_rng_from_seed(uint64_t seed, uint32_t key[8], uint64_t *nonce);
+void csgn_oracle_keyed_layout(uint64_t n_bits, uint64_t *units, uint64_t *passes, uint64_t *group);
+void csgn_oracle_encrypt_keyed(uint64_t n_bits, uint64_t d, const uint64_t *key_idx, uint64_t batch,
+                               uint64_t first_ciphertext, const uint8_t *plain,
+                               const uint32_t rng_key[8], uint64_t nonce, unsigned rounds,
+                               uint64_t *out);
+
 /* ---- decrypt (src/SecretKey.cpp:82-147) -------------------------------------------
  * Faithful form: unpacks the stream bit by bit according to bitlen[], then applies the
  * AND-over-key / XOR-over-terms reduction.  bitlen may be NULL => canonical. */

@@ -417,6 +417,25 @@ static int cmd_batch(int count)
         std::vector<unsigned char> back = in.back().decrypt(sk);
         EXPECT(back == bits[k]);
     }
+    {
+        // default form: generator key from the OS, fresh per call -- decrypts to the bits, never the same words twice
+        CiphertextBatch a = CiphertextBatch::encrypt(sk, bits[0]), b = CiphertextBatch::encrypt(sk, bits[0]);
+        EXPECT(a.decrypt(sk) == bits[0] && b.decrypt(sk) == bits[0]);
+        EXPECT(a.at(0).getLen() == 20);
+        bool same = true;
+        for (uint64_t w = 0; w < 20; ++w)
+            same = same && a.at(0).getValues()[w] == b.at(0).getValues()[w];
+        EXPECT(!same);
+        // seeded form: a shard of the stream equals the same elements of the whole
+        if (count > 3) {
+            std::vector<unsigned char> tailbits(bits[1].begin() + 3, bits[1].end());
+            CiphertextBatch whole = CiphertextBatch::encrypt(sk, bits[1], 4242);
+            CiphertextBatch shard = CiphertextBatch::encrypt(sk, tailbits, 4242, 3);
+            Ciphertext w3 = whole.at(3), s0 = shard.at(0);
+            for (uint64_t w = 0; w < 20; ++w)
+                EXPECT(w3.getValues()[w] == s0.getValues()[w]);
+        }
+    }
     CiphertextBatch x = in[0];
     std::vector<unsigned char> xb = bits[0];
     int k = 1;

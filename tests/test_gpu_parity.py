@@ -462,6 +462,72 @@ def test_encrypt_device_rng_properties(hip, oracle, n, d):
     assert np.array_equal(again.reshape(batch, dl), host) and not np.array_equal(other.reshape(batch, dl), host)
 
 
+KEYED_CONTEXTS = [(1247, 16), (4096, 32), (65, 4), (64, 4), (63, 4), (130, 5), (129, 3), (1247, 2), (4096, 3),
+                  (300, 3), (1300, 4), (128, 1), (8192, 2), (2048, 5)]
+
+
+@pytest.mark.parametrize("n,d", KEYED_CONTEXTS)
+@pytest.mark.parametrize("wave", [1, 0])
+def test_encrypt_keyed_matches_the_restated_definition(hip, oracle, knobs, n, d, wave):
+    """csgn_encrypt_keyed (ChaCha keystream, wave kernel and one-lane-per-ciphertext kernel) word for
+    word against oracle.encrypt_keyed, on windows of the stream that start and end inside a group
+    of ciphertexts.  Small D makes the all-secret-positions-came-out-1 clear frequent."""
+    knobs.set("enc_wave", wave)
+    key = make_key(n, d, 16)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    units, passes, group = oracle.keyed_layout(n)
+    rng = hip.rng_from_seed(77 + n, 8)
+    rk, nonce = oracle.rng_from_seed(77 + n)
+    assert list(rng.key) == [int(x) for x in rk] and rng.nonce == nonce
+    dl = oracle.default_len(n)
+    prng = np.random.default_rng(d)
+    for first, batch in [(0, 3 * group + 5), (1, 1), (group - 1, 2), (5 * group + 7, 2 * group), (group, group),
+                         (2**33 + 3, group + 9)]:
+        plain = prng.integers(0, 2, batch).astype(np.uint8)
+        got = hip.download(hip.encrypt_keyed(n, d, hip.upload(plain), dkey, dmask, rng, first_ciphertext=first))
+        want = oracle.encrypt_keyed(n, key, plain, rk, nonce, 8, first_ciphertext=first)
+        assert np.array_equal(got, want), (n, d, wave, first, batch)
+        if d > 1:
+            bits = hip.download(hip.decrypt_uniform(n, batch, 1, hip.upload(got), dmask))
+            assert np.array_equal(bits, plain)
+
+
+@pytest.mark.parametrize("rounds", [8, 12, 20])
+def test_encrypt_keyed_rounds_and_a_million_ciphertexts(hip, oracle, rounds):
+    """1 M fresh ciphertexts at N=1247 (BASELINE config 4's inputs): digest equal to the restated
+    definition's, every ciphertext decrypts to its plaintext (a missed clear -- probability 2^-16 per
+    plaintext-0 ciphertext, so about 8 in this batch -- would decrypt to 1)."""
+    n, d, dl = 1247, 16, 20
+    batch = (1 << 20) if rounds == 8 else (1 << 16)
+    key = make_key(n, d, 3)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    plain = np.random.default_rng(rounds).integers(0, 2, batch).astype(np.uint8)
+    rng = hip.rng_from_seed(5, rounds)
+    rk, nonce = oracle.rng_from_seed(5)
+    out = hip.encrypt_keyed(n, d, hip.upload(plain), dkey, dmask, rng, first_ciphertext=12345)
+    want = oracle.encrypt_keyed(n, key, plain, rk, nonce, rounds, first_ciphertext=12345)
+    assert hip.digest(out) == oracle.digest(want)
+    assert np.array_equal(hip.download(hip.decrypt_uniform(n, batch, 1, out, dmask)), plain)
+
+
+def test_encrypt_keyed_os_entropy_and_argument_checks(hip, oracle):
+    import ctypes as C
+    from csgn_amd import capi
+    a, b = hip.rng_from_os(), hip.rng_from_os(20)
+    assert list(a.key) != list(b.key) and a.nonce != b.nonce and (a.rounds, b.rounds) == (8, 20)
+    n, d = 1247, 16
+    key = make_key(n, d, 1)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    plain = hip.upload(np.array([1, 0, 1, 1, 0], dtype=np.uint8))
+    out = hip.encrypt_keyed(n, d, plain, dkey, dmask, a)
+    assert list(hip.download(hip.decrypt_uniform(n, 5, 1, out, dmask))) == [1, 0, 1, 1, 0]
+    bad = capi.CsgnRng()
+    bad.rounds = 7
+    assert hip.lib.csgn_encrypt_keyed(n, d, 5, 0, plain.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(bad),
+                                      out.data_ptr(), None) == -1
+    assert hip.lib.csgn_rng_from_seed(C.byref(bad), 1, 9) == -1
+
+
 # -------------------------------------------------------------------------- permutation
 
 def test_permutation_golden(hip, oracle, kat):

@@ -167,3 +167,91 @@ def test_oracle_homomorphic_properties(oracle):
             acc, _ = oracle.mul(n, acc, rhs); accb &= rb
         assert oracle.decrypt(n, key, acc) == accb
         assert oracle.decrypt_canonical(n, key, acc) == accb
+
+
+# ------------------------------------------------- keyed device generator (shared definitions)
+
+def test_chacha_block_known_answer(oracle):
+    """RFC 8439 section 2.3.2: key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00.
+    In the 64/64 layout used here that is state words 12..15 = 1, 0x09000000, 0x4a000000, 0."""
+    key = np.frombuffer(bytes(range(32)), dtype="<u4")
+    got = oracle.chacha_block(key, 0x4A000000, 1 | (0x09000000 << 32), 20)
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert [int(x) for x in got] == want
+    # fewer rounds give other words, and the block depends on every input
+    assert [int(x) for x in oracle.chacha_block(key, 0x4A000000, 1 | (0x09000000 << 32), 8)] != want
+    assert not np.array_equal(oracle.chacha_block(key, 1, 2, 8), oracle.chacha_block(key, 1, 3, 8))
+    assert not np.array_equal(oracle.chacha_block(key, 1, 2, 8), oracle.chacha_block(key, 2, 2, 8))
+
+
+@pytest.mark.parametrize("n,units,passes,group", [(1247, 10, 5, 128), (4096, 32, 1, 8), (64, 1, 1, 256), (65, 1, 1, 256),
+                                                  (129, 2, 1, 128), (300, 3, 3, 256), (1300, 11, 11, 256),
+                                                  (16384 * 8, 1024, 4, 1)])
+def test_keyed_layout(oracle, n, units, passes, group):
+    assert oracle.keyed_layout(n) == (units, passes, group)
+    assert passes * 256 == group * units
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (65, 4), (63, 2), (130, 5), (100, 1), (1300, 3)])
+def test_keyed_encrypt_restatement_properties(oracle, n, d):
+    rng = np.random.default_rng(n + d)
+    key = rng.permutation(n)[:d].astype(np.uint64)
+    rk, nonce = oracle.rng_from_seed(1234)
+    batch = 700
+    plain = rng.integers(0, 2, batch).astype(np.uint8)
+    dl = oracle.default_len(n)
+    ct = oracle.encrypt_keyed(n, key, plain, rk, nonce, 8)
+    rem = n % 64
+    if rem:
+        assert not np.any(ct.reshape(batch, dl)[:, -1] & np.uint64((1 << (64 - rem)) - 1))
+    if d > 1:
+        for i in range(batch):
+            assert oracle.decrypt(n, key, ct[i * dl:(i + 1) * dl]) == plain[i], i
+    # the stream is indexed by the GLOBAL ciphertext number: any window reproduces its slice
+    for first, cnt in [(0, 1), (1, 5), (127, 3), (128, 200), (255, 257), (699, 1)]:
+        win = oracle.encrypt_keyed(n, key, plain[first:first + cnt], rk, nonce, 8, first_ciphertext=first)
+        assert np.array_equal(win, ct[first * dl:(first + cnt) * dl]), (first, cnt)
+    # other nonce / rounds / key: other words
+    assert not np.array_equal(oracle.encrypt_keyed(n, key, plain, rk, nonce + 1, 8), ct)
+    assert not np.array_equal(oracle.encrypt_keyed(n, key, plain, rk, nonce, 12), ct)
+    rk2 = rk.copy()
+    rk2[3] ^= 1
+    assert not np.array_equal(oracle.encrypt_keyed(n, key, plain, rk2, nonce, 8), ct)
+
+
+def test_keyed_plaintext0_rule_has_the_reference_distribution(oracle):
+    """csgn_encrypt_keyed draws EVERY position and, when all D secret positions came out 1, clears
+    s[draw % D]; the reference (src/SecretKey.cpp:51-76, restated in oracle.encrypt) draws the chosen
+    position first and forces it to 0 when all OTHERS are 1.  Exhaustive enumeration over every
+    random outcome at N=7: both give exactly the same distribution over ciphertexts."""
+    from fractions import Fraction
+    from itertools import product
+    n = 7
+    for key in ([1, 4, 6], [0, 3], [2, 2, 5], [5]):
+        d = len(key)
+        kset = sorted(set(key))
+        # reference: draws = [sRandom] + one per non-chosen position (+ 1 spare)
+        ref = {}
+        for s_rand in range(d):
+            for bits in product((0, 1), repeat=n - 1):
+                for spare in (0, 1):
+                    draws = np.array([s_rand] + list(bits) + [spare], dtype=np.int32)
+                    ct, used = oracle.encrypt(n, key, 0, draws)
+                    w = Fraction(1, d * 2 ** (n - 1)) * (Fraction(1, 2) if used == n + 1 else (1 if spare == 0 else 0))
+                    if w:
+                        ref[int(ct[0])] = ref.get(int(ct[0]), 0) + w
+        # keyed rule: N uniform bits, then the clear
+        mine = {}
+        for bits in product((0, 1), repeat=n):
+            word = 0
+            for j, b in enumerate(bits):
+                word |= b << (63 - j)
+            if all(bits[p] for p in kset) and len(kset) >= 2:
+                for idx in range(d):
+                    w2 = word & ~(1 << (63 - key[idx]))
+                    mine[w2] = mine.get(w2, 0) + Fraction(1, d * 2 ** n)
+            else:
+                mine[word] = mine.get(word, 0) + Fraction(1, 2 ** n)
+        assert sum(ref.values()) == 1 and sum(mine.values()) == 1
+        assert ref == mine, key
