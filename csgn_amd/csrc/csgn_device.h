@@ -107,6 +107,18 @@ __device__ inline void words_to_unit(const UnitWords<2> &r, unit16 &v)
 }
 __device__ inline void words_to_unit(const UnitWords<1> &r, unit8 &v) { v = r.w[0]; }
 
+// v_writelane_b32: drop a wave-uniform 64-bit value into ONE lane of a VGPR pair (hipcc 7.2
+// exposes no builtin for it).  `lane` must be a compile-time constant.  The s_nop is the
+// gfx940+ "VALU writes SGPR -> VALU reads that SGPR" hazard (2 wait states): the ballot is
+// produced by a v_cmp immediately before, and hipcc pads nothing inside an asm statement
+// (observed: without it the low word of some lanes read a stale SGPR).
+__device__ inline void write_lane64(u64 uniform_value, int lane, u32 &lo, u32 &hi)
+{
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                 : "+v"(lo), "+v"(hi)
+                 : "s"((u32)uniform_value), "s"((u32)(uniform_value >> 32)), "n"(lane));
+}
+
 // ------------------------------------------------------------------------- launch helpers
 template <typename T>
 inline bool aligned16(const T *p)

@@ -303,21 +303,35 @@ struct EncWaveArgs {
     unit16 *out;                  // batch*U units
     u64 first_ct, batch;          // global index of plain[0] / out[0], ciphertext count
     u64 group0, ngroups;          // first group and number of groups the launch covers
-    u32 U, Gc, D;
+    u32 U, Gc, D, iters;          // iters: groups per wave (every wave of the grid runs the same count)
     u32 tail_lo, tail_hi;         // the last word's valid-bit mask
     FastDiv dU;
 };
 
-// One wave = one group of Gc ciphertexts = P passes of 256 units.  FULL: every ciphertext of the
-// group is inside [first_ct, first_ct + batch) (all but the first and last group of a launch).
+// all mask bits set in v?  (~v & m) OR-ed over the four dwords: one v_bitop3_b32 each
+__device__ inline bool unit_covers_chain(unit16 v, unit16 m)
+{
+    u32 t = ~v.x & m.x;
+    t |= ~v.y & m.y;
+    t |= ~v.z & m.z;
+    t |= ~v.w & m.w;
+    return t == 0u;
+}
+
+// One wave = one group of Gc ciphertexts = P passes of 256 units.  Everything that depends only on
+// a unit's place r in the group -- its key-mask unit, the valid-bit mask of its second word, the
+// ciphertext it belongs to -- was tabulated in LDS by the workgroup (mtab / ttab / ctab), so the
+// per-unit work beside the generator is: two LDS reads, one plaintext byte, the cover test, the OR
+// of the key mask, one store.  FULL: every ciphertext of the group is inside [first_ct, first_ct +
+// batch) (all but the first and last group of a launch).
 template <int ROUNDS, int P, bool FULL>
-__device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *lmask, u64 *cover, u32 lane, u64 group,
-                                     u32 nonce_lo, u32 nonce_hi)
+__device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, const uint2 *ttab,
+                                     const unsigned short *ctab, u64 *cover, u32 lane, u64 group, u32 nonce_lo,
+                                     u32 nonce_hi)
 {
     const u32 U = a.U;
     const u64 cbase = group * a.Gc;                        // first ciphertext of the group (global index)
-    // valid ciphertexts of the group, as local indices [cl_lo, cl_hi)
-    u32 cl_lo = 0, cl_hi = a.Gc;
+    u32 cl_lo = 0, cl_hi = a.Gc;                           // valid ciphertexts of the group, local indices
     if (!FULL) {
         cl_lo = cbase < a.first_ct ? (u32)(a.first_ct - cbase) : 0u;
         const u64 end = a.first_ct + a.batch;
@@ -328,10 +342,8 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *lmask, 
     const long long origin = (long long)cbase - (long long)a.first_ct;
     unit16 *outg = a.out + origin * (long long)U;
     const uint8_t *plaing = a.plain + origin;
-
-    u32 cl = csgn_fastdiv(lane, a.dU), j = lane - cl * U;   // unit r = lane of pass 0, quarter 0
-    const u32 step_c = csgn_fastdiv(64u, a.dU), step_j = 64u - step_c * U;
     const u64 blk0 = group * (u64)P * 64u + lane;
+    u32 acc_lo = 0, acc_hi = 0;                            // lane s keeps the cover ballot of slot s = p*4+q
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const u64 ctr = blk0 + (u64)p * 64u;
@@ -340,105 +352,103 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *lmask, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 r = (u32)p * 256u + (u32)q * 64u + lane;
-            const unit16 m = lmask[j];
+            const unit16 m = mtab[r];
+            const uint2 tl = ttab[r];
+            const u32 cl = ctab[r];
             const bool inr = FULL || (cl - cl_lo < cl_hi - cl_lo);
-            const u32 pl = plaing[FULL ? cl : min(max(cl, cl_lo), cl_hi - 1u)] & 1u;
+            const u32 pl = plaing[FULL ? cl : min(max(cl, cl_lo), cl_hi - 1u)];
             unit16 v;
             v.x = x[4 * q];
             v.y = x[4 * q + 1];
-            v.z = x[4 * q + 2];
-            v.w = x[4 * q + 3];
-            if (j == U - 1u) {                              // padding bits of the last word stay 0
-                v.z &= a.tail_lo;
-                v.w &= a.tail_hi;
-            }
-            const bool cov = unit_covers(v, m);             // all secret positions of this unit came out 1
-            const u64 b = __ballot(cov);
-            if (lane == 0)
-                cover[p * 4 + q] = b;
-            const u32 pm = 0u - pl;                         // plaintext 1: OR the key mask in (src/SecretKey.cpp:44-45)
+            v.z = x[4 * q + 2] & tl.x;                      // padding bits of a ciphertext's last word stay 0
+            v.w = x[4 * q + 3] & tl.y;
+            const u64 b = __ballot(unit_covers_chain(v, m)); // all secret positions of this unit came out 1
+            write_lane64(b, p * 4 + q, acc_lo, acc_hi);
+            const u32 pm = (u32)__builtin_amdgcn_sbfe((int)pl, 0, 1);   // plaintext 1 -> ~0: OR the key mask in (src/SecretKey.cpp:44-45)
             v.x |= m.x & pm;
             v.y |= m.y & pm;
             v.z |= m.z & pm;
             v.w |= m.w & pm;
             if (inr)
                 unit_store<unit16, true>(outg + r, v);
-            // the next unit of this lane is 64 further on
-            j += step_j;
-            cl += step_c;
-            if (j >= U) {
-                j -= U;
-                cl += 1u;
-            }
         }
     }
+    if (lane < (u32)P * 4u)
+        cover[lane] = ((u64)acc_hi << 32) | acc_lo;
 }
 
 template <int ROUNDS, int P>
 __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    unit16 *lmask = reinterpret_cast<unit16 *>(smem_raw);                      // U units
-    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (size_t)a.U * 16u);    // 4 waves x (P*4 + 1) words
+    constexpr u32 R = 256u * P;                                                  // units per group
+    unit16 *mtab = reinterpret_cast<unit16 *>(smem_raw);                         // R key-mask units
+    uint2 *ttab = reinterpret_cast<uint2 *>(smem_raw + (size_t)R * 16u);         // R valid-bit masks (second word)
+    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (size_t)R * 24u);        // 4 waves x P*4 words
+    unsigned short *ctab = reinterpret_cast<unsigned short *>(smem_raw + (size_t)R * 24u + 4u * P * 4u * 8u);   // R local ciphertext numbers
 
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    for (u32 k = tid; k < a.U; k += 256u)
-        lmask[k] = a.mask[k];
-    u64 *cover = cover_all + wave * (P * 4 + 1);
-    if (lane == 0)
-        cover[P * 4] = 0;                                   // pad word for the straddling shift
+    const u32 U = a.U;
+    for (u32 r = tid; r < R; r += 256u) {
+        const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
+        mtab[r] = a.mask[j];
+        ttab[r] = (j == U - 1u) ? make_uint2(a.tail_lo, a.tail_hi) : make_uint2(~0u, ~0u);
+        ctab[r] = (unsigned short)cl;
+    }
+    u64 *cover = cover_all + wave * (P * 4);
     __syncthreads();
 
-    const u64 gi = (u64)blockIdx.x * 4u + wave;             // group of this wave, relative to group0
-    const bool active = gi < a.ngroups;
-    const u64 group = a.group0 + gi;
     u32 nonce_lo = a.rng.nonce_lo, nonce_hi = a.rng.nonce_hi;
     if (a.epoch) {
         const u64 nn = (((u64)nonce_hi << 32) | nonce_lo) + *a.epoch;
         nonce_lo = (u32)nn;
         nonce_hi = (u32)(nn >> 32);
     }
-    const u64 cbase = group * a.Gc;
-    const bool full = cbase >= a.first_ct && cbase + a.Gc <= a.first_ct + a.batch;
-    if (active) {
+    // every wave walks `iters` groups, a whole grid apart each time (wave-local state only: no
+    // workgroup barrier inside the loop)
+    for (u32 it = 0; it < a.iters; ++it) {
+        const u64 gi = ((u64)it * gridDim.x + blockIdx.x) * 4u + wave;           // relative to group0
+        if (gi >= a.ngroups)
+            break;
+        const u64 group = a.group0 + gi;
+        const u64 cbase = group * a.Gc;
+        const bool full = cbase >= a.first_ct && cbase + a.Gc <= a.first_ct + a.batch;
         if (full)
-            encrypt_group<ROUNDS, P, true>(a, lmask, cover, lane, group, nonce_lo, nonce_hi);
+            encrypt_group<ROUNDS, P, true>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
         else
-            encrypt_group<ROUNDS, P, false>(a, lmask, cover, lane, group, nonce_lo, nonce_hi);
-    }
-    __syncthreads();
-    if (!active)
-        return;
-    // src/SecretKey.cpp:51-76 for plaintext 0: if ALL D secret positions came out 1 the chosen one is
-    // cleared (the reference draws the chosen position first and forces it to 0 when the others are
-    // all 1; drawing every position and clearing the chosen one afterwards is the same distribution).
-    // Probability 2^-D per ciphertext, so this branch is almost never taken.
-    const u32 U = a.U;
-    for (u32 cl = lane; cl < a.Gc; cl += kWave) {
-        const u64 c = cbase + cl;
-        if (c < a.first_ct || c >= a.first_ct + a.batch)
-            continue;
-        bool all = true;
-        for (u32 bit = cl * U, left = U; left && all;) {
-            const u32 w = bit >> 6, sh = bit & 63u, take = min(left, 64u - sh);
-            const u64 need = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
-            all = ((cover[w] >> sh) & need) == need;
-            bit += take;
-            left -= take;
+            encrypt_group<ROUNDS, P, false>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
+        __builtin_amdgcn_wave_barrier();        // cover[] is private to this wave; its LDS operations run in order
+        // src/SecretKey.cpp:51-76 for plaintext 0: if ALL D secret positions came out 1 the chosen one is
+        // cleared (the reference draws the chosen position first and forces it to 0 when the others are
+        // all 1; drawing every position and clearing the chosen one afterwards is the same distribution).
+        // Probability 2^-D per ciphertext, so the branch below is almost never taken.
+        for (u32 cl = lane; cl < a.Gc; cl += kWave) {
+            const u64 c = cbase + cl;
+            if (c < a.first_ct || c >= a.first_ct + a.batch)
+                continue;
+            bool all = true;
+            for (u32 bit = cl * U, left = U; left && all;) {
+                const u32 w = bit >> 6, sh = bit & 63u, take = min(left, 64u - sh);
+                const u64 need = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
+                all = ((cover[w] >> sh) & need) == need;
+                bit += take;
+                left -= take;
+            }
+            if (!all || (a.plain[c - a.first_ct] & 1u))
+                continue;
+            // with a single distinct secret position there are no "other" positions and the reference
+            // never clears (its v stays 0, src/SecretKey.cpp:55-76)
+            u32 secret_bits = 0;
+            for (u32 k = 0; k < 2u * U; ++k)
+                secret_bits += (u32)__popcll(reinterpret_cast<const u64 *>(a.mask)[k]);
+            if (secret_bits < 2u)
+                continue;
+            const u32 pos = keyed_draw_pos<ROUNDS>(a.rng, nonce_lo, nonce_hi, c, a.key_idx, a.D);
+            __threadfence();                                    // this wave's stores of the word have landed
+            u64 *word = reinterpret_cast<u64 *>(a.out) + (c - a.first_ct) * (u64)(2u * U) + (pos >> 6);
+            atomicAnd(reinterpret_cast<unsigned long long *>(word), ~(1ull << (63u - (pos & 63u))));
         }
-        if (!all || (a.plain[c - a.first_ct] & 1u))
-            continue;
-        // with a single distinct secret position there are no "other" positions and the reference
-        // never clears (its v stays 0, src/SecretKey.cpp:55-76)
-        u32 secret_bits = 0;
-        for (u32 k = 0; k < 2u * U; ++k)
-            secret_bits += (u32)__popcll(reinterpret_cast<const u64 *>(a.mask)[k]);
-        if (secret_bits < 2u)
-            continue;
-        const u32 pos = keyed_draw_pos<ROUNDS>(a.rng, nonce_lo, nonce_hi, c, a.key_idx, a.D);
-        __threadfence();                                    // this wave's stores of the word have landed
-        u64 *word = reinterpret_cast<u64 *>(a.out) + (c - a.first_ct) * (u64)(2u * U) + (pos >> 6);
-        atomicAnd(reinterpret_cast<unsigned long long *>(word), ~(1ull << (63u - (pos & 63u))));
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -626,6 +636,7 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
         a.out = reinterpret_cast<unit16 *>(out);
         a.first_ct = first_ct;
         a.batch = batch;
+        a.iters = 1;
         a.group0 = first_ct / Gc;
         a.ngroups = (first_ct + batch - 1) / Gc - a.group0 + 1;
         a.U = U;
@@ -634,10 +645,24 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
         a.tail_lo = (u32)tail;
         a.tail_hi = (u32)(tail >> 32);
         a.dU = csgn_fastdiv_make(U);
-        const u64 blocks = (a.ngroups + 3) / 4;
-        if (blocks > kMaxBlocks256)
-            return hipErrorInvalidValue;
-        const size_t lds = (size_t)U * 16u + 4u * (P * 4u + 1u) * 8u;
+        // persistent workgroups: the LDS tables are built once per workgroup, so each wave should walk
+        // several groups; 256 CUs x 4 workgroups fill the chip (33 KB of LDS per workgroup at P = 5)
+        int cus = 256;
+        {
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        }
+        const u64 wg_needed = (a.ngroups + 3) / 4;
+        // Workgroups per CU (knob enc_wave = k > 1 forces k; >= 64 = one group per wave): 4 where the
+        // tables take 33 KB of LDS (P >= 3; N=1247), 16 for the small-table sizes (measured at N=4096 /
+        // 2048, 4 M ciphertexts: 3.4 -> 4.3 TB/s; profiles/r02/bench_encrypt.log)
+        const int per_cu = tune(TUNE_ENC_WAVE) > 1 ? tune(TUNE_ENC_WAVE) : (P >= 3 ? 4 : 16);
+        const u64 resident = per_cu >= 64 ? wg_needed : (u64)cus * (u64)per_cu;
+        u64 blocks = wg_needed <= resident ? wg_needed : resident;
+        a.iters = (u32)((wg_needed + blocks - 1) / blocks);
+        blocks = (wg_needed + a.iters - 1) / a.iters;         // equal trip counts
+        const size_t lds = (size_t)256u * P * 24u + 4u * P * 4u * 8u + (size_t)256u * P * 2u;
 #define CSGN_ENC_WAVE(R, PP) k_encrypt_wave<R, PP><<<(u32)blocks, 256, lds, s>>>(a)
 #define CSGN_ENC_WAVE_P(R)                  \
     switch (P) {                            \

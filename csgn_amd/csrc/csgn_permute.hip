@@ -6,18 +6,6 @@ namespace csgn {
 
 namespace {
 
-// v_writelane_b32: drop a wave-uniform 64-bit value into ONE lane of a VGPR pair (hipcc 7.2
-// exposes no builtin for it).  `lane` must be a compile-time constant.  The s_nop is the
-// gfx940+ "VALU writes SGPR -> VALU reads that SGPR" hazard (2 wait states): the ballot is
-// produced by a v_cmp immediately before, and hipcc pads nothing inside an asm statement
-// (observed: without it the low word of some lanes read a stale SGPR).
-__device__ inline void write_lane64(u64 uniform_value, int lane, u32 &lo, u32 &hi)
-{
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                 : "+v"(lo), "+v"(hi)
-                 : "s"((u32)uniform_value), "s"((u32)(uniform_value >> 32)), "n"(lane));
-}
-
 template <int NW>
 __global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, FastDiv ddL, u64 out_terms,
                                                  u64 in_stride_words, u32 have_input, u32 TB,
