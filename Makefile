@@ -7,7 +7,7 @@ CXX     ?= g++
 CSRC    := csgn_amd/csrc
 LIBDIR  := csgn_amd/lib
 HIP_SRC := $(addprefix $(CSRC)/,csgn_capi.hip csgn_mul.hip csgn_add.hip csgn_decrypt.hip csgn_encrypt.hip \
-                                csgn_permute.hip csgn_compact.hip csgn_harness.hip csgn_tuning.cpp)
+                                csgn_permute.hip csgn_compact.hip csgn_harness.hip csgn_bitlen.hip csgn_tuning.cpp)
 HIP_HDR := $(wildcard $(CSRC)/*.h) include/csgn_hip.h
 CLS_SRC := $(sort $(wildcard $(CSRC)/certfhe/*.cpp))
 CLS_HDR := $(wildcard include/certfhe/*.h) $(wildcard $(CSRC)/certfhe/*.h)
@@ -17,7 +17,7 @@ all: $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcertFHE.so
 
 $(LIBDIR)/libcsgn_hip.so: $(HIP_SRC) $(HIP_HDR)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) -o $@ $(HIP_SRC)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Iinclude -I$(CSRC) -o $@ $(HIP_SRC)
 
 $(LIBDIR)/libcertFHE.so: $(CLS_SRC) $(CLS_HDR) $(LIBDIR)/libcsgn_hip.so
 	$(CXX) -std=c++11 -O2 -fPIC -shared -Iinclude -Iinclude/certfhe -o $@ $(CLS_SRC) \

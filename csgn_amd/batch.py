@@ -218,6 +218,23 @@ class HipPath:
                                             _ptr(perm), _ptr(out), self.stream))
         return out[:n_out]
 
+    # -- explicit bitlen (one ciphertext) ------------------------------------------------
+    def decrypt_bitlen(self, n_bits: int, key: torch.Tensor, words: torch.Tensor, bitlen: torch.Tensor) -> int:
+        length = words.numel()
+        bit = torch.zeros(1, dtype=torch.uint8, device=self.device)
+        scratch = torch.empty(int(self.lib.csgn_bitlen_scratch_bytes(length)), dtype=torch.uint8, device=self.device)
+        check(self.lib.csgn_decrypt_bitlen(n_bits, key.numel(), length, _ptr(words), _ptr(bitlen), _ptr(key),
+                                           _ptr(bit), _ptr(scratch), self.stream))
+        return int(bit.item())
+
+    def permute_bitlen(self, n_bits: int, words: torch.Tensor, bitlen: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+        length = words.numel()
+        out = self.empty_words(self.default_len(n_bits))
+        scratch = torch.empty(int(self.lib.csgn_bitlen_scratch_bytes(length)), dtype=torch.uint8, device=self.device)
+        check(self.lib.csgn_permute_bitlen(n_bits, length, _ptr(words), _ptr(bitlen), _ptr(perm), _ptr(out),
+                                           _ptr(scratch), self.stream))
+        return out
+
     # -- harness --------------------------------------------------------------------------
     def synth_fill(self, seed: int, n_bits: int, first_word: int, n_words: int,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:

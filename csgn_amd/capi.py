@@ -70,6 +70,9 @@ SIGNATURES = {
     "csgn_encrypt_keyed": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_device_rng": (C.c_int, [u64, u64, u64, vp, vp, vp, u64, vp, vp]),
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
+    "csgn_bitlen_scratch_bytes": (C.c_size_t, [u64]),
+    "csgn_decrypt_bitlen": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_permute_bitlen": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_synth_fill": (C.c_int, [u64, u64, u64, u64, vp, vp]),
     "csgn_digest": (C.c_int, [vp, u64, u64, vp, vp]),
     "csgn_circuit_create": (C.c_int, [u64, u64, C.POINTER(vp)]),

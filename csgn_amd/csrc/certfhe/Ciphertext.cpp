@@ -359,15 +359,30 @@ void Ciphertext::applyPermutation_inplace(const Permutation &permutation)
 {
     const Context &ctx = requireContext(certFHEcontext);
     const uint64_t n = ctx.getN(), dl = ctx.getDefaultN();
-    if (custom_bitlen)
-        throw std::runtime_error("certFHE::Ciphertext::applyPermutation: a ciphertext with a "
-                                 "non-canonical Bitlen cannot be permuted on the device");
     if (permutation.getLength() < n)
         throw std::invalid_argument("certFHE::Ciphertext::applyPermutation: permutation shorter than N");
     std::vector<uint32_t> p32(n);
     const uint64_t *p = permutation.getPermutation();
     for (uint64_t i = 0; i < n; ++i)
         p32[i] = (uint32_t)p[i];
+    if (custom_bitlen) {
+        // a Bitlen other than the canonical pattern: (v, bitlen) is a bit stream (src/Ciphertext.cpp:16-31);
+        // the result is one term with the canonical Bitlen (:36-47)
+        // staging: [bitlen (len words)][perm as u32]
+        std::shared_ptr<DevicePayload> stage = detail::allocBytes((size_t)len * 8 + (((size_t)n * 4 + 7) & ~(size_t)7));
+        detail::check(csgn_memcpy_h2d(stage->ptr, host_bitlen, (size_t)len * 8, detail::stream()), "csgn_memcpy_h2d");
+        detail::check(csgn_memcpy_h2d(stage->data() + len, p32.data(), (size_t)n * 4, detail::stream()),
+                      "csgn_memcpy_h2d");
+        std::shared_ptr<DevicePayload> work = detail::allocBytes((csgn_bitlen_scratch_bytes(len) + 7) & ~(size_t)7);
+        std::shared_ptr<DevicePayload> out = detail::allocWords(dl);
+        detail::check(csgn_permute_bitlen(n, len, deviceValues(), stage->data(),
+                                          reinterpret_cast<const uint32_t *>(stage->data() + len), out->data(),
+                                          work->ptr, detail::stream()),
+                      "csgn_permute_bitlen");
+        detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");
+        publish(out, dl);
+        return;
+    }
     // one staging block: [perm as u32, padded to 8 bytes]
     std::shared_ptr<DevicePayload> dperm = detail::allocBytes(((size_t)n * 4 + 7) & ~(size_t)7);
     detail::check(csgn_memcpy_h2d(dperm->ptr, p32.data(), (size_t)n * 4, detail::stream()), "csgn_memcpy_h2d");

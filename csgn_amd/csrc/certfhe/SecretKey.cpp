@@ -12,6 +12,9 @@
 
 #include "runtime.h"
 
+#include <cstring>
+#include <vector>
+
 namespace certFHE {
 
 using detail::DevicePayload;
@@ -202,9 +205,33 @@ Plaintext SecretKey::decrypt(Ciphertext &ciphertext)
 {
     const Context &ctx = requireContext(certFHEContext);
     const uint64_t n = ctx.getN(), dl = ctx.getDefaultN();
-    if (!ciphertext.hasCanonicalBitlen())
-        throw std::runtime_error("certFHE::SecretKey::decrypt: a ciphertext with a non-canonical "
-                                 "Bitlen cannot be decrypted on the device");
+    if (!ciphertext.hasCanonicalBitlen()) {
+        // a Bitlen other than 64,...,64,N%64 (4-argument constructor / setBitlen): the reference reads
+        // (v, bitlen) as a bit stream (src/SecretKey.cpp:110-140); so does csgn_decrypt_bitlen
+        const uint64_t words = ciphertext.getLen();
+        if (words == 0)
+            return Plaintext(0);
+        // staging: [bitlen (words)][key indices (length)]
+        std::vector<uint64_t> stage(words + (uint64_t)length);
+        memcpy(stage.data(), ciphertext.getBitlen(), words * sizeof(uint64_t));
+        for (long i = 0; i < length; ++i)
+            stage[words + i] = s[i];
+        std::shared_ptr<DevicePayload> dstage = detail::uploadWords(stage.data(), stage.size());
+        std::shared_ptr<DevicePayload> work = detail::allocBytes((csgn_bitlen_scratch_bytes(words) + 7) & ~(size_t)7);
+        void *d_bit = nullptr;
+        volatile unsigned char *h_bit = detail::resultSlot(&d_bit);
+        detail::check(csgn_decrypt_bitlen(n, (uint64_t)length, words, ciphertext.deviceValues(), dstage->data(),
+                                          dstage->data() + words, static_cast<uint8_t *>(d_bit), work->ptr,
+                                          detail::stream()),
+                      "csgn_decrypt_bitlen");
+        // the staging block held the secret indices: wipe it before it returns to the block cache
+        detail::check(csgn_memset(dstage->data() + words, 0, (size_t)length * 8, detail::stream()), "csgn_memset");
+        detail::syncDevice();
+        volatile uint64_t *wipe = stage.data() + words;
+        for (long i = 0; i < length; ++i)
+            wipe[i] = 0;
+        return Plaintext((int)(*h_bit & 1u));
+    }
     const uint64_t terms = dl ? ciphertext.getLen() / dl : 0;
     if (terms == 0)
         return Plaintext(0);                   // empty term list XORs to 0

@@ -623,6 +623,40 @@ int csgn_permute_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms_in, int
     return CSGN_OK;
 }
 
+size_t csgn_bitlen_scratch_bytes(uint64_t len_words) { return csgn::bitlen_scratch_bytes(len_words); }
+
+int csgn_decrypt_bitlen(uint64_t n_bits, uint64_t d, uint64_t len_words, const uint64_t *d_v,
+                        const uint64_t *d_bitlen, const uint64_t *d_key, uint8_t *d_bit, void *d_scratch,
+                        void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(d >= 1, "d must be >= 1");
+    REQUIRE(d_key && d_bit && d_scratch && ((d_v && d_bitlen) || len_words == 0), "null device pointer");
+    REQUIRE(len_words < (1ull << 40), "ciphertext too long");
+    hipError_t e = csgn::decrypt_bitlen(n_bits, d, len_words, (const u64 *)d_v, (const u64 *)d_bitlen,
+                                        (const u64 *)d_key, d_bit, d_scratch, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ciphertext too long for one launch");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+int csgn_permute_bitlen(uint64_t n_bits, uint64_t len_words, const uint64_t *d_v, const uint64_t *d_bitlen,
+                        const uint32_t *d_perm, uint64_t *d_out, void *d_scratch, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(d_perm && d_out && d_scratch && ((d_v && d_bitlen) || len_words == 0), "null device pointer");
+    REQUIRE(len_words < (1ull << 40), "ciphertext too long");
+    hipError_t e = csgn::permute_bitlen(n_bits, len_words, (const u64 *)d_v, (const u64 *)d_bitlen, d_perm,
+                                        (u64 *)d_out, d_scratch, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ciphertext too long for one launch");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
 int csgn_synth_fill(uint64_t seed, uint64_t n_bits, uint64_t first_word, uint64_t n_words,
                     uint64_t *d_out, void *stream)
 {

@@ -49,6 +49,12 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
                          const u64 *d_epoch, u64 *out, hipStream_t s);
 hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64 *terms,
                    const u32 *perm, u64 *out, hipStream_t s);
+// one ciphertext with an explicit bitlen side array (csgn_bitlen.hip)
+size_t bitlen_scratch_bytes(u64 len);
+hipError_t decrypt_bitlen(u64 n_bits, u64 d, u64 len, const u64 *v, const u64 *bitlen, const u64 *key,
+                          uint8_t *bit, void *scratch, hipStream_t s);
+hipError_t permute_bitlen(u64 n_bits, u64 len, const u64 *v, const u64 *bitlen, const u32 *perm, u64 *out,
+                          void *scratch, hipStream_t s);
 hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 

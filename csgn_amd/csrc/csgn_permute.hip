@@ -2,6 +2,9 @@
 // Hand-written CDNA4 (gfx950) HIP; shared helpers in csgn_device.h, design notes in DESIGN.md.
 #include "csgn_device.h"
 
+#include <algorithm>
+#include <type_traits>
+
 namespace csgn {
 
 namespace {
@@ -350,6 +353,346 @@ __global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastD
         flush(gprev);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Bit-plane permutation, second form (round 2).  The first form above is bound by latency, not by
+// instruction count: its LDS image (term rows + planes + source table = 23.6 KB at N=1247, 72 KB at
+// N=4096) leaves 6 resp. 2 waves per CU, so one or two waves per SIMD sit out every LDS round trip and
+// DPP hazard of a 1 500-instruction turn.  Here the only LDS is the plane array itself (8 bytes per
+// term bit, 10 KB at N=1247):
+//   - no row staging: lane t reads ITS term's words straight from global memory (16 bytes per load,
+//     one term per lane; the 64 lines a load touches are re-used by the next loads of the turn out
+//     of L1/L2) and writes its permuted words straight back -- HBM still sees every line once;
+//   - the source-plane table lives in registers (the wave is persistent over groups of 64 terms);
+//   - W waves share one 64-term group and one plane array, each transposing every W-th word, so a
+//     big plane array (32 KB at N=4096) still keeps 16 waves on the CU.
+// Per turn: wait for the prefetched terms; words -> planes (one wave_transpose64 per word);
+// barrier; prefetch the next group; planes -> words through the source table; store; barrier.
+// ---------------------------------------------------------------------------------------
+template <int MAXI, int CI, int UW, int MAXT>
+__global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes2(u32 n_bits, u32 dL, u64 out_terms, u64 in_stride_words,
+                                                          const u64 *__restrict__ terms,
+                                                          const u32 *__restrict__ perm, u64 *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u64 *planes = reinterpret_cast<u64 *>(smem_raw);         // dL*64 planes + one all-zero plane
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, W = blockDim.x >> 6;
+    const u32 NI = dL / UW;                                  // items (UW words) per term
+    const u32 none = dL * 64u;
+    const TrLane trc = tr_lane(lane);
+    typedef u64 StageUnit __attribute__((ext_vector_type(UW)));
+    const u64 groups = (out_terms + 63) / 64;
+
+    // byte offset in planes[] of the source of every output bit this lane will assemble:
+    // output word w, lane b <-> term bit j = 64*w + 63 - b  <-  old bit perm[j]
+    // (plane numbers, two 16-bit entries per register: dL <= 256 keeps them below 2^16)
+    constexpr int NS = (MAXI * UW + 1) / 2;
+    u32 srcpk[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+        srcpk[e] = 0;
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k)
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            const u32 i = wave + (u32)k * W;
+            const u32 j = (i * UW + (u32)u) * 64u + 63u - lane;
+            u32 p = none;
+            if (i < NI && j < n_bits) {
+                p = perm[j];
+                if (p >= n_bits)
+                    p = none;
+            }
+            const int e = k * UW + u;
+            srcpk[e / 2] |= p << (16 * (e & 1));
+        }
+    if (tid == 0)
+        planes[none] = 0;
+
+    StageUnit v[MAXI];
+    auto fetch = [&](u64 g) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        const u64 *base = terms + (t0 + min(lane, nt - 1u)) * in_stride_words;   // lanes past the end re-read the last term
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const u32 i = min(wave + (u32)k * W, NI - 1u);
+            v[k] = *reinterpret_cast<const StageUnit *>(base + i * UW);
+        }
+    };
+
+    u64 g = blockIdx.x;
+    if (g < groups)
+        fetch(g);
+    __syncthreads();
+    for (; g < groups; g += gridDim.x) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        // 1. my words of the 64 terms -> bit planes (CI items = CI*UW words in flight per transpose
+        //    batch; a shorter batch takes the remainder, so no word is transposed for nothing)
+        auto to_planes = [&](auto cn_tag, int c0) {
+            constexpr int CN = decltype(cn_tag)::value;
+            u32 h[2 * CN * UW];
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const u64 x = v[c0 + c][u];
+                    h[2 * (c * UW + u)] = (u32)x;
+                    h[2 * (c * UW + u) + 1] = (u32)(x >> 32);
+                }
+            wave_transpose64_n<CN * UW>(h, trc);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const u32 i = wave + (u32)(c0 + c) * W;
+                if (i < NI) {                                // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < UW; ++u)
+                        planes[(i * UW + (u32)u) * 64u + 63u - lane] =
+                            ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
+                }
+            }
+        };
+#pragma unroll
+        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
+            if (wave + (u32)c0 * W < NI)                     // wave-uniform: skip batches past my last item
+                to_planes(std::integral_constant<int, CI>(), c0);
+        if constexpr (MAXI % CI != 0)
+            if (wave + (u32)(MAXI / CI * CI) * W < NI)
+                to_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+        __syncthreads();
+        // the next group's terms travel while this one is finished
+        if (g + gridDim.x < groups)
+            fetch(g + gridDim.x);
+        // 2. new bit j <- old bit perm[j]: gather planes, turn them back into words, store
+        u64 *orow = out + (t0 + lane) * dL;
+        auto from_planes = [&](auto cn_tag, int c0) {
+            constexpr int CN = decltype(cn_tag)::value;
+            u32 h[2 * CN * UW];
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int e = (c0 + c) * UW + u;
+                    const u32 pl = (e & 1) ? srcpk[e / 2] >> 16 : srcpk[e / 2] & 0xFFFFu;
+                    const u64 y = planes[pl];
+                    h[2 * (c * UW + u)] = (u32)y;
+                    h[2 * (c * UW + u) + 1] = (u32)(y >> 32);
+                }
+            wave_transpose64_n<CN * UW>(h, trc);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const u32 i = wave + (u32)(c0 + c) * W;
+                if (i < NI && lane < nt) {
+                    StageUnit o;
+#pragma unroll
+                    for (int u = 0; u < UW; ++u)
+                        o[u] = ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
+                    *reinterpret_cast<StageUnit *>(orow + i * UW) = o;
+                }
+            }
+        };
+#pragma unroll
+        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
+            if (wave + (u32)c0 * W < NI)
+                from_planes(std::integral_constant<int, CI>(), c0);
+        if constexpr (MAXI % CI != 0)
+            if (wave + (u32)(MAXI / CI * CI) * W < NI)
+                from_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Bit-plane permutation, third form: the second form's LDS economy (ONE array, W waves per 64-term
+// group, source table in registers) with the first form's coalesced HBM access.  The one LDS array is
+// used in turn as term rows (coalesced 16-byte units in, one word per lane out), as bit planes, and
+// as term rows again for the way back; what has to survive a change of role waits in registers.
+//   A  prefetched units -> rows          B  rows -> my words (lane = term)
+//   C  words -> planes (transposes)          [next group's loads are issued here]
+//   D  planes -> my new words (gather through the source table + transposes), kept in registers
+//   E  new words -> rows                 F  rows -> HBM, coalesced
+// Six workgroup barriers per turn (wave-level when W = 1); LDS per group = max(planes, rows) =
+// 10.5 KB at N=1247, 33 KB at N=4096.
+// ---------------------------------------------------------------------------------------
+template <int MAXI, int CI, int UW, int MAXT>
+__global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes3(u32 n_bits, u32 dL, u64 out_terms,
+                                                                     u64 in_stride_words,
+                                                                     const u64 *__restrict__ terms,
+                                                                     const u32 *__restrict__ perm,
+                                                                     u64 *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    u64 *buf = reinterpret_cast<u64 *>(smem_raw);            // planes: buf[j], j <= none;  rows: buf[t*SA + k]
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, T = blockDim.x, W = T >> 6;
+    const u32 NI = dL / UW;                                  // items (UW words) per term
+    const u32 nu = 64u * NI;                                 // staging units of a full group
+    const u32 SA = dL | 1u;                                  // odd row stride: conflict-free column access
+    const u32 none = dL * 64u;
+    const TrLane trc = tr_lane(lane);
+    typedef u64 StageUnit __attribute__((ext_vector_type(UW)));
+    const u64 groups = (out_terms + 63) / 64;
+
+    // source planes of the output bits this lane assembles (item i = wave + k*W), two per register
+    constexpr int NS = (MAXI * UW + 1) / 2;
+    u32 srcpk[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+        srcpk[e] = 0;
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k)
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            const u32 i = wave + (u32)k * W;
+            const u32 j = (i * UW + (u32)u) * 64u + 63u - lane;
+            u32 p = none;
+            if (i < NI && j < n_bits) {
+                p = perm[j];
+                if (p >= n_bits)
+                    p = none;
+            }
+            const int e = k * UW + u;
+            srcpk[e / 2] |= p << (16 * (e & 1));
+        }
+    // staging slots of this thread: unit q*T + tid of the group -> (term, word offset)
+    u32 rowoff[MAXI], tq[MAXI], inoff[MAXI];
+#pragma unroll
+    for (int q = 0; q < MAXI; ++q) {
+        const u32 u = min((u32)q * T + tid, nu - 1u);
+        const u32 t = u / NI;
+        tq[q] = t;
+        rowoff[q] = t * SA + (u - t * NI) * UW;
+        inoff[q] = (u - t * NI) * UW;
+    }
+    StageUnit uu[MAXI];
+    auto fetch = [&](u64 g) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        const u64 *base = terms + t0 * in_stride_words;
+#pragma unroll
+        for (int q = 0; q < MAXI; ++q)                       // terms past the end re-read the last one
+            uu[q] = *reinterpret_cast<const StageUnit *>(base + (u64)min(tq[q], nt - 1u) * in_stride_words + inoff[q]);
+    };
+
+    u64 g = blockIdx.x;
+    if (g < groups)
+        fetch(g);
+    for (; g < groups; g += gridDim.x) {
+        const u64 t0 = g * 64;
+        const u32 nt = (u32)min((u64)64, out_terms - t0);
+        // A. units -> rows
+#pragma unroll
+        for (int q = 0; q < MAXI; ++q)
+            if ((u32)q * T + tid < nu) {
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    buf[rowoff[q] + u] = uu[q][u];
+            }
+        __syncthreads();
+        // B. my words of term `lane`
+        StageUnit w[MAXI];
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const u32 i = min(wave + (u32)k * W, NI - 1u);
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                w[k][u] = buf[lane * SA + i * UW + u];
+        }
+        __syncthreads();
+        if (tid == 0)
+            buf[none] = 0;                                   // the all-zero plane ("no source")
+        // C. words -> planes
+        auto to_planes = [&](auto cn_tag, int c0) {
+            constexpr int CN = decltype(cn_tag)::value;
+            u32 h[2 * CN * UW];
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const u64 x = w[c0 + c][u];
+                    h[2 * (c * UW + u)] = (u32)x;
+                    h[2 * (c * UW + u) + 1] = (u32)(x >> 32);
+                }
+            wave_transpose64_n<CN * UW>(h, trc);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const u32 i = wave + (u32)(c0 + c) * W;
+                if (i < NI) {                                // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < UW; ++u)
+                        buf[(i * UW + (u32)u) * 64u + 63u - lane] =
+                            ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
+                }
+            }
+        };
+#pragma unroll
+        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
+            if (wave + (u32)c0 * W < NI)
+                to_planes(std::integral_constant<int, CI>(), c0);
+        if constexpr (MAXI % CI != 0)
+            if (wave + (u32)(MAXI / CI * CI) * W < NI)
+                to_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+        __syncthreads();
+        if (g + gridDim.x < groups)
+            fetch(g + gridDim.x);                            // travels during D..F
+        // D. planes -> my new words (registers)
+        auto from_planes = [&](auto cn_tag, int c0) {
+            constexpr int CN = decltype(cn_tag)::value;
+            u32 h[2 * CN * UW];
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int e = (c0 + c) * UW + u;
+                    const u32 pl = (e & 1) ? srcpk[e / 2] >> 16 : srcpk[e / 2] & 0xFFFFu;
+                    const u64 y = buf[pl];
+                    h[2 * (c * UW + u)] = (u32)y;
+                    h[2 * (c * UW + u) + 1] = (u32)(y >> 32);
+                }
+            wave_transpose64_n<CN * UW>(h, trc);
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    w[c0 + c][u] = ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
+        };
+#pragma unroll
+        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
+            if (wave + (u32)c0 * W < NI)
+                from_planes(std::integral_constant<int, CI>(), c0);
+        if constexpr (MAXI % CI != 0)
+            if (wave + (u32)(MAXI / CI * CI) * W < NI)
+                from_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+        __syncthreads();
+        // E. new words -> rows
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const u32 i = wave + (u32)k * W;
+            if (i < NI) {
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    buf[lane * SA + i * UW + u] = w[k][u];
+            }
+        }
+        __syncthreads();
+        // F. rows -> out, coalesced (the group's output is one contiguous run of nt*dL words)
+        StageUnit *obase = reinterpret_cast<StageUnit *>(out + t0 * dL);
+#pragma unroll
+        for (int q = 0; q < MAXI; ++q) {
+            const u32 u = (u32)q * T + tid;
+            if (u < nt * NI) {
+                StageUnit o;
+#pragma unroll
+                for (int x = 0; x < UW; ++x)
+                    o[x] = buf[rowoff[q] + x];
+                obase[u] = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------ public
@@ -362,8 +705,145 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     if (out_terms == 0)
         return hipSuccess;
     const u64 stride = per_term ? dL : terms_in * dL;
-    // bit-plane form (64 terms per wave) unless the batch is too small to fill a wave or the LDS
-    // image (rows + planes) would not fit; CSGN_PERM_BALLOT=1 forces the ballot form
+    // bit-plane form, round 2 (k_permute_planes2): planes only in LDS, W waves per 64-term group
+    if (terms_in != 0 && out_terms >= 16 && dL <= 256 && !tune(TUNE_PERM_BALLOT) && tune(TUNE_PERM_V1) != 1) {
+        // knob perm_v1: 0 = third form (coalesced, one LDS array), 1 = first form, 2 = second form (direct access)
+        const bool v3 = tune(TUNE_PERM_V1) != 2;
+        const size_t lds = std::max<size_t>(((size_t)dL * 64 + 1) * 8, v3 ? (size_t)(64 * (dL | 1) * 8) : (size_t)0);
+        int cus = 256;
+        {
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        }
+        const bool wide = dL % 2 == 0 && stride % 2 == 0 && (((uintptr_t)terms | (uintptr_t)out) & 15) == 0 &&
+                          !tune(TUNE_PERM_NARROW);
+        const u32 UW = wide ? 2u : 1u;
+        const u32 NI = (u32)dL / UW;
+        // LDS comes in 1 KiB granules; aim at ~16 waves per CU
+        const u32 groups_per_cu = std::max<u32>(1u, (u32)((160u * 1024u) / ((lds + 1023) / 1024 * 1024)));
+        // Waves per group.  At least enough to put ~16 waves on the CU and to keep a wave's items
+        // within its register budget (third form: 4 items = 112 VGPRs; second: 8); among the
+        // admissible counts the one that wastes the fewest transposes -- every wave runs whole
+        // batches of CI items and the group waits for its slowest wave, so the cost of a choice is
+        // W * roundup(ceil(NI/W), CI) transposed items for NI useful ones.  N=1247 (10 items): 5 waves
+        // x 2 items, measured 5.0 TB/s against 4.5 for 3 waves x 4/3/3 (profiles/r02/ab_permute.log).
+        auto bucket = [&](u32 per_wave, u32 *ci) -> u32 {
+            const u32 mx = per_wave <= 2 ? 2u : per_wave <= 4 ? 4u : per_wave <= 5 ? 5u : per_wave <= 8 ? 8u : 10u;
+            *ci = wide ? 2u : (mx == 2 ? 2u : (mx == 5 || mx == 10) ? 5u : 4u);
+            return mx;
+        };
+        u32 w_min = std::max<u32>(1u, (16u + groups_per_cu - 1) / groups_per_cu);
+        w_min = std::max<u32>(w_min, v3 ? (NI + 3u) / 4u : (NI + 7u) / 8u);
+        w_min = std::min<u32>(w_min, std::min<u32>(16u, NI));
+        u32 W = w_min;
+        {
+            u64 best = ~0ull;
+            for (u32 cand = w_min; cand <= std::min<u32>(16u, NI); ++cand) {
+                const u32 pw = (NI + cand - 1) / cand;
+                if (pw > 10)
+                    continue;
+                u32 ci = 2;
+                (void)bucket(pw, &ci);
+                const u64 cost = (u64)cand * ((pw + ci - 1) / ci * ci);
+                if (cost < best) {
+                    best = cost;
+                    W = cand;
+                }
+            }
+        }
+        if (const int forced = tune(TUNE_PERM_WAVES))
+            W = std::min<u32>(std::max<u32>((u32)std::max(1, forced), (NI + 9u) / 10u), std::min<u32>(16u, NI));
+        const u32 per_wave = (NI + W - 1) / W;
+        const u64 groups = (out_terms + 63) / 64;
+        const int persist = tune(TUNE_PERM_PERSIST);
+        if (groups * 64u * W >= (1ull << 32) && persist == 0)
+            return hipErrorInvalidValue;
+        // Persistent workgroups: as many groups per CU as are really resident (registers and LDS: the
+        // runtime's answer, remembered per kernel and LDS size), but not more than ~20 waves -- an
+        // oversubscribed CU runs the surplus workgroups after the others (measured at N=1247, 5 waves
+        // per group: 4 groups per CU 4.9-5.0 TB/s, 6 groups 4.3).  Equal trip counts per workgroup.
+        auto grid_for = [&](int occ) -> u32 {
+            u64 per_cu = (u64)std::max(1, occ);
+            per_cu = std::min<u64>(per_cu, std::max<u32>(1u, 20u / W));
+            if (persist > 1)
+                per_cu = (u64)persist;
+            const u64 resident = persist == 0 ? groups : (u64)cus * per_cu;
+            const u64 rounds = (groups + resident - 1) / resident;
+            return (u32)((groups + rounds - 1) / rounds);
+        };
+#define CSGN_PLANES_K(KERNEL, MAXI, CI, UWV, MAXT)                                                        \
+    do {                                                                                                  \
+        if (lds > 65536) {                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<MAXI, CI, UWV, MAXT>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            if (e != hipSuccess)                                                                          \
+                return e;                                                                                 \
+        }                                                                                                 \
+        static thread_local size_t asked_lds = 0;                                                         \
+        static thread_local u32 asked_w = 0;                                                              \
+        static thread_local int asked_occ = 0;                                                            \
+        if (asked_lds != lds || asked_w != W) {                                                           \
+            int q = 0;                                                                                    \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, KERNEL<MAXI, CI, UWV, MAXT>, (int)(64u * W), \
+                                                             lds) != hipSuccess || q < 1)                 \
+                q = 1;                                                                                    \
+            asked_occ = q;                                                                                \
+            asked_lds = lds;                                                                              \
+            asked_w = W;                                                                                  \
+        }                                                                                                 \
+        KERNEL<MAXI, CI, UWV, MAXT><<<grid_for(asked_occ), 64u * W, lds, s>>>((u32)n_bits, (u32)dL, out_terms, \
+                                                                              stride, terms, perm, out);  \
+    } while (0)
+#define CSGN_PLANES2_T(MAXI, CI, UWV, MAXT)                              \
+    do {                                                                 \
+        if (v3)                                                          \
+            CSGN_PLANES_K(k_permute_planes3, MAXI, CI, UWV, MAXT);       \
+        else                                                             \
+            CSGN_PLANES_K(k_permute_planes2, MAXI, CI, UWV, MAXT);       \
+    } while (0)
+#define CSGN_PLANES2(MAXI, CI, UWV)                 \
+    do {                                            \
+        if (W == 1)                                 \
+            CSGN_PLANES2_T(MAXI, CI, UWV, 64);      \
+        else if (W <= 4)                            \
+            CSGN_PLANES2_T(MAXI, CI, UWV, 256);     \
+        else                                        \
+            CSGN_PLANES2_T(MAXI, CI, UWV, 1024);    \
+    } while (0)
+        if (per_wave > 10) {
+            // more than 10 items per wave even with 16 waves (odd dL > 160): the forms below take it
+        } else if (wide) {
+            if (per_wave <= 2)
+                CSGN_PLANES2(2, 2, 2);
+            else if (per_wave <= 4)
+                CSGN_PLANES2(4, 2, 2);
+            else if (per_wave <= 5)
+                CSGN_PLANES2(5, 2, 2);
+            else if (per_wave <= 8)
+                CSGN_PLANES2(8, 2, 2);
+            else
+                CSGN_PLANES2(10, 2, 2);
+        } else {
+            if (per_wave <= 2)
+                CSGN_PLANES2(2, 2, 1);
+            else if (per_wave <= 4)
+                CSGN_PLANES2(4, 4, 1);
+            else if (per_wave <= 5)
+                CSGN_PLANES2(5, 5, 1);
+            else if (per_wave <= 8)
+                CSGN_PLANES2(8, 4, 1);
+            else
+                CSGN_PLANES2(10, 5, 1);
+        }
+#undef CSGN_PLANES2
+#undef CSGN_PLANES2_T
+#undef CSGN_PLANES_K
+        if (per_wave <= 10)
+            return hipGetLastError();
+    }
+    // bit-plane form, round 1 (64 terms per wave, LDS row staging; knob perm_v1) unless the batch is too
+    // small to fill a wave or the LDS image (rows + planes) would not fit; knob perm_ballot forces the ballot form
     {
         const u64 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
         const size_t lds = ((size_t)64 * (dLp | 1) + dLp * 64 + 1) * 8 + dLp * 64 * 2;

@@ -26,8 +26,9 @@ enum TuneKey {
     TUNE_RAGGED_TABLE,   // ragged multiply: 1 = per-chunk (pair, i, j) side table from the plan step, 0 = search per lane
     TUNE_PERM_BALLOT,    // 1 = ballot bit-gather permutation kernel instead of the bit-plane kernel
     TUNE_PERM_NARROW,    // 1 = 8-byte staging accesses in the bit-plane kernel
-    TUNE_PERM_WAVES,     // cap on bit-plane waves per CU, 0 = occupancy query
-    TUNE_PERM_V1,        // 1 = round-1 bit-plane kernel (LDS row staging) instead of the round-2 one
+    TUNE_PERM_WAVES,     // first form: cap on waves per CU; second/third form: waves per 64-term group; 0 = auto
+    TUNE_PERM_V1,        // bit-plane kernel: 0 = third form (default), 1 = first form (round 1), 2 = second form (direct access)
+    TUNE_PERM_PERSIST,   // second/third form: 1 = persistent workgroups striding over the groups, 0 = one group per workgroup, k > 1 = k groups per CU resident
     TUNE_DEC_LOOP,       // 1 = looping 256-term decrypt pass 1 instead of the segment form
     TUNE_ENC_LDS,        // 1 = LDS-staged encrypt kernel instead of the segment form
     TUNE_ENC_WAVE,       // device-RNG encrypt: 1 = wave-local kernel (default), 0 = segment kernel

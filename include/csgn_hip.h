@@ -271,6 +271,27 @@ int csgn_permute_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms_in, int
                          const uint64_t *d_terms, const uint32_t *d_perm, uint64_t *d_out,
                          void *stream);
 
+/* ------------------------------------------- explicit bitlen (one ciphertext) ---- */
+
+/* A ciphertext built through the reference's 4-argument constructor / setBitlen may carry ANY
+ * bitlen side array; the reference then reads (v, bitlen) as a bit stream -- word i contributes its
+ * top bitlen[i] bits -- and addresses it at flat positions (src/SecretKey.cpp:104-147,
+ * src/Ciphertext.cpp:16-69).  These two calls do exactly that for ONE ciphertext of len_words words,
+ * with d_bitlen[len_words] on the device (values above 64 are read as 64; a position past the end of
+ * the stream reads 0):
+ *   decrypt:  *d_bit = XOR over k < len_words/dL of AND over i < d of stream[n*k + key[i]]
+ *             (d_key: the D indices themselves, not the mask -- positions are stream positions);
+ *   permute:  d_out[dL words]: new bit j = stream[perm[j]] for j < min(N, stream length), the rest 0
+ *             (as in the reference the result is ONE term).
+ * d_scratch: csgn_bitlen_scratch_bytes(len_words).  With the canonical pattern both agree with
+ * csgn_decrypt_uniform / csgn_permute_uniform, which are the fast paths. */
+size_t csgn_bitlen_scratch_bytes(uint64_t len_words);
+int csgn_decrypt_bitlen(uint64_t n_bits, uint64_t d, uint64_t len_words, const uint64_t *d_v,
+                        const uint64_t *d_bitlen, const uint64_t *d_key, uint8_t *d_bit, void *d_scratch,
+                        void *stream);
+int csgn_permute_bitlen(uint64_t n_bits, uint64_t len_words, const uint64_t *d_v, const uint64_t *d_bitlen,
+                        const uint32_t *d_perm, uint64_t *d_out, void *d_scratch, void *stream);
+
 /* ------------------------------------------------------------------- harness ---- */
 
 /* Synthetic operand words: word idx = splitmix64(seed + GOLDEN*(idx+1)), the

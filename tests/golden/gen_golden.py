@@ -37,12 +37,60 @@ def make_key(n, d, seed):
     return rng.permutation(n)[:d].astype(np.uint64)
 
 
+def bitlen_stream_cases(ref, orc):
+    """(x) ciphertexts that carry a NON-canonical bitlen side array (4-argument constructor /
+    setBitlen): the reference reads (v, bitlen) as a bit stream (src/SecretKey.cpp:104-147,
+    src/Ciphertext.cpp:16-69).  Patterns keep every addressed position inside the stream (the
+    reference reads out of bounds otherwise).  Written to csgn_kat_bitlen.json."""
+    cases = []
+    for (n, d, terms, seed) in [(1247, 16, 1, 1), (1247, 16, 7, 2), (4096, 32, 3, 3), (65, 4, 5, 4), (130, 5, 9, 5),
+                                (64, 3, 4, 6), (200, 6, 33, 7)]:
+        rng = np.random.default_rng(9000 + seed)
+        dl = (n + 63) // 64
+        key = make_key(n, d, seed)
+        v = orc.synth(500 + seed, n, 0, terms * dl)
+        # force a few terms to hit so both plaintext values occur
+        mask = orc.key_mask(n, key)
+        for pattern in ("all64", "mixed"):
+            if pattern == "all64":
+                bl = np.full(terms * dl, 64, dtype=np.uint64)
+            else:
+                # per word 64 or a little less, total >= n*terms + margin so every n*k + s[i] is inside
+                bl = np.full(terms * dl, 64, dtype=np.uint64)
+                slack = int(64 * terms * dl - n * terms)
+                cut = rng.integers(0, 3, size=terms * dl)
+                while int(cut.sum()) > slack:
+                    cut[rng.integers(0, cut.size)] = 0
+                bl -= cut.astype(np.uint64)
+            vv = v.copy()
+            # plant hits: set the stream bits n*k + s[i] for some k (done on the unpacked stream)
+            pos = np.concatenate([[0], np.cumsum(bl)]).astype(np.int64)
+            for k in range(0, terms, 2):
+                for s_i in key:
+                    q = n * k + int(s_i)
+                    w = int(np.searchsorted(pos, q, side="right") - 1)
+                    vv[w] |= np.uint64(1) << np.uint64(63 - (q - pos[w]))
+            dec = ref.decrypt(n, d, key, vv, bl)
+            perm = ref.perm_random(n, 40 + seed)
+            pv, pbl = ref.permute_ciphertext(n, d, perm, vv, bl)
+            cases.append(dict(n=n, d=d, terms=terms, pattern=pattern, key=ints(key), v=hexs(vv), bitlen=ints(bl),
+                              dec=int(dec), perm=ints(perm), permuted=hexs(pv), permuted_bitlen=ints(pbl)))
+    return cases
+
+
 def main():
     build_ref()
     ref = load_ref()
     if ref is None:
         raise SystemExit("reference not buildable here")
     orc = Oracle()
+    if "--bitlen-only" in sys.argv:
+        path = os.path.join(HERE, "csgn_kat_bitlen.json")
+        with open(path, "w") as f:
+            json.dump({"bitlen_stream": bitlen_stream_cases(ref, orc)}, f, separators=(",", ":"))
+            f.write("\n")
+        print("wrote", path, os.path.getsize(path), "bytes")
+        return
     out = {}
 
     # (i) fresh ciphertexts ---------------------------------------------------------
@@ -178,6 +226,11 @@ def main():
     path = os.path.join(HERE, "csgn_kat.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
+    print("wrote", path, os.path.getsize(path), "bytes")
+    path = os.path.join(HERE, "csgn_kat_bitlen.json")
+    with open(path, "w") as f:
+        json.dump({"bitlen_stream": bitlen_stream_cases(ref, orc)}, f, separators=(",", ":"))
         f.write("\n")
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -528,6 +528,66 @@ def test_encrypt_keyed_os_entropy_and_argument_checks(hip, oracle):
     assert hip.lib.csgn_rng_from_seed(C.byref(bad), 1, 9) == -1
 
 
+# ------------------------------------- non-canonical bitlen: (v, bitlen) as a bit stream
+
+def test_bitlen_stream_golden(hip, oracle):
+    """csgn_decrypt_bitlen / csgn_permute_bitlen on the genuine reference's answers for ciphertexts
+    whose Bitlen is not the canonical pattern (tests/golden/csgn_kat_bitlen.json)."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "csgn_kat_bitlen.json")) as f:
+        cases = json.load(f)["bitlen_stream"]
+    for c in cases:
+        n = c["n"]
+        key = np.array(c["key"], dtype=np.uint64)
+        v, bl = words(c["v"]), np.array(c["bitlen"], dtype=np.uint64)
+        dv, dbl = hip.upload(v), hip.upload(bl)
+        assert hip.decrypt_bitlen(n, hip.upload(key), dv, dbl) == c["dec"], (n, c["pattern"])
+        perm = hip.upload(np.array(c["perm"], dtype=np.uint32))
+        assert np.array_equal(hip.download(hip.permute_bitlen(n, dv, dbl, perm)), words(c["permuted"]))
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (65, 4), (64, 3), (63, 2), (130, 5), (2100, 7)])
+def test_bitlen_stream_matches_oracle_on_arbitrary_patterns(hip, oracle, n, d):
+    """Any bitlen the class API can be handed: zeros, short streams (positions past the end read 0,
+    as the oracle defines the reference's out-of-bounds read), ragged lengths, long term lists; and
+    the canonical pattern, where the stream calls must agree with the fast paths."""
+    rng = np.random.default_rng(n + d)
+    dl = oracle.default_len(n)
+    for terms, kind in [(1, "canon"), (5, "canon"), (1, "rand"), (3, "rand"), (40, "rand"), (7, "zeros"), (9, "short"),
+                        (2000, "near"), (1, "tiny")]:
+        length = terms * dl + (3 if kind == "short" else 0)
+        key = rng.permutation(n)[:d].astype(np.uint64)
+        v = oracle.synth(int(rng.integers(1, 1 << 30)), n, 0, length)
+        if kind == "canon":
+            bl = canonical_bitlen(n, terms)
+        elif kind == "rand":
+            bl = rng.integers(0, 65, size=length).astype(np.uint64)
+        elif kind == "zeros":
+            bl = rng.choice([0, 0, 64, 17], size=length).astype(np.uint64)
+        elif kind == "near":
+            bl = (64 - rng.integers(0, 2, size=length)).astype(np.uint64)
+        elif kind == "tiny":
+            bl = np.ones(length, dtype=np.uint64)
+        else:
+            bl = rng.integers(50, 65, size=length).astype(np.uint64)
+        # make the answer depend on the data: plant the key in every other term where the stream reaches
+        pos = np.concatenate([[0], np.cumsum(bl)]).astype(np.int64)
+        for k in range(0, terms, 2):
+            for s_i in key:
+                q = n * k + int(s_i)
+                if q < pos[-1]:
+                    w = int(np.searchsorted(pos, q, side="right") - 1)
+                    v[w] |= np.uint64(1) << np.uint64(63 - (q - pos[w]))
+        dv, dbl, dkey = hip.upload(v), hip.upload(bl), hip.upload(key)
+        assert hip.decrypt_bitlen(n, dkey, dv, dbl) == oracle.decrypt(n, key, v, bl), (n, terms, kind)
+        perm = rng.permutation(n).astype(np.uint64)
+        got = hip.download(hip.permute_bitlen(n, dv, dbl, hip.upload(perm.astype(np.uint32))))
+        assert np.array_equal(got, oracle.permute_ciphertext(n, perm, v, bl)), (n, terms, kind)
+        if kind == "canon":
+            dmask = hip.upload(hip.key_mask(n, key))
+            assert hip.decrypt_bitlen(n, dkey, dv, dbl) == int(hip.download(hip.decrypt_uniform(n, 1, terms, dv, dmask))[0])
+            assert np.array_equal(got, hip.download(hip.permute_uniform(n, 1, terms, dv, hip.upload(perm.astype(np.uint32)))))
+
+
 # -------------------------------------------------------------------------- permutation
 
 def test_permutation_golden(hip, oracle, kat):
@@ -730,14 +790,17 @@ def test_permute_all_word_counts(hip, oracle, n):
     assert np.array_equal(hip.download(hip.permute_uniform(n, 3, 3, hip.upload(w), dperm, per_term=True)), out)
 
 
-@pytest.mark.parametrize("n", [1, 31, 63, 64, 65, 130, 1247, 1280, 4096, 4100, 8192, 10000])
-@pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot"])
+@pytest.mark.parametrize("n", [1, 31, 63, 64, 65, 130, 1247, 1280, 1300, 4096, 4100, 8192, 10000, 16384])
+@pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot", "planes-v1", "planes-v2", "planes-v2-narrow", "planes-w1", "planes-w3", "planes-w16"])
 def test_permute_kernel_forms(hip, oracle, knobs, n, form):
     """Bit-plane form (64 terms per wave, 64x64 bit transposes; 16- and 8-byte staging) against
     the ballot form and the oracle, on batches that leave ragged last waves; strided first-term
     input and per-term mode."""
     knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
-    knobs.set("CSGN_PERM_NARROW", "1" if form == "planes-narrow" else "0")
+    knobs.set("CSGN_PERM_NARROW", "1" if form.endswith("narrow") else "0")
+    knobs.set("perm_v1", 1 if form.startswith("planes-v1") else 2 if form.startswith("planes-v2") else 0)
+    if form.startswith("planes-w"):
+        knobs.set("perm_waves", int(form[len("planes-w"):]))
     dl = oracle.default_len(n)
     rng = np.random.default_rng(1000 + n)
     perm = rng.permutation(n).astype(np.uint64)
@@ -778,11 +841,14 @@ def test_permute_forms_fuzz(hip, oracle, knobs):
         per_term = bool(rng.integers(0, 2)) if terms_in > 1 else False
         W = hip.synth_fill(it, n, 0, batch * terms_in * dl)
         outs = []
-        for form in ("planes", "narrow", "ballot"):
+        for form in ("planes", "narrow", "ballot", "v1", "waves", "v2"):
             knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
             knobs.set("CSGN_PERM_NARROW", "1" if form == "narrow" else "0")
+            knobs.set("perm_v1", 1 if form == "v1" else 2 if form == "v2" else 0)
+            knobs.set("perm_waves", int(rng.integers(1, 17)) if form == "waves" else 0)
             outs.append(hip.permute_uniform(n, batch, terms_in, W, dperm, per_term=per_term).clone())
-        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (n, batch, terms_in, per_term)
+        for o in outs[:2] + outs[3:]:
+            assert torch.equal(o, outs[2]), (n, batch, terms_in, per_term)
         if it % 10 == 3:                              # a true permutation (it % 5 != 0): oracle too
             hw, ho = hip.download(W), hip.download(outs[0])
             stride = dl if per_term else terms_in * dl

@@ -255,3 +255,25 @@ def test_keyed_plaintext0_rule_has_the_reference_distribution(oracle):
                 mine[word] = mine.get(word, 0) + Fraction(1, 2 ** n)
         assert sum(ref.values()) == 1 and sum(mine.values()) == 1
         assert ref == mine, key
+
+
+# ------------------------------------- non-canonical bitlen: (v, bitlen) as a bit stream
+
+KAT_BITLEN_PATH = os.path.join(os.path.dirname(__file__), "golden", "csgn_kat_bitlen.json")
+
+
+def test_golden_bitlen_stream_decrypt_and_permute(oracle):
+    """Ciphertexts with a Bitlen other than 64,...,64,N%64 (4-argument constructor / setBitlen):
+    decrypt and permutation of the genuine reference, which reads (v, bitlen) as a bit stream
+    (src/SecretKey.cpp:104-147, src/Ciphertext.cpp:16-69)."""
+    with open(KAT_BITLEN_PATH) as f:
+        cases = json.load(f)["bitlen_stream"]
+    assert len(cases) >= 10 and {c["dec"] for c in cases} == {0, 1}
+    for c in cases:
+        n = c["n"]
+        key = np.array(c["key"], dtype=np.uint64)
+        v, bl = words(c["v"]), np.array(c["bitlen"], dtype=np.uint64)
+        assert oracle.decrypt(n, key, v, bl) == c["dec"], (n, c["pattern"])
+        got = oracle.permute_ciphertext(n, np.array(c["perm"], dtype=np.uint64), v, bl)
+        assert np.array_equal(got, words(c["permuted"])), (n, c["pattern"])
+        assert c["permuted_bitlen"] == [int(x) for x in canonical_bitlen(n, 1)] or n % 64 == 0

@@ -241,3 +241,25 @@ def test_text_forms_match_reference(oracle, ref, n, d):
     assert ref.text("plaintext", n, d, length=0) == text_plaintext(0) == "0\n"
     perm = ref.perm_random(n, 4)
     assert ref.text("permutation", n, d, perm, None, n) == text_permutation(perm)
+
+
+@pytest.mark.parametrize("n,d", [(1247, 16), (4096, 32), (65, 4), (130, 5), (200, 6)])
+def test_noncanonical_bitlen_stream_semantics(oracle, ref, n, d):
+    """decrypt / permutation of ciphertexts whose Bitlen is not the canonical pattern: restatement
+    vs the genuine reference on random patterns that keep every addressed position inside the
+    stream (src/SecretKey.cpp:104-147, src/Ciphertext.cpp:16-69)."""
+    rng = np.random.default_rng(n * 7 + d)
+    dl = oracle.default_len(n)
+    for terms in (1, 2, 6, 17):
+        key = rng.permutation(n)[:d].astype(np.uint64)
+        v = oracle.synth(int(rng.integers(1, 1 << 30)), n, 0, terms * dl)
+        bl = np.full(terms * dl, 64, dtype=np.uint64)
+        slack = int(64 * terms * dl - n * terms)
+        cut = rng.integers(0, 4, size=terms * dl)
+        while int(cut.sum()) > slack:
+            cut[rng.integers(0, cut.size)] = 0
+        bl -= cut.astype(np.uint64)
+        assert ref.decrypt(n, d, key, v, bl) == oracle.decrypt(n, key, v, bl)
+        perm = ref.perm_random(n, int(rng.integers(1, 1 << 20)))
+        want, wbl = ref.permute_ciphertext(n, d, perm, v, bl)
+        assert np.array_equal(oracle.permute_ciphertext(n, perm, v, bl), want)
