@@ -258,6 +258,100 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Ragged batches, indexed form (round 2).  The flat kernel above keeps ONE dependent chain of loads
+// in flight per wave (search -> operand offsets -> operand units -> store), 1 KiB of output per
+// chain: with cold operands every link is an L2 / HBM miss and a CU's 32 wave slots cannot keep
+// more than ~13 KB per microsecond moving (measured 3.3 TB/s cold, 5.5 warm).  Here
+//   * a side table built once per call -- the pair that owns every 32nd output term -- replaces the
+//     log2(batch)-deep search by one load, and makes every 4 KiB chunk independent of its neighbours;
+//   * each lane carries M units (one per 4 KiB chunk, so every wave instruction is still one
+//     coalesced 1 KiB access) through the chain STAGE BY STAGE: M table loads, then 2M offset loads,
+//     then 3M operand-offset loads, then 2M operand loads, then M stores.  Four links instead of
+//     six to twenty, and M KiB of output per wave in flight on each.
+// Lanes whose term is not in the table's pair or its successor (runs of tiny or empty pairs) take
+// the galloping search between the stages.
+// ---------------------------------------------------------------------------------------
+constexpr u32 kTabShift = 5;                        // one table entry per 32 output terms
+
+__global__ void __launch_bounds__(256) k_ragged_table(const u64 *__restrict__ offOut, u32 batch, u64 nent,
+                                                      u32 *__restrict__ table)
+{
+    const u64 e = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (e < nent)
+        table[e] = csr_find(offOut, 0u, batch, e << kTabShift);
+}
+
+template <typename Unit, int M>
+__global__ void __launch_bounds__(256) k_mul_ragged_tab(const Unit *__restrict__ L,
+                                                        const u64 *__restrict__ offL,
+                                                        const Unit *__restrict__ R,
+                                                        const u64 *__restrict__ offR,
+                                                        Unit *__restrict__ out,
+                                                        const u64 *__restrict__ offOut,
+                                                        const u32 *__restrict__ table, u32 batch,
+                                                        u64 unit_base, u64 total_units, u32 U, FastDiv dU)
+{
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g_begin = unit_base + (u64)bid * (256u * M);
+    if (g_begin >= total_units)
+        return;
+    const u64 term0 = g_begin / U;                              // workgroup-uniform
+    const u32 r0blk = (u32)(g_begin - term0 * U);
+    const u64 last = total_units - 1;
+    u64 term[M];
+    u32 k[M], p[M];
+    bool live[M];
+    // A. table
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const u64 g = g_begin + (u32)m * 256u + threadIdx.x;
+        live[m] = g <= last;
+        const u32 r = r0blk + (u32)m * 256u + threadIdx.x;      // distance from the workgroup's first term, in units
+        const u32 dt = csgn_fastdiv(r, dU);
+        term[m] = min(term0 + dt, last / U);                    // lanes past the end repeat the last term
+        k[m] = live[m] ? r - dt * U : 0u;
+        p[m] = table[term[m] >> kTabShift];
+    }
+    // B. the table's pair owns term 32e; this lane's term (up to 31 further on) is in it unless the
+    //    next pair starts at or before the term
+    u64 o0[M], o1[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        o0[m] = offOut[p[m]];
+        o1[m] = offOut[min(p[m] + 1u, batch)];
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (p[m] + 1u < batch && o1[m] <= term[m]) {            // rare for pairs of more than 32 product terms
+            p[m] = csr_gallop(offOut, p[m] + 1u, batch, term[m]);
+            o0[m] = offOut[p[m]];
+        }
+    // C. operand offsets of the pair
+    u64 l0[M], rr0[M], rr1[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        l0[m] = offL[p[m]];
+        rr0[m] = offR[p[m]];
+        rr1[m] = offR[p[m] + 1u];
+    }
+    // D. operand units
+    Unit lv[M], rv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const u32 t2 = max((u32)(rr1[m] - rr0[m]), 1u);
+        const u32 q = (u32)(term[m] - o0[m]);                   // product term index inside the pair
+        const u32 i = q / t2, j = q - i * t2;
+        lv[m] = L[(l0[m] + i) * U + k[m]];
+        rv[m] = R[(rr0[m] + j) * U + k[m]];
+    }
+    // E. the product
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (live[m])
+            unit_store<Unit, true>(out + g_begin + (u32)m * 256u + threadIdx.x, lv[m] & rv[m]);
+}
+
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
 // launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
 // and the fix-up -- 1M pairs plan in tens of microseconds.
@@ -737,6 +831,52 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
+    // Indexed form for outputs of 32 MB and more (the table costs one extra launch and a
+    // stream-ordered allocation of 4 bytes per 32 output terms); knob ragged_table = 0 keeps the
+    // searching kernel, 2 / 4 / 8 set the units per lane (default 4), a negative value drops the size
+    // threshold.
+    const int tab_knob = csgn::tune(TUNE_RAGGED_TABLE);       // < 0: whatever the size (tests)
+    if (tab_knob != 0 && (tab_knob < 0 || total_units * (wide ? 16u : 8u) >= (32ull << 20)) &&
+        total_out_terms < (1ull << 37)) {
+        const u64 nent = (total_out_terms >> kTabShift) + 1;
+        u32 *table = nullptr;
+        if (hipMallocAsync((void **)&table, nent * sizeof(u32), s) == hipSuccess) {
+            k_ragged_table<<<ceil_div_u64(nent, 256u), 256, 0, s>>>(offOut, (u32)batch, nent, table);
+            const int mreq = tab_knob < 0 ? -tab_knob : tab_knob;
+            const int M = (mreq == 2 || mreq == 4 || mreq == 8) ? mreq : 4;
+            const bool touch = wide && total_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+            const u64 per_launch = touch ? (1ull << 26) : (kMaxBlocks256 / 8u) * 256u * (u64)M;   // units
+            hipError_t le = hipGetLastError();
+            for (u64 u0 = 0; u0 < total_units && le == hipSuccess; u0 += per_launch) {
+                const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
+                const u32 blocks = ceil_div_u64(nu, 256u * (u32)M);
+                if (touch)
+                    k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
+                                                       reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
+                                                       u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
+#define CSGN_RAGGED_TAB(MM)                                                                             \
+    do {                                                                                                \
+        if (wide)                                                                                       \
+            k_mul_ragged_tab<unit16, MM><<<blocks, 256, 0, s>>>(                                        \
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,   \
+                reinterpret_cast<unit16 *>(out), offOut, table, (u32)batch, u0, u0 + nu, U, dU);        \
+        else                                                                                            \
+            k_mul_ragged_tab<unit8, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, table,    \
+                                                               (u32)batch, u0, u0 + nu, U, dU);         \
+    } while (0)
+                switch (M) {
+                case 2: CSGN_RAGGED_TAB(2); break;
+                case 8: CSGN_RAGGED_TAB(8); break;
+                default: CSGN_RAGGED_TAB(4); break;
+                }
+#undef CSGN_RAGGED_TAB
+                le = hipGetLastError();
+            }
+            const hipError_t fe = hipFreeAsync(table, s);
+            return le != hipSuccess ? le : fe;
+        }
+        (void)hipGetLastError();        // no stream-ordered allocator: the searching kernel below needs none
+    }
     const int chunks = ragged_chunks(total_units);
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need

@@ -765,7 +765,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         // per group: 4 groups per CU 4.9-5.0 TB/s, 6 groups 4.3).  Equal trip counts per workgroup.
         auto grid_for = [&](int occ) -> u32 {
             u64 per_cu = (u64)std::max(1, occ);
-            per_cu = std::min<u64>(per_cu, std::max<u32>(1u, 20u / W));
+            per_cu = std::min<u64>(per_cu, std::max<u32>(1u, (20u + W - 1) / W));
             if (persist > 1)
                 per_cu = (u64)persist;
             const u64 resident = persist == 0 ? groups : (u64)cus * per_cu;

@@ -1429,11 +1429,17 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     dOL, dOR = hip.upload(offL), hip.upload(offR)
     knobs.set("CSGN_RAGGED_FLAT", "1")
     knobs.set("CSGN_RAGGED_TOUCH", "0")
+    knobs.set("ragged_table", 0)                                # the searching kernel, unsliced
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
     ref = ref.clone()
-    knobs.set("CSGN_RAGGED_TOUCH", "1")
+    knobs.set("CSGN_RAGGED_TOUCH", "1")                         # ... sliced with the touch pass
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
+    for tab, touch in ((1, 1), (1, 0), (8, 1)):                 # the indexed kernel (default for this size)
+        knobs.set("ragged_table", tab)
+        knobs.set("CSGN_RAGGED_TOUCH", touch)
+        out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+        assert torch.equal(out, ref) and torch.equal(off, ref_off), (tab, touch)
     mo = hip.download(off)
     assert np.array_equal(mo, csr((t1s * t2s).tolist()))
     cut_term = (1 << 26) // 10                                  # first term of the second slice
@@ -1448,8 +1454,9 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
 def test_ragged_forms_fuzz(hip, oracle, knobs):
     """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
     ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
-    prefetch off / 32 / 5000 pairs ahead, and through the default dispatch: identical words; every
-    fifth batch is compared pair by pair with the oracle."""
+    prefetch off / 32 / 5000 pairs ahead, through the indexed multiply (side table, 2 / 4 / 8 units
+    per lane) and through the default dispatch: identical words; every fifth batch is compared pair
+    by pair with the oracle."""
     import torch
     rng = np.random.default_rng(4242 + FUZZ_SEED)
     for it in range(30):
@@ -1472,8 +1479,12 @@ def test_ragged_forms_fuzz(hip, oracle, knobs):
         ref_mul = ref_add = None
         for env in ({}, {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "1", "CSGN_RAGGED_PF": "0"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "8", "CSGN_RAGGED_PF": "32"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "16", "CSGN_RAGGED_PF": "5000"}):
-            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF"):
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "16", "CSGN_RAGGED_PF": "5000"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-4"},          # indexed form, whatever the size
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-2"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-8"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "0"}):
+            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE"):
                 knobs.unset(k)
             for k, v in env.items():
                 knobs.set(k, v)

@@ -7,7 +7,8 @@ from csgn_amd.batch import HipPath, check
 from csgn_amd import capi
 CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
-VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no slice touch',{'CSGN_RAGGED_TOUCH':'0'}),('cold, no touch, no prefetch',{'CSGN_RAGGED_TOUCH':'0','CSGN_RAGGED_PF':'0'}),('same, no touch',{'NSETS':'1','CSGN_RAGGED_TOUCH':'0'})]
+VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no slice touch',{'CSGN_RAGGED_TOUCH':'0'}),('cold M=2',{'CSGN_RAGGED_TABLE':'2'}),('cold M=8',{'CSGN_RAGGED_TABLE':'8'}),('cold M=8 no touch',{'CSGN_RAGGED_TABLE':'8','CSGN_RAGGED_TOUCH':'0'}),
+          ('r1 kernel: same',{'NSETS':'1','CSGN_RAGGED_TABLE':'0'}),('r1 kernel: cold',{'CSGN_RAGGED_TABLE':'0'}),('r1 kernel: cold, no touch',{'CSGN_RAGGED_TABLE':'0','CSGN_RAGGED_TOUCH':'0'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]

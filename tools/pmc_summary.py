@@ -82,6 +82,36 @@ def main():
             lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
             if lines:
                 out.setdefault("bench_lines", {})[name] = json.loads(lines[-1])
+    # profiles/traffic_current.json: what bench.py reports as roofline.traffic -- tied to the launch
+    # shape and to the kernel source it was measured on (bench.py drops it when either differs)
+    if "--traffic-json" in sys.argv and wn and rn:
+        line = None
+        for name in ("pmc_WRITE_SIZE.json", "bench_trace.json"):
+            line = out.get("bench_lines", {}).get(name) or line
+        if line:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            cfg = line["config"]
+            traffic = {
+                "kernel": kernel_arg, "n_bits": cfg["n_bits"], "terms": cfg["terms"],
+                "pairs_per_launch": cfg["pairs_per_launch"],
+                "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
+                "hbm_write_bytes_per_launch": out["hbm_write_bytes_per_launch"],
+                "hbm_read_bytes_per_launch": out["hbm_read_bytes_per_launch"],
+                "read_bytes_by_kernel": {k: v * 1024 * 2 for k, v in out["fetch_size_kib_raw_by_kernel"].items()},
+                "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
+                "kernel_source_sha16": bench.kernel_source_hash(),
+                "captured": sys.argv[sys.argv.index("--traffic-json") + 2] if len(sys.argv) > sys.argv.index("--traffic-json") + 2 else dst,
+                "batch_per_gpu": cfg["batch_per_gpu"], "pmc_launches_sampled": [wn, rn],
+                "method": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes, program directly after -- "
+                          "(python3 bench.py); KiB units; FETCH_SIZE x2 (gfx950 wide-read correction); WRITE_SIZE exact. "
+                          "Reads = operands once by k_touch (from HBM) + once by k_mul_flat (L2 fills served by the "
+                          "memory-side cache the touch filled; the L2-side counter cannot tell them from HBM reads, "
+                          "so both are counted)",
+            }
+            with open(sys.argv[sys.argv.index("--traffic-json") + 1], "w") as f:
+                json.dump(traffic, f, indent=1)
+                f.write("\n")
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst + "_summary.json", "w") as f:
         json.dump(out, f, indent=1)
