@@ -266,11 +266,17 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
 //   * a side table built once per call -- the pair that owns every 32nd output term -- replaces the
 //     log2(batch)-deep search by one load, and makes every 4 KiB chunk independent of its neighbours;
 //   * each lane carries M units (one per 4 KiB chunk, so every wave instruction is still one
-//     coalesced 1 KiB access) through the chain STAGE BY STAGE: M table loads, then 2M offset loads,
-//     then 3M operand-offset loads, then 2M operand loads, then M stores.  Four links instead of
-//     six to twenty, and M KiB of output per wave in flight on each.
+//     coalesced 1 KiB access) through the chain STAGE BY STAGE: M table loads, then 5M offset loads
+//     (product and operand offsets of the table's pair together), then 2M operand loads, then M
+//     stores.  Three links instead of six to twenty, and M KiB of output per wave in flight on each.
 // Lanes whose term is not in the table's pair or its successor (runs of tiny or empty pairs) take
 // the galloping search between the stages.
+// MEASURED (profiles/r02/bench_ragged.log): it loses to the searching kernel on every batch tried --
+// log-normal batch 3.8 vs 4.8 TB/s with the operands cached, 3.1-3.5 vs 4.6 cold; 1 M ragged 1x1
+// pairs 2.6 vs 3.2 -- so it is OFF by default (knob ragged_table) and kept as the record of the
+// experiment VERDICT r1 #10 asked for.  The searching kernel's workgroup-uniform search runs on the
+// scalar unit and its per-chunk walk is one broadcast load; the table form pays a table build, a
+// stream-ordered allocation and 64-bit address arithmetic for five offset loads per unit.
 // ---------------------------------------------------------------------------------------
 constexpr u32 kTabShift = 5;                        // one table entry per 32 output terms
 
@@ -314,27 +320,27 @@ __global__ void __launch_bounds__(256) k_mul_ragged_tab(const Unit *__restrict__
         p[m] = table[term[m] >> kTabShift];
     }
     // B. the table's pair owns term 32e; this lane's term (up to 31 further on) is in it unless the
-    //    next pair starts at or before the term
-    u64 o0[M], o1[M];
+    //    next pair starts at or before the term.  The pair's operand offsets are fetched in the same
+    //    round trip, on the bet that the table's pair is the right one.
+    u64 o0[M], o1[M], l0[M], rr0[M], rr1[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         o0[m] = offOut[p[m]];
         o1[m] = offOut[min(p[m] + 1u, batch)];
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        if (p[m] + 1u < batch && o1[m] <= term[m]) {            // rare for pairs of more than 32 product terms
-            p[m] = csr_gallop(offOut, p[m] + 1u, batch, term[m]);
-            o0[m] = offOut[p[m]];
-        }
-    // C. operand offsets of the pair
-    u64 l0[M], rr0[M], rr1[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
         l0[m] = offL[p[m]];
         rr0[m] = offR[p[m]];
-        rr1[m] = offR[p[m] + 1u];
+        rr1[m] = offR[min(p[m] + 1u, batch)];
     }
+    // C. lost bets (rare for pairs of more than 32 product terms): search on, fetch again
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (p[m] + 1u < batch && o1[m] <= term[m]) {
+            p[m] = csr_gallop(offOut, p[m] + 1u, batch, term[m]);
+            o0[m] = offOut[p[m]];
+            l0[m] = offL[p[m]];
+            rr0[m] = offR[p[m]];
+            rr1[m] = offR[p[m] + 1u];
+        }
     // D. operand units
     Unit lv[M], rv[M];
 #pragma unroll
@@ -831,10 +837,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    // Indexed form for outputs of 32 MB and more (the table costs one extra launch and a
-    // stream-ordered allocation of 4 bytes per 32 output terms); knob ragged_table = 0 keeps the
-    // searching kernel, 2 / 4 / 8 set the units per lane (default 4), a negative value drops the size
-    // threshold.
+    // Indexed form (opt-in, see k_mul_ragged_tab: measured slower): knob ragged_table = 1 uses it for
+    // outputs of 32 MB and more (the table costs one extra launch and a stream-ordered allocation of
+    // 4 bytes per 32 output terms), 2 / 4 / 8 set the units per lane (default 4), a negative value
+    // drops the size threshold.
     const int tab_knob = csgn::tune(TUNE_RAGGED_TABLE);       // < 0: whatever the size (tests)
     if (tab_knob != 0 && (tab_knob < 0 || total_units * (wide ? 16u : 8u) >= (32ull << 20)) &&
         total_out_terms < (1ull << 37)) {
