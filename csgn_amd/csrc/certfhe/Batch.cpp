@@ -219,7 +219,8 @@ Ciphertext CiphertextBatch::at(uint64_t i) const
 
 // ------------------------------------------------------------------ BatchCircuit
 
-BatchCircuit::BatchCircuit(const Context &context, uint64_t count) : handle(nullptr), ctx(context), count_(count)
+BatchCircuit::BatchCircuit(const Context &context, uint64_t count)
+    : handle(nullptr), ctx(context), count_(count), next_first(0)
 {
     detail::ensureDevice();
     detail::check(csgn_circuit_create(ctx.getN(), count, &handle), "csgn_circuit_create");
@@ -238,6 +239,53 @@ unsigned BatchCircuit::input(uint64_t terms)
     uint32_t id = 0;
     detail::check(csgn_circuit_input(handle, terms, &id), "csgn_circuit_input");
     return id;
+}
+
+unsigned BatchCircuit::encryptInput(const SecretKey &key)
+{
+    if (!key.certFHEContext || key.certFHEContext->getN() != ctx.getN())
+        throw std::invalid_argument("certFHE::BatchCircuit::encryptInput: key and circuit differ in N");
+    key.ensureMask();
+    masks.push_back(key.device_mask);
+    const uint64_t d = (uint64_t)key.length;
+    // one block: [key indices (d words)][plaintext bytes, zero until setPlain()]
+    std::vector<uint64_t> stage(d + (count_ + 7) / 8, 0);
+    for (uint64_t i = 0; i < d; ++i)
+        stage[i] = key.s[i];
+    std::shared_ptr<DevicePayload> blk = detail::uploadWords(stage.data(), stage.size());
+    volatile uint64_t *wipe = stage.data();
+    for (uint64_t i = 0; i < d; ++i)
+        wipe[i] = 0;
+    masks.push_back(blk);
+    csgn_rng rng;
+    detail::check(csgn_rng_from_os(&rng, 8), "csgn_rng_from_os");
+    uint32_t id = 0;
+    detail::check(csgn_circuit_encrypt(handle, d, reinterpret_cast<const uint8_t *>(blk->data() + d), blk->data(),
+                                       key.device_mask->data(), &rng, next_first, &id),
+                  "csgn_circuit_encrypt");
+    volatile uint32_t *wk = rng.key;
+    for (int i = 0; i < 8; ++i)
+        wk[i] = 0;
+    next_first += (uint64_t)1 << 40;                // every encrypt input draws from its own range
+    plains.push_back(std::make_pair((unsigned)id, blk));
+    return id;
+}
+
+void BatchCircuit::setPlain(unsigned encrypted_input, const std::vector<unsigned char> &bits)
+{
+    if (bits.size() != count_)
+        throw std::invalid_argument("certFHE::BatchCircuit::setPlain: one bit per element expected");
+    for (size_t i = 0; i < plains.size(); ++i)
+        if (plains[i].first == encrypted_input) {
+            // the key indices occupy the first words of the block; the bytes follow
+            const uint64_t d_words = plains[i].second->words - (count_ + 7) / 8;
+            detail::check(csgn_memcpy_h2d(plains[i].second->data() + d_words, bits.data(), (size_t)count_,
+                                          detail::stream()),
+                          "csgn_memcpy_h2d");
+            detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");
+            return;
+        }
+    throw std::invalid_argument("certFHE::BatchCircuit::setPlain: not an encrypted input of this circuit");
 }
 
 unsigned BatchCircuit::add(unsigned a, unsigned b)

@@ -694,16 +694,24 @@ struct csgn_circuit {
         size_t offset;        // bytes into block
     };
     struct Op {
-        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute
+        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator)
         uint32_t a, b, out;
-        const void *mask;     // decrypt: key mask (u64 words); permute: permutation (u32 entries)
+        const void *mask;     // decrypt / encrypt: key mask (u64 words); permute: permutation (u32 entries)
         size_t scratch, bits; // byte offsets (decrypt)
+        // encrypt only
+        const uint8_t *plain;
+        const uint64_t *key;
+        uint64_t d, first;
+        csgn_rng rng;
     };
     uint64_t n_bits = 0, batch = 0;
     std::vector<Value> values;
     std::vector<Op> ops;
     std::vector<size_t> bits_offsets;
     size_t bytes = 0;
+    size_t epoch_offset = 0;  // u64 run counter in the block, bumped by the graph's first node
+    bool has_encrypt = false;
+    uint64_t runs = 0;
     void *block = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -775,7 +783,12 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
                     (unsigned long long)c->batch, (unsigned long long)terms);
     c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
     const uint32_t out = (uint32_t)(c->values.size() - 1);
-    c->ops.push_back({kind, a, b, out, nullptr, 0, 0});
+    csgn_circuit::Op op = {};
+    op.kind = kind;
+    op.a = a;
+    op.b = b;
+    op.out = out;
+    c->ops.push_back(op);
     *value = out;
     return CSGN_OK;
 }
@@ -789,7 +802,13 @@ int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, ui
     REQUIRE(a < c->values.size(), "operand value does not exist");
     const size_t scratch = circuit_reserve(c, csgn::decrypt_scratch_bytes(c->batch, c->batch * c->values[a].terms));
     const size_t bits = circuit_reserve(c, (size_t)c->batch);
-    c->ops.push_back({2, a, 0, 0, d_mask, scratch, bits});
+    csgn_circuit::Op op = {};
+    op.kind = 2;
+    op.a = a;
+    op.mask = d_mask;
+    op.scratch = scratch;
+    op.bits = bits;
+    c->ops.push_back(op);
     c->bits_offsets.push_back(bits);
     *bits_id = (uint32_t)(c->bits_offsets.size() - 1);
     return CSGN_OK;
@@ -803,10 +822,50 @@ int csgn_circuit_permute(csgn_circuit *c, uint32_t a, const uint32_t *d_perm, ui
     const uint64_t dl = csgn_default_len(c->n_bits);
     c->values.push_back({1, circuit_reserve(c, (size_t)(c->batch * dl * 8))});
     const uint32_t out = (uint32_t)(c->values.size() - 1);
-    c->ops.push_back({3, a, 0, out, d_perm, 0, 0});
+    csgn_circuit::Op op = {};
+    op.kind = 3;
+    op.a = a;
+    op.out = out;
+    op.mask = d_perm;
+    c->ops.push_back(op);
     *value = out;
     return CSGN_OK;
 }
+
+int csgn_circuit_encrypt(csgn_circuit *c, uint64_t d, const uint8_t *d_plain, const uint64_t *d_key,
+                         const uint64_t *d_mask, const csgn_rng *h_rng, uint64_t first_ciphertext,
+                         uint32_t *value)
+{
+    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
+    REQUIRE(d_plain && d_key && d_mask && h_rng, "null argument");
+    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
+    REQUIRE(h_rng->rounds == 8 || h_rng->rounds == 12 || h_rng->rounds == 20, "rng rounds must be 8, 12 or 20");
+    REQUIRE(first_ciphertext + c->batch >= first_ciphertext && first_ciphertext + c->batch < (1ull << 56),
+            "ciphertext index range too large");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    if (!product_below(c->batch, 1, dl, 1ull << 57))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)c->batch);
+    if (!c->has_encrypt) {
+        c->has_encrypt = true;
+        c->epoch_offset = circuit_reserve(c, 8);
+    }
+    c->values.push_back({1, circuit_reserve(c, (size_t)(c->batch * dl * 8))});
+    const uint32_t out = (uint32_t)(c->values.size() - 1);
+    csgn_circuit::Op op = {};
+    op.kind = 4;
+    op.out = out;
+    op.mask = d_mask;
+    op.plain = d_plain;
+    op.key = d_key;
+    op.d = d;
+    op.first = first_ciphertext;
+    op.rng = *h_rng;
+    c->ops.push_back(op);
+    *value = out;
+    return CSGN_OK;
+}
+
+uint64_t csgn_circuit_epoch(const csgn_circuit *c) { return c ? c->runs : 0; }
 
 int csgn_circuit_build(csgn_circuit *c)
 {
@@ -831,9 +890,27 @@ int csgn_circuit_build(csgn_circuit *c)
         }
     }
     unsigned char *base = static_cast<unsigned char *>(c->block);
+    uint64_t *epoch = reinterpret_cast<uint64_t *>(base + c->epoch_offset);
+    if (c->has_encrypt) {
+        const hipError_t ez = hipMemset(epoch, 0, 8);
+        if (ez != hipSuccess) {
+            (void)hipStreamDestroy(s);
+            return hip_fail(ez, "hipMemset (circuit epoch)");
+        }
+        c->runs = 0;
+    }
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess && c->has_encrypt)
+        e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under nonce + its own run number
     for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
         const csgn_circuit::Op &op = c->ops[i];
+        if (op.kind == 4) {
+            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
+            e = csgn::encrypt_keyed(c->n_bits, op.d, c->batch, op.first, op.plain, (const u64 *)op.key,
+                                    (const u64 *)op.mask, op.rng.key, op.rng.nonce, op.rng.rounds,
+                                    (const u64 *)epoch, (u64 *)O, s);
+            continue;
+        }
         const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);
         if (op.kind == 2) {
             const uint64_t t = c->values[op.a].terms;
@@ -892,6 +969,7 @@ int csgn_circuit_run(csgn_circuit *c, void *stream)
 {
     REQUIRE(c && c->exec, "the circuit is not built");
     HIP_TRY(hipGraphLaunch(c->exec, S(stream)));
+    c->runs += 1;
     return CSGN_OK;
 }
 

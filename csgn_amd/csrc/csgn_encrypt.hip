@@ -599,6 +599,16 @@ u32 gcd_u32(u32 a, u32 b)
 }
 } // namespace
 
+namespace {
+__global__ void k_bump_epoch(u64 *epoch) { *epoch += 1; }
+} // namespace
+
+hipError_t bump_epoch(u64 *d_epoch, hipStream_t s)
+{
+    k_bump_epoch<<<1, 1, 0, s>>>(d_epoch);
+    return hipGetLastError();
+}
+
 void encrypt_keyed_layout(u64 n_bits, u32 *U, u32 *P, u32 *Gc)
 {
     const u64 dL = (n_bits + 63) / 64;

@@ -43,6 +43,7 @@ hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, con
 hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
                    const u32 *chosen, const uint8_t *last, const u64 *mask, u64 *out, hipStream_t s);
 // Keyed (ChaCha) device-RNG encrypt; keystream layout in csgn_encrypt.hip.
+hipError_t bump_epoch(u64 *d_epoch, hipStream_t s);      // *d_epoch += 1 (head node of a circuit with encrypt inputs)
 void encrypt_keyed_layout(u64 n_bits, u32 *U, u32 *P, u32 *Gc);
 hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain, const u64 *key_idx,
                          const u64 *mask, const u32 rng_key[8], u64 nonce, u32 rounds,

@@ -10,6 +10,7 @@
 #define CERTFHE_BATCH_H
 
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "Ciphertext.h"
@@ -82,7 +83,9 @@ class BatchCircuit {
     ::csgn_circuit *handle;
     Context ctx;
     uint64_t count_;
-    std::vector<std::shared_ptr<detail::DevicePayload> > masks;   // key masks / permutations the graph refers to
+    std::vector<std::shared_ptr<detail::DevicePayload> > masks;   // key masks / permutations / plaintext bytes the graph refers to
+    std::vector<std::pair<unsigned, std::shared_ptr<detail::DevicePayload> > > plains;   // encrypt inputs: value id -> plaintext bytes
+    uint64_t next_first;                                           // stream range handed to the next encrypt input
     BatchCircuit(const BatchCircuit &);
     BatchCircuit &operator=(const BatchCircuit &);
 
@@ -90,6 +93,11 @@ class BatchCircuit {
     BatchCircuit(const Context &context, uint64_t count);
     ~BatchCircuit();
     unsigned input(uint64_t terms = 1);
+    // An input ENCRYPTED INSIDE THE GRAPH (csgn_circuit_encrypt): `count` fresh ciphertexts of the bits
+    // last given to setPlain(), under `key`, by the keyed generator with a key drawn from the OS here;
+    // every run() draws a new keystream.  No staging copy: Enc,Enc -> * -> Dec is one graph launch.
+    unsigned encryptInput(const SecretKey &key);
+    void setPlain(unsigned encrypted_input, const std::vector<unsigned char> &bits);
     unsigned add(unsigned a, unsigned b);
     unsigned mul(unsigned a, unsigned b);
     unsigned permute(unsigned a, const Permutation &p);   // applyPermutation: ONE term, the permuted first term

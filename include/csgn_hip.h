@@ -327,6 +327,19 @@ int csgn_circuit_decrypt(csgn_circuit *circuit, uint32_t a, const uint64_t *d_ma
 /* Ciphertext::applyPermutation on every element of value `a` (d_perm: N uint32 entries, must stay
  * valid): as in the reference the result is ONE term, the permuted first term. */
 int csgn_circuit_permute(csgn_circuit *circuit, uint32_t a, const uint32_t *d_perm, uint32_t *value);
+/* An INPUT produced inside the graph: batch fresh ciphertexts (one term each) of the plaintext bytes
+ * at d_plain, encrypted by the keyed generator (csgn_encrypt_keyed) straight into the circuit's block:
+ * no staging copy, and a fresh-ciphertext circuit Enc,Enc -> * / + -> Dec (BASELINE configs 2 and 4
+ * end to end) replays as ONE graph launch.  d_plain (batch bytes), d_key (D indices) and d_mask stay
+ * the caller's and must remain valid; rewrite d_plain between runs to encrypt other bits.  Element i
+ * of run r (r = 1, 2, ...; csgn_circuit_epoch after csgn_circuit_run) draws stream position
+ * first_ciphertext + i of the generator (h_rng->key, h_rng->nonce + r): the graph's first node
+ * increments the run counter on the device, so no replay re-uses a keystream.  Give every encrypt
+ * node of a circuit its own first_ciphertext range (or its own nonce). */
+int csgn_circuit_encrypt(csgn_circuit *circuit, uint64_t d, const uint8_t *d_plain, const uint64_t *d_key,
+                         const uint64_t *d_mask, const csgn_rng *h_rng, uint64_t first_ciphertext,
+                         uint32_t *value);
+uint64_t csgn_circuit_epoch(const csgn_circuit *circuit);      /* runs launched so far */
 int csgn_circuit_build(csgn_circuit *circuit);
 uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
 uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);

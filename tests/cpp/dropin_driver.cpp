@@ -617,6 +617,32 @@ static int cmd_graph(int count)
             EXPECT(psk.decrypt(e).getValue() == yb[j]);
         }
     }
+    {
+        // fresh-ciphertext circuit entirely inside one graph (BASELINE configs 2 / 4 end to end):
+        // two encrypted inputs, product and sum, both decrypted; new bits and a new keystream per run
+        BatchCircuit f(ctx, count);
+        unsigned ea = f.encryptInput(sk), eb = f.encryptInput(sk);
+        unsigned rm = f.decrypt(f.mul(ea, eb), sk), rs = f.decrypt(f.add(ea, eb), sk);
+        f.build();
+        std::vector<uint64_t> first_words;
+        for (int round = 0; round < 3; ++round) {
+            std::vector<unsigned char> ba(count), bb(count), wm(count), ws(count);
+            for (int i = 0; i < count; ++i) {
+                ba[i] = (unsigned char)((i * 7 + round) & 1);
+                bb[i] = (unsigned char)(((i >> 1) + round) & 1);
+                wm[i] = ba[i] & bb[i];
+                ws[i] = ba[i] ^ bb[i];
+            }
+            f.setPlain(ea, ba);
+            f.setPlain(eb, bb);
+            f.run();
+            EXPECT(f.bits(rm) == wm);
+            EXPECT(f.bits(rs) == ws);
+            EXPECT(f.value(ea).decrypt(sk) == ba);
+            first_words.push_back(f.value(ea).at(0).getValues()[0]);
+        }
+        EXPECT(first_words[0] != first_words[1] || first_words[1] != first_words[2]);
+    }
     printf("graph ok count=%d\n", count);
     return 0;
 }

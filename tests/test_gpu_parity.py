@@ -1351,6 +1351,68 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("n,d,batch", [(1247, 16, 65536), (1247, 16, 1000), (4096, 32, 77), (65, 3, 5000)])
+def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, batch):
+    """BASELINE configs 2 / 4 end to end as ONE hipGraph: two encrypt nodes (keyed generator writing
+    straight into the circuit's block), c1*c0 and c1+c0, two decrypts.  Every replay must use a new
+    keystream (nonce + run number, bumped on the device); ciphertext words equal the restated
+    definition, bits equal the clear circuit."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 31)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    rng = hip.rng_from_seed(99, 8)
+    rk, nonce = oracle.rng_from_seed(99)
+    pa = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    pb = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    first_b = 1 << 40                                           # second node: its own range of the stream
+    va = new(lib.csgn_circuit_encrypt, d, pa.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(rng), 0)
+    vb = new(lib.csgn_circuit_encrypt, d, pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(rng), first_b)
+    vm = new(lib.csgn_circuit_mul, va, vb)
+    vs = new(lib.csgn_circuit_add, va, vb)
+    bm = new(lib.csgn_circuit_decrypt, vm, dmask.data_ptr())
+    bs = new(lib.csgn_circuit_decrypt, vs, dmask.data_ptr())
+    check(lib.csgn_circuit_build(c))
+    assert lib.csgn_circuit_epoch(c) == 0
+    seen = []
+    for run in (1, 2, 3):
+        ha = np.random.default_rng(run).integers(0, 2, batch).astype(np.uint8)
+        hb = np.random.default_rng(100 + run).integers(0, 2, batch).astype(np.uint8)
+        pa.copy_(torch.from_numpy(ha))
+        pb.copy_(torch.from_numpy(hb))
+        check(lib.csgn_circuit_run(c, hip.stream))
+        assert lib.csgn_circuit_epoch(c) == run
+        def grab(v, terms):
+            t = hip.empty_words(batch * terms * dl)
+            check(lib.csgn_memcpy_d2d(t.data_ptr(), lib.csgn_circuit_value(c, v), batch * terms * dl * 8, hip.stream))
+            return t
+        ca, cb = grab(va, 1), grab(vb, 1)
+        sample = slice(0, min(batch, 3000) * dl)
+        assert np.array_equal(hip.download(ca)[sample],
+                              oracle.encrypt_keyed(n, key, ha[:min(batch, 3000)], rk, nonce + run, 8))
+        assert np.array_equal(hip.download(cb)[sample],
+                              oracle.encrypt_keyed(n, key, hb[:min(batch, 3000)], rk, nonce + run, 8, first_ciphertext=first_b))
+        assert torch.equal(grab(vm, 1), ca & cb)                # src/Ciphertext.cpp:124-131
+        both = grab(vs, 2).view(batch, 2 * dl)
+        assert torch.equal(both[:, :dl].reshape(-1), ca) and torch.equal(both[:, dl:].reshape(-1), cb)
+        for bid, want in ((bm, ha & hb), (bs, ha ^ hb)):
+            gb = torch.empty(batch, dtype=torch.uint8, device=hip.device)
+            check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+            assert np.array_equal(hip.download(gb), want)
+        seen.append(hip.download(ca)[:dl].copy())
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])   # no keystream re-use
+    lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("batch", [1, 3, 200])
 def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     """BASELINE config 5 as ONE hipGraph: Context(4096,32), a random Permutation applied to every
