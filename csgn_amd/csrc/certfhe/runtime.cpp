@@ -17,24 +17,33 @@ thread_local int g_requested = -1;    // Library::useDevice
 // again; re-use is ordered by the single stream all class operations run on, so a block that
 // an in-flight kernel still reads is only overwritten by work queued behind that kernel.
 struct BlockCache {
-    static const int kClasses = 48;
+    // Size classes: powers of two up to 1 MiB, four per octave above (1, 1.25, 1.5, 1.75 x 2^k), so a
+    // 168 MB product holds 176 MB of HBM instead of 256 MB.
+    static const int kClasses = 48 * 4;
     static const size_t kMaxCachedBlock = (size_t)256 << 20;   // larger blocks go straight back
     static const size_t kMaxCachedTotal = (size_t)4 << 30;
     std::vector<void *> free_list[kClasses];
     size_t cached_bytes;
     BlockCache() : cached_bytes(0) {}
     ~BlockCache() { release(); }
-    static int size_class(size_t bytes)
+    // class of the smallest capacity >= bytes; *capacity receives that capacity
+    static int size_class(size_t bytes, size_t *capacity)
     {
-        int c = 8;                                  // 256-byte minimum
-        while (((size_t)1 << c) < bytes)
-            ++c;
-        return c;
+        int k = 8;                                  // 256-byte minimum
+        while (((size_t)1 << k) < bytes)
+            ++k;
+        if (k <= 20 || bytes <= ((size_t)1 << (k - 1))) {
+            *capacity = (size_t)1 << k;
+            return 4 * k;
+        }
+        const size_t base = (size_t)1 << (k - 1), step = base >> 2;     // bytes in (base, 2*base]
+        const size_t q = (bytes - base + step - 1) / step;              // 1..4 quarters above base
+        *capacity = base + q * step;
+        return q == 4 ? 4 * k : 4 * (k - 1) + (int)q;
     }
     void *take(size_t bytes, size_t *capacity)
     {
-        const int c = size_class(bytes);
-        *capacity = (size_t)1 << c;
+        const int c = size_class(bytes, capacity);
         if (c < kClasses && !free_list[c].empty()) {
             void *p = free_list[c].back();
             free_list[c].pop_back();
@@ -53,7 +62,8 @@ struct BlockCache {
     void give(void *p, size_t capacity)
     {
         static const bool disabled = getenv("CSGN_NO_BLOCK_CACHE") != nullptr;   // A/B switch
-        const int c = size_class(capacity);
+        size_t same = 0;
+        const int c = size_class(capacity, &same);   // capacities are class sizes: same == capacity
         if (!disabled && c < kClasses && capacity <= kMaxCachedBlock && cached_bytes + capacity <= kMaxCachedTotal) {
             free_list[c].push_back(p);
             cached_bytes += capacity;
