@@ -11,7 +11,8 @@
 //   - the bitlen side-array is implied by (N, T) and only materialised when asked for;
 //     a ciphertext constructed with some other Bitlen keeps it on the host and follows
 //     the reference's propagation rules (left operand's term under *, concatenation
-//     under +), but cannot be decrypted or permuted on the device.
+//     under +); decrypt and applyPermutation then read (values, Bitlen) as the bit stream the
+//     reference reads (csgn_decrypt_bitlen / csgn_permute_bitlen), on the device as well.
 #ifndef CERTFHE_CIPHERTEXT_H
 #define CERTFHE_CIPHERTEXT_H
 
