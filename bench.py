@@ -70,6 +70,10 @@ def parse_args():
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes through torch.distributed.run even for --gpus 1")
     ap.add_argument("--verify-slots", type=int, default=8, help="arena slots compared with the oracle after timing")
+    ap.add_argument("--dev-ranks-share-gpu", action="store_true",
+                    help="DEVELOPMENT ONLY: every rank uses GPU 0 and the process group runs on gloo, so that the "
+                         "world > 1 logic (shards, offsets, verification, max-over-ranks) can be rehearsed on a "
+                         "one-GPU box; RCCL refuses two ranks on one device, so no RCCL number comes out of it")
     return ap.parse_args()
 
 
@@ -80,6 +84,8 @@ def spawn_ranks(args) -> int:
     import subprocess
     import torch
     visible = torch.cuda.device_count()
+    if args.dev_ranks_share_gpu and visible >= 1:
+        visible = args.gpus
     if visible < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but {visible} device(s) visible; refusing to run "
               f"on fewer GPUs than asked", file=sys.stderr)
@@ -243,6 +249,8 @@ def main():
     from csgn_amd.batch import HipPath
     from csgn_amd.shard import gather_term_counts, shard_range
 
+    if args.dev_ranks_share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
@@ -253,7 +261,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dev_ranks_share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
     hip = HipPath(local_rank)
@@ -287,7 +298,7 @@ def main():
     shard_lib = None
     if use_dist:
         collective = "torch.distributed.all_gather_into_tensor(result term counts) [RCCL]"
-        if args.collective == "native":
+        if args.collective == "native" and not args.dev_ranks_share_gpu:
             try:
                 shard_lib = capi.load_shard_library()
                 ident = [None]
@@ -303,19 +314,23 @@ def main():
             except Exception as e:           # a second RCCL path exists: say so and use it
                 print(f"# rank {rank}: native communicator unavailable ({e!r}); using torch.distributed", file=sys.stderr)
                 comm = None
-        ok_native = torch.tensor([1 if comm is not None else 0], device=dev)
+        cdev = torch.device("cpu") if args.dev_ranks_share_gpu else dev     # gloo reduces host tensors
+        ok_native = torch.tensor([1 if comm is not None else 0], device=cdev)
         dist.all_reduce(ok_native, op=dist.ReduceOp.MIN)      # all ranks must take the same path
         if int(ok_native.item()) == 0 and comm is not None:
             shard_lib.csgn_comm_destroy(comm)
             comm = None
         if comm is None:
-            collective = "torch.distributed.all_gather_into_tensor(result term counts) [RCCL]"
+            collective = "torch.distributed.all_gather_into_tensor(result term counts) [%s]" % (
+                "gloo, DEVELOPMENT rehearsal: ranks share one GPU" if args.dev_ranks_share_gpu else "RCCL")
     torch.cuda.synchronize()
 
     def gather():
         if comm is not None:
             capi.check_shard(shard_lib.csgn_comm_gather_counts(comm, counts.data_ptr(), total_pairs,
                                                                gathered.data_ptr(), hip.stream))
+        elif args.dev_ranks_share_gpu:
+            gathered.copy_(gather_term_counts(counts.cpu(), total_pairs, force=True))
         else:
             gather_term_counts(counts, total_pairs, out=gathered, force=True)
 
@@ -357,7 +372,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=(torch.device("cpu") if args.dev_ranks_share_gpu else dev))
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())

@@ -324,7 +324,11 @@ __device__ inline bool unit_covers_chain(unit16 v, unit16 m)
 // per-unit work beside the generator is: two LDS reads, one plaintext byte, the cover test, the OR
 // of the key mask, one store.  FULL: every ciphertext of the group is inside [first_ct, first_ct +
 // batch) (all but the first and last group of a launch).
-template <int ROUNDS, int P, bool FULL>
+// COMPACT: instead of the three per-unit tables (26 bytes per unit: 33 KB for the 1 280 units of an
+// N=1247 group, four workgroups per CU) ONE 4-byte entry per unit -- local ciphertext number, byte
+// offset of its key-mask unit, "last unit of a ciphertext" flag -- and the U mask units themselves
+// (5.3 KB): five more VALU instructions per unit, four times the resident waves.
+template <int ROUNDS, int P, bool FULL, bool COMPACT>
 __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, const uint2 *ttab,
                                      const unsigned short *ctab, u64 *cover, u32 lane, u64 group, u32 nonce_lo,
                                      u32 nonce_hi)
@@ -352,9 +356,22 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 r = (u32)p * 256u + (u32)q * 64u + lane;
-            const unit16 m = mtab[r];
-            const uint2 tl = ttab[r];
-            const u32 cl = ctab[r];
+            unit16 m;
+            uint2 tl;
+            u32 cl;
+            if (COMPACT) {
+                // mtab: the U mask units; ttab (as u32[]): one packed entry per unit of the group
+                const u32 e = reinterpret_cast<const u32 *>(ttab)[r];
+                cl = e & 0xFFFFu;
+                m = *reinterpret_cast<const unit16 *>(reinterpret_cast<const unsigned char *>(mtab) + ((e >> 16) & 0x7FFFu));
+                const u32 lastm = (u32)((int)e >> 31);                    // ~0 on a ciphertext's last unit
+                tl.x = a.tail_lo | ~lastm;
+                tl.y = a.tail_hi | ~lastm;
+            } else {
+                m = mtab[r];
+                tl = ttab[r];
+                cl = ctab[r];
+            }
             const bool inr = FULL || (cl - cl_lo < cl_hi - cl_lo);
             const u32 pl = plaing[FULL ? cl : min(max(cl, cl_lo), cl_hi - 1u)];
             unit16 v;
@@ -377,23 +394,36 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
         cover[lane] = ((u64)acc_hi << 32) | acc_lo;
 }
 
-template <int ROUNDS, int P>
+template <int ROUNDS, int P, bool COMPACT>
 __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr u32 R = 256u * P;                                                  // units per group
-    unit16 *mtab = reinterpret_cast<unit16 *>(smem_raw);                         // R key-mask units
-    uint2 *ttab = reinterpret_cast<uint2 *>(smem_raw + (size_t)R * 16u);         // R valid-bit masks (second word)
-    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (size_t)R * 24u);        // 4 waves x P*4 words
-    unsigned short *ctab = reinterpret_cast<unsigned short *>(smem_raw + (size_t)R * 24u + 4u * P * 4u * 8u);   // R local ciphertext numbers
-
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const u32 U = a.U;
-    for (u32 r = tid; r < R; r += 256u) {
-        const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
-        mtab[r] = a.mask[j];
-        ttab[r] = (j == U - 1u) ? make_uint2(a.tail_lo, a.tail_hi) : make_uint2(~0u, ~0u);
-        ctab[r] = (unsigned short)cl;
+    // full tables:    [mtab: R mask units][ttab: R tail masks][cover: 4 x P*4 words][ctab: R u16]
+    // compact tables: [mtab: U mask units, 16-byte aligned][etab: R u32][cover]
+    unit16 *mtab = reinterpret_cast<unit16 *>(smem_raw);
+    const size_t m_bytes = COMPACT ? (size_t)U * 16u : (size_t)R * 16u;
+    uint2 *ttab = reinterpret_cast<uint2 *>(smem_raw + m_bytes);
+    const size_t t_bytes = COMPACT ? (size_t)R * 4u : (size_t)R * 8u;
+    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + ((m_bytes + t_bytes + 7u) & ~(size_t)7u));
+    unsigned short *ctab = reinterpret_cast<unsigned short *>(cover_all + 4u * P * 4u);
+    if (COMPACT) {
+        for (u32 k = tid; k < U; k += 256u)
+            mtab[k] = a.mask[k];
+        u32 *etab = reinterpret_cast<u32 *>(ttab);
+        for (u32 r = tid; r < R; r += 256u) {
+            const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
+            etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0x80000000u : 0u);
+        }
+    } else {
+        for (u32 r = tid; r < R; r += 256u) {
+            const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
+            mtab[r] = a.mask[j];
+            ttab[r] = (j == U - 1u) ? make_uint2(a.tail_lo, a.tail_hi) : make_uint2(~0u, ~0u);
+            ctab[r] = (unsigned short)cl;
+        }
     }
     u64 *cover = cover_all + wave * (P * 4);
     __syncthreads();
@@ -414,9 +444,9 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
         const u64 cbase = group * a.Gc;
         const bool full = cbase >= a.first_ct && cbase + a.Gc <= a.first_ct + a.batch;
         if (full)
-            encrypt_group<ROUNDS, P, true>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
+            encrypt_group<ROUNDS, P, true, COMPACT>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
         else
-            encrypt_group<ROUNDS, P, false>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
+            encrypt_group<ROUNDS, P, false, COMPACT>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
         __builtin_amdgcn_wave_barrier();        // cover[] is private to this wave; its LDS operations run in order
         // src/SecretKey.cpp:51-76 for plaintext 0: if ALL D secret positions came out 1 the chosen one is
         // cleared (the reference draws the chosen position first and forces it to 0 when the others are
@@ -664,16 +694,26 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         }
         const u64 wg_needed = (a.ngroups + 3) / 4;
-        // Workgroups per CU (knob enc_wave = k > 1 forces k; >= 64 = one group per wave): 4 where the
-        // tables take 33 KB of LDS (P >= 3; N=1247), 16 for the small-table sizes (measured at N=4096 /
-        // 2048, 4 M ciphertexts: 3.4 -> 4.3 TB/s; profiles/r02/bench_encrypt.log)
-        const int per_cu = tune(TUNE_ENC_WAVE) > 1 ? tune(TUNE_ENC_WAVE) : (P >= 3 ? 4 : 16);
+        // Compact LDS tables where the full ones would limit residency (U*16 <= 32 KB for the offset
+        // field; knob enc_compact: -1 = auto, 0 / 1 forced)
+        const int ck = tune(TUNE_ENC_COMPACT);
+        const bool compact = U * 16u <= 32768u && (ck < 0 ? P >= 3 : ck != 0);
+        // Workgroups per CU (knob enc_wave = k > 1 forces k; >= 64 = one group per wave): 16 with the
+        // small tables, 4 where the full tables take 33 KB of LDS
+        const int per_cu = tune(TUNE_ENC_WAVE) > 1 ? tune(TUNE_ENC_WAVE) : ((P >= 3 && !compact) ? 4 : 16);
         const u64 resident = per_cu >= 64 ? wg_needed : (u64)cus * (u64)per_cu;
         u64 blocks = wg_needed <= resident ? wg_needed : resident;
         a.iters = (u32)((wg_needed + blocks - 1) / blocks);
         blocks = (wg_needed + a.iters - 1) / a.iters;         // equal trip counts
-        const size_t lds = (size_t)256u * P * 24u + 4u * P * 4u * 8u + (size_t)256u * P * 2u;
-#define CSGN_ENC_WAVE(R, PP) k_encrypt_wave<R, PP><<<(u32)blocks, 256, lds, s>>>(a)
+        const size_t lds = (compact ? (((size_t)U * 16u + 256u * P * 4u + 7u) & ~(size_t)7u)
+                                    : (size_t)256u * P * 24u) + 4u * P * 4u * 8u + (compact ? 0u : (size_t)256u * P * 2u);
+#define CSGN_ENC_WAVE(R, PP)                                                \
+    do {                                                                    \
+        if (compact)                                                        \
+            k_encrypt_wave<R, PP, true><<<(u32)blocks, 256, lds, s>>>(a);   \
+        else                                                                \
+            k_encrypt_wave<R, PP, false><<<(u32)blocks, 256, lds, s>>>(a);  \
+    } while (0)
 #define CSGN_ENC_WAVE_P(R)                  \
     switch (P) {                            \
     case 1: CSGN_ENC_WAVE(R, 1); break;     \

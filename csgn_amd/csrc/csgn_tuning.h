@@ -32,6 +32,7 @@ enum TuneKey {
     TUNE_DEC_LOOP,       // 1 = looping 256-term decrypt pass 1 instead of the segment form
     TUNE_ENC_LDS,        // 1 = LDS-staged encrypt kernel instead of the segment form
     TUNE_ENC_WAVE,       // device-RNG encrypt: 1 = wave-local kernel (default), 0 = segment kernel
+    TUNE_ENC_COMPACT,    // keyed encrypt: compact LDS tables: -1 = auto (groups of 3+ passes), 0 / 1 forced
     TUNE_COUNT
 };
 

@@ -467,12 +467,13 @@ KEYED_CONTEXTS = [(1247, 16), (4096, 32), (65, 4), (64, 4), (63, 4), (130, 5), (
 
 
 @pytest.mark.parametrize("n,d", KEYED_CONTEXTS)
-@pytest.mark.parametrize("wave", [1, 0])
+@pytest.mark.parametrize("wave", [1, 0, 2])
 def test_encrypt_keyed_matches_the_restated_definition(hip, oracle, knobs, n, d, wave):
     """csgn_encrypt_keyed (ChaCha keystream, wave kernel and one-lane-per-ciphertext kernel) word for
     word against oracle.encrypt_keyed, on windows of the stream that start and end inside a group
     of ciphertexts.  Small D makes the all-secret-positions-came-out-1 clear frequent."""
-    knobs.set("enc_wave", wave)
+    knobs.set("enc_wave", 1 if wave == 2 else wave)           # 0: one lane per ciphertext; 2: wave kernel with
+    knobs.set("enc_compact", 0 if wave == 2 else 1)            # the full LDS tables, 1: with the compact ones
     key = make_key(n, d, 16)
     dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
     units, passes, group = oracle.keyed_layout(n)

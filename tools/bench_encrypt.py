@@ -28,10 +28,14 @@ for n, d in [(1247, 16), (4096, 32), (2048, 16)]:
         row = []
         for rounds in (8, 12, 20):
             rng = hip.rng_from_seed(3, rounds)
-            for wave in ((1, 2, 8, 16, 64, 0) if batch >= 1 << 20 and rounds == 8 else (1,)):
-                capi.set_tuning("enc_wave", wave)
+            for wave in ((1, -1, 8, 32, 64, 0) if batch >= 1 << 20 and rounds == 8 else (1,)):
+                capi.reset_tuning()
+                if wave == -1:
+                    capi.set_tuning("enc_compact", 0)          # full LDS tables
+                else:
+                    capi.set_tuning("enc_wave", wave)
                 t = timed(lambda: hip.encrypt_keyed(n, d, plain, dkey, dmask, rng, out=out))
-                row.append(f"chacha{rounds}{'' if wave == 1 else '/ct-kernel' if wave == 0 else '/wg%d' % wave} {batch*dl*8/t/1e9:6.0f} GB/s ({batch/t/1e9:5.2f} Gct/s, {t*1e6:7.1f} us)")
+                row.append(f"chacha{rounds}{'' if wave == 1 else '/ct-kernel' if wave == 0 else '/full-tables' if wave == -1 else '/wg%d' % wave} {batch*dl*8/t/1e9:6.0f} GB/s ({batch/t/1e9:5.2f} Gct/s, {t*1e6:7.1f} us)")
         capi.reset_tuning()
         if batch == 1 << 20:
             rnd = hip.synth_fill(9, n, 0, batch * dl)
