@@ -78,6 +78,7 @@ SIGNATURES = {
     "csgn_circuit_create": (C.c_int, [u64, u64, C.POINTER(vp)]),
     "csgn_circuit_destroy": (None, [vp]),
     "csgn_circuit_input": (C.c_int, [vp, u64, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_input_ragged": (C.c_int, [vp, vp, C.POINTER(C.c_uint32)]),
     "csgn_circuit_add": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "csgn_circuit_mul": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "csgn_circuit_decrypt": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "csgn_circuit_build": (C.c_int, [vp]),
     "csgn_circuit_value": (vp, [vp, C.c_uint32]),
     "csgn_circuit_value_terms": (u64, [vp, C.c_uint32]),
+    "csgn_circuit_value_total_terms": (u64, [vp, C.c_uint32]),
+    "csgn_circuit_value_offsets": (vp, [vp, C.c_uint32]),
     "csgn_circuit_bits": (vp, [vp, C.c_uint32]),
     "csgn_circuit_run": (C.c_int, [vp, vp]),
     "csgn_mul_uniform_kernel": (C.c_char_p, [u64, u64, u64, u64]),

@@ -690,8 +690,14 @@ const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1
  * operations of a few microseconds each) is replayed with one hipGraphLaunch. */
 struct csgn_circuit {
     struct Value {
-        uint64_t terms;
+        uint64_t terms;       // uniform: terms per element; ragged: 0
         size_t offset;        // bytes into block
+        // ragged values (static shapes: the per-element term counts are fixed when the circuit is
+        // described, so every size downstream is known on the host and the graph needs no plan step)
+        std::vector<uint64_t> per;   // batch entries, empty for a uniform value
+        size_t csr_offset;           // bytes into block of the batch+1 CSR term offsets (0 = none yet)
+        uint64_t total;              // terms over the whole batch
+        uint64_t max_terms;
     };
     struct Op {
         int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator)
@@ -725,6 +731,31 @@ size_t circuit_reserve(csgn_circuit *c, size_t n)
     return at;
 }
 }
+
+extern "C++" {
+namespace {
+csgn_circuit::Value make_uniform(csgn_circuit *c, uint64_t terms, size_t offset)
+{
+    csgn_circuit::Value v;
+    v.terms = terms;
+    v.offset = offset;
+    v.csr_offset = 0;
+    v.total = c->batch * terms;
+    v.max_terms = terms;
+    return v;
+}
+uint64_t terms_of(const csgn_circuit::Value &v, uint64_t i) { return v.per.empty() ? v.terms : v.per[i]; }
+// CSR offsets of a value inside the block (created on first need, also for uniform values that meet
+// a ragged one)
+size_t ensure_csr(csgn_circuit *c, uint32_t id)
+{
+    csgn_circuit::Value &v = c->values[id];
+    if (!v.csr_offset)
+        v.csr_offset = circuit_reserve(c, (size_t)(c->batch + 1) * 8);
+    return v.csr_offset;
+}
+} // namespace
+} // extern "C++"
 
 int csgn_circuit_create(uint64_t n_bits, uint64_t batch, csgn_circuit **circuit)
 {
@@ -761,8 +792,33 @@ int csgn_circuit_input(csgn_circuit *c, uint64_t terms, uint32_t *value)
     if (!product_below(c->batch, terms, dl, 1ull << 57))
         return fail(CSGN_ERR_UNSUPPORTED, "input of %llu x %llu terms: size overflows",
                     (unsigned long long)c->batch, (unsigned long long)terms);
-    c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
+    c->values.push_back(make_uniform(c, terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))));
     *value = (uint32_t)(c->values.size() - 1);
+    return CSGN_OK;
+}
+
+int csgn_circuit_input_ragged(csgn_circuit *c, const uint64_t *h_terms, uint32_t *value)
+{
+    REQUIRE(c && value && h_terms && !c->exec, "null argument, or the circuit is already built");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    csgn_circuit::Value v;
+    v.terms = 0;
+    v.csr_offset = 0;
+    v.total = 0;
+    v.max_terms = 0;
+    v.per.assign(h_terms, h_terms + c->batch);
+    for (uint64_t i = 0; i < c->batch; ++i) {
+        REQUIRE(h_terms[i] < (1ull << 31), "element %llu has too many terms", (unsigned long long)i);
+        v.total += h_terms[i];
+        v.max_terms = h_terms[i] > v.max_terms ? h_terms[i] : v.max_terms;
+    }
+    if (!product_below(v.total ? v.total : 1, 1, dl, 1ull << 57))
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged input of %llu terms: size overflows", (unsigned long long)v.total);
+    v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
+    c->values.push_back(v);
+    const uint32_t id = (uint32_t)(c->values.size() - 1);
+    (void)ensure_csr(c, id);
+    *value = id;
     return CSGN_OK;
 }
 
@@ -771,6 +827,45 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
     REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
     REQUIRE(a < c->values.size() && b < c->values.size(), "operand value does not exist");
     const uint64_t dl = csgn_default_len(c->n_bits);
+    const bool ragged = !c->values[a].per.empty() || !c->values[b].per.empty();
+    if (ragged) {
+        // per-element shapes are static: every downstream size is computed here, on the host
+        csgn_circuit::Value v;
+        v.terms = 0;
+        v.csr_offset = 0;
+        v.total = 0;
+        v.max_terms = 0;
+        v.per.resize(c->batch);
+        for (uint64_t i = 0; i < c->batch; ++i) {
+            const uint64_t ta = terms_of(c->values[a], i), tb = terms_of(c->values[b], i);
+            if (kind && !product_below(ta, tb, dl, 1ull << 32))
+                return fail(CSGN_ERR_UNSUPPORTED, "element %llu: product of %llu x %llu terms exceeds 2^32 words",
+                            (unsigned long long)i, (unsigned long long)ta, (unsigned long long)tb);
+            const uint64_t t = kind ? ta * tb : ta + tb;
+            if (!kind && t * dl >= (1ull << 31))
+                return fail(CSGN_ERR_UNSUPPORTED, "element %llu: sum of %llu terms exceeds 2^31 words",
+                            (unsigned long long)i, (unsigned long long)t);
+            v.per[i] = t;
+            v.total += t;
+            v.max_terms = t > v.max_terms ? t : v.max_terms;
+        }
+        if (!product_below(v.total ? v.total : 1, 1, dl, 1ull << 57))
+            return fail(CSGN_ERR_UNSUPPORTED, "value of %llu terms: size overflows", (unsigned long long)v.total);
+        v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
+        c->values.push_back(v);
+        const uint32_t out = (uint32_t)(c->values.size() - 1);
+        (void)ensure_csr(c, a);
+        (void)ensure_csr(c, b);
+        (void)ensure_csr(c, out);
+        csgn_circuit::Op op = {};
+        op.kind = kind;
+        op.a = a;
+        op.b = b;
+        op.out = out;
+        c->ops.push_back(op);
+        *value = out;
+        return CSGN_OK;
+    }
     const uint64_t ta = c->values[a].terms, tb = c->values[b].terms;
     const uint64_t terms = kind ? ta * tb : ta + tb;
     if (kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || !product_below(ta, tb, dl, 1ull << 32)))
@@ -781,7 +876,7 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
     if (!product_below(c->batch, terms, dl, 1ull << 57))
         return fail(CSGN_ERR_UNSUPPORTED, "value of %llu x %llu terms: size overflows",
                     (unsigned long long)c->batch, (unsigned long long)terms);
-    c->values.push_back({terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))});
+    c->values.push_back(make_uniform(c, terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))));
     const uint32_t out = (uint32_t)(c->values.size() - 1);
     csgn_circuit::Op op = {};
     op.kind = kind;
@@ -800,7 +895,7 @@ int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, ui
 {
     REQUIRE(c && bits_id && d_mask && !c->exec, "null argument, or the circuit is already built");
     REQUIRE(a < c->values.size(), "operand value does not exist");
-    const size_t scratch = circuit_reserve(c, csgn::decrypt_scratch_bytes(c->batch, c->batch * c->values[a].terms));
+    const size_t scratch = circuit_reserve(c, csgn::decrypt_scratch_bytes(c->batch, c->values[a].total));
     const size_t bits = circuit_reserve(c, (size_t)c->batch);
     csgn_circuit::Op op = {};
     op.kind = 2;
@@ -820,7 +915,9 @@ int csgn_circuit_permute(csgn_circuit *c, uint32_t a, const uint32_t *d_perm, ui
     REQUIRE(a < c->values.size(), "operand value does not exist");
     // reference semantics (src/Ciphertext.cpp:7-82): the result is ONE term, the permuted first term
     const uint64_t dl = csgn_default_len(c->n_bits);
-    c->values.push_back({1, circuit_reserve(c, (size_t)(c->batch * dl * 8))});
+    if (!c->values[a].per.empty())
+        return fail(CSGN_ERR_UNSUPPORTED, "permutation of a ragged circuit value is not supported");
+    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
     const uint32_t out = (uint32_t)(c->values.size() - 1);
     csgn_circuit::Op op = {};
     op.kind = 3;
@@ -849,7 +946,7 @@ int csgn_circuit_encrypt(csgn_circuit *c, uint64_t d, const uint8_t *d_plain, co
         c->has_encrypt = true;
         c->epoch_offset = circuit_reserve(c, 8);
     }
-    c->values.push_back({1, circuit_reserve(c, (size_t)(c->batch * dl * 8))});
+    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
     const uint32_t out = (uint32_t)(c->values.size() - 1);
     csgn_circuit::Op op = {};
     op.kind = 4;
@@ -899,6 +996,20 @@ int csgn_circuit_build(csgn_circuit *c)
         }
         c->runs = 0;
     }
+    // CSR offsets of the ragged values (and of uniform values that meet one): known on the host
+    for (size_t i = 0; i < c->values.size(); ++i) {
+        const csgn_circuit::Value &v = c->values[i];
+        if (!v.csr_offset)
+            continue;
+        std::vector<uint64_t> off(c->batch + 1, 0);
+        for (uint64_t k = 0; k < c->batch; ++k)
+            off[k + 1] = off[k] + terms_of(v, k);
+        const hipError_t eu = hipMemcpy(base + v.csr_offset, off.data(), off.size() * 8, hipMemcpyHostToDevice);
+        if (eu != hipSuccess) {
+            (void)hipStreamDestroy(s);
+            return hip_fail(eu, "hipMemcpy (circuit CSR offsets)");
+        }
+    }
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess && c->has_encrypt)
         e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under nonce + its own run number
@@ -913,9 +1024,28 @@ int csgn_circuit_build(csgn_circuit *c)
         }
         const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);
         if (op.kind == 2) {
-            const uint64_t t = c->values[op.a].terms;
-            e = csgn::decrypt(c->n_bits, c->batch, t, c->batch * t, (const u64 *)A, nullptr, (const u64 *)op.mask,
-                              base + op.bits, base + op.scratch, s);
+            const csgn_circuit::Value &va = c->values[op.a];
+            if (!va.per.empty())
+                e = csgn::decrypt(c->n_bits, c->batch, 0, va.total, (const u64 *)A,
+                                  reinterpret_cast<const u64 *>(base + va.csr_offset), (const u64 *)op.mask,
+                                  base + op.bits, base + op.scratch, s);
+            else
+                e = csgn::decrypt(c->n_bits, c->batch, va.terms, c->batch * va.terms, (const u64 *)A, nullptr,
+                                  (const u64 *)op.mask, base + op.bits, base + op.scratch, s);
+        } else if (!c->values[op.out].per.empty()) {
+            // ragged add / multiply: the CSR forms, offsets already in the block
+            const csgn_circuit::Value &va = c->values[op.a], &vb = c->values[op.b], &vo = c->values[op.out];
+            const u64 *B = reinterpret_cast<const u64 *>(base + vb.offset);
+            u64 *O = reinterpret_cast<u64 *>(base + vo.offset);
+            const u64 *oa = reinterpret_cast<const u64 *>(base + va.csr_offset);
+            const u64 *ob = reinterpret_cast<const u64 *>(base + vb.csr_offset);
+            u64 *oo = reinterpret_cast<u64 *>(base + vo.csr_offset);
+            if (op.kind)
+                e = vo.total ? csgn::mul_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, va.max_terms,
+                                                vb.max_terms, vo.total, s)
+                             : hipSuccess;
+            else
+                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s);
         } else if (op.kind == 3) {
             uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
             e = csgn::permute(c->n_bits, c->batch, c->values[op.a].terms, false, (const u64 *)A,
@@ -956,6 +1086,18 @@ uint64_t *csgn_circuit_value(csgn_circuit *c, uint32_t value)
 uint64_t csgn_circuit_value_terms(csgn_circuit *c, uint32_t value)
 {
     return (c && value < c->values.size()) ? c->values[value].terms : 0;
+}
+
+uint64_t csgn_circuit_value_total_terms(csgn_circuit *c, uint32_t value)
+{
+    return (c && value < c->values.size()) ? c->values[value].total : 0;
+}
+
+const uint64_t *csgn_circuit_value_offsets(csgn_circuit *c, uint32_t value)
+{
+    if (!c || !c->block || value >= c->values.size() || c->values[value].per.empty())
+        return nullptr;
+    return reinterpret_cast<const uint64_t *>(static_cast<unsigned char *>(c->block) + c->values[value].csr_offset);
 }
 
 uint8_t *csgn_circuit_bits(csgn_circuit *c, uint32_t bits_id)

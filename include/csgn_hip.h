@@ -319,6 +319,13 @@ typedef struct csgn_circuit csgn_circuit;
 int csgn_circuit_create(uint64_t n_bits, uint64_t batch, csgn_circuit **circuit);
 void csgn_circuit_destroy(csgn_circuit *circuit);
 int csgn_circuit_input(csgn_circuit *circuit, uint64_t terms, uint32_t *value);
+/* A RAGGED input: element i has h_terms[i] terms (batch entries on the host; 0 allowed).  Shapes are
+ * static -- fixed when the circuit is described -- so every size downstream is known on the host, the
+ * CSR offsets of every ragged value are uploaded once at build time and the graph needs no plan step.
+ * add / mul with a ragged operand give a ragged result (the CSR kernels csgn_add_ragged /
+ * csgn_mul_ragged); decrypt works on either kind; permute of a ragged value is not supported.  The
+ * input's words go to csgn_circuit_value() in CSR order (element after element). */
+int csgn_circuit_input_ragged(csgn_circuit *circuit, const uint64_t *h_terms, uint32_t *value);
 int csgn_circuit_add(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *value);   /* a + b: concatenation */
 int csgn_circuit_mul(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *value);   /* a * b: all-pairs AND */
 /* Decrypt value `a` under the key whose dL-word mask is d_mask (must stay valid); *bits_id
@@ -342,7 +349,9 @@ int csgn_circuit_encrypt(csgn_circuit *circuit, uint64_t d, const uint8_t *d_pla
 uint64_t csgn_circuit_epoch(const csgn_circuit *circuit);      /* runs launched so far */
 int csgn_circuit_build(csgn_circuit *circuit);
 uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
-uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);
+uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);      /* per element; 0 for a ragged value */
+uint64_t csgn_circuit_value_total_terms(csgn_circuit *circuit, uint32_t value); /* over the whole batch */
+const uint64_t *csgn_circuit_value_offsets(csgn_circuit *circuit, uint32_t value);   /* device CSR offsets (batch+1) of a ragged value, NULL otherwise */
 uint8_t *csgn_circuit_bits(csgn_circuit *circuit, uint32_t bits_id);          /* device pointer */
 int csgn_circuit_run(csgn_circuit *circuit, void *stream);
 

@@ -1414,6 +1414,87 @@ def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, bat
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 40), (65, 4, 1000)])
+def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
+    """Ragged values in a captured circuit (static per-element shapes): x = (a*b + c) * (a + u) with
+    ragged a, b, c (0..5 terms per element, empty ones included) and a uniform u, two decrypts.  Words
+    against the one-by-one CSR calls and, per sampled element, the oracle; bits against the oracle."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import CsgnError, check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n + batch)
+    key = make_key(n, d, 5)
+    dmask = hip.upload(hip.key_mask(n, key))
+    ta, tb, tc = (rng.integers(0, 6, size=batch).astype(np.uint64) for _ in range(3))
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    va = new(lib.csgn_circuit_input_ragged, ta.ctypes.data)
+    vb = new(lib.csgn_circuit_input_ragged, tb.ctypes.data)
+    vc = new(lib.csgn_circuit_input_ragged, tc.ctypes.data)
+    vu = new(lib.csgn_circuit_input, 2)
+    vab = new(lib.csgn_circuit_mul, va, vb)
+    vs = new(lib.csgn_circuit_add, vab, vc)
+    vau = new(lib.csgn_circuit_add, va, vu)
+    vx = new(lib.csgn_circuit_mul, vs, vau)
+    b_s = new(lib.csgn_circuit_decrypt, vs, dmask.data_ptr())
+    b_x = new(lib.csgn_circuit_decrypt, vx, dmask.data_ptr())
+    with pytest.raises(CsgnError):
+        new(lib.csgn_circuit_permute, va, dmask.data_ptr())     # ragged permute: refused
+    check(lib.csgn_circuit_build(c))
+    assert lib.csgn_circuit_value_terms(c, vx) == 0 and lib.csgn_circuit_value_terms(c, vu) == 2
+    tx = (ta * tb + tc) * (ta + 2)
+    assert lib.csgn_circuit_value_total_terms(c, vx) == int(tx.sum())
+    # inputs: planted so that decryptions are not all zero
+    def fill(v, terms, seed):
+        total = int(terms.sum())
+        w = oracle.synth(seed, n, 0, max(total, 1) * dl)[:total * dl].reshape(total, dl)
+        hit = np.random.default_rng(seed).integers(0, 2, total).astype(bool)
+        w[hit] |= oracle.key_mask(n, key)
+        w = np.ascontiguousarray(w.reshape(-1))
+        if total:
+            check(lib.csgn_memcpy_h2d(lib.csgn_circuit_value(c, v), w.ctypes.data, w.size * 8, hip.stream))
+        return w
+    ha, hb, hc = fill(va, ta, 1), fill(vb, tb, 2), fill(vc, tc, 3)
+    hu = fill(vu, np.full(batch, 2, dtype=np.uint64), 4)
+    check(lib.csgn_circuit_run(c, hip.stream))
+    torch.cuda.synchronize()
+    def grab(v):
+        total = int(lib.csgn_circuit_value_total_terms(c, v))
+        t = hip.empty_words(max(total * dl, 1))
+        check(lib.csgn_memcpy_d2d(t.data_ptr(), lib.csgn_circuit_value(c, v), total * dl * 8, hip.stream))
+        return hip.download(t)[:total * dl]
+    gx, gs = grab(vx), grab(vs)
+    off = lambda t: np.concatenate([[0], np.cumsum(t)]).astype(np.int64)
+    oa, ob, oc, ox, os_ = off(ta), off(tb), off(tc), off(tx), off(ta * tb + tc)
+    got_off = torch.empty(batch + 1, dtype=torch.int64, device=hip.device)
+    check(lib.csgn_memcpy_d2d(got_off.data_ptr(), lib.csgn_circuit_value_offsets(c, vx), (batch + 1) * 8, hip.stream))
+    assert np.array_equal(hip.download(got_off).astype(np.int64), ox)
+    bits = {}
+    for name, bid in (("s", b_s), ("x", b_x)):
+        gb = torch.empty(batch, dtype=torch.uint8, device=hip.device)
+        check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+        bits[name] = hip.download(gb)
+    for i in range(0, batch, max(1, batch // 60)):
+        a_i, b_i, c_i = ha[oa[i] * dl:oa[i + 1] * dl], hb[ob[i] * dl:ob[i + 1] * dl], hc[oc[i] * dl:oc[i + 1] * dl]
+        u_i = hu[2 * i * dl:2 * (i + 1) * dl]
+        ab = oracle.mul(n, a_i, b_i)[0] if a_i.size and b_i.size else np.zeros(0, dtype=np.uint64)
+        s_i = np.concatenate([ab, c_i])
+        au = np.concatenate([a_i, u_i])
+        x_i = oracle.mul(n, s_i, au)[0] if s_i.size else np.zeros(0, dtype=np.uint64)
+        assert np.array_equal(gs[os_[i] * dl:os_[i + 1] * dl], s_i), i
+        assert np.array_equal(gx[ox[i] * dl:ox[i + 1] * dl], x_i), i
+        assert bits["s"][i] == (oracle.decrypt_canonical(n, key, s_i) if s_i.size else 0)
+        assert bits["x"][i] == (oracle.decrypt_canonical(n, key, x_i) if x_i.size else 0)
+    assert bits["x"].any() or bits["s"].any()
+    lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("batch", [1, 3, 200])
 def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     """BASELINE config 5 as ONE hipGraph: Context(4096,32), a random Permutation applied to every
