@@ -30,7 +30,7 @@ struct FastDiv {
     u32 shift;
 };
 
-inline FastDiv csgn_fastdiv_make(u32 d)
+__host__ __device__ inline FastDiv csgn_fastdiv_make(u32 d)
 {
     FastDiv f;
     f.d = d;
@@ -38,7 +38,11 @@ inline FastDiv csgn_fastdiv_make(u32 d)
     f.shift = 0;
     if (d <= 1)
         return f;                       // handled by the d==1 test in csgn_fastdiv
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 l = 31u - (u32)__clz((int)d);      // floor(log2 d)
+#else
     u32 l = 31u - (u32)__builtin_clz(d);   // floor(log2 d)
+#endif
     if ((d & (d - 1)) == 0) {           // power of two: t = 0, q = (n >> 1) >> (l-1)
         f.shift = l - 1;
         return f;

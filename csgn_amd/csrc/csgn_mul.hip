@@ -358,6 +358,84 @@ __global__ void __launch_bounds__(256) k_mul_ragged_tab(const Unit *__restrict__
             unit_store<Unit, true>(out + g_begin + (u32)m * 256u + threadIdx.x, lv[m] & rv[m]);
 }
 
+// ---------------------------------------------------------------------------------------
+// Ragged batches, record form (round 2).  The flat kernel above spends most of its ~100 VALU
+// instructions per unit on bookkeeping: four 8-byte loads from three offset arrays with 64-bit
+// address arithmetic each, and a 32-bit division by a per-pair divisor (q / t2, ~30 instructions).
+// At 4.8 TB/s that is 0.6 of the VALU issue rate: the kernel is as much issue-bound as
+// memory-bound.  Here one small kernel first writes a 32-byte RECORD per pair -- product offset,
+// operand offsets, t2 and the multiply-shift constants that divide by it -- and the product
+// kernel then needs, per unit, the walk to its pair (as before), ONE 32-byte load and a
+// six-instruction division.
+// MEASURED (profiles/r02/bench_ragged.log): no gain -- log-normal batch 5.17 vs 5.10 TB/s with cached
+// operands, 4.61 vs 4.72 cold -- and a loss on small outputs, where the record kernel and the
+// stream-ordered allocation are a fifth of the call (one 1024x1024 pair among 65 535 singles 2.1 vs
+// 2.6).  So the kernel is not issue-bound on its bookkeeping either; OFF by default (knob ragged_rec).
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(32))) PairRec {
+    u64 o0;          // first product term of the pair
+    u64 l0;          // first left term
+    u64 r0s;         // first right term | fastdiv shift << 56
+    u64 t2m;         // t2 | fastdiv magic << 32
+};
+
+__global__ void __launch_bounds__(256) k_ragged_records(const u64 *__restrict__ offL, const u64 *__restrict__ offR,
+                                                        const u64 *__restrict__ offOut, u32 batch,
+                                                        PairRec *__restrict__ rec)
+{
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= batch)
+        return;
+    const u64 r0 = offR[p];
+    const u32 t2 = (u32)(offR[p + 1] - r0);
+    const FastDiv f = csgn_fastdiv_make(t2 ? t2 : 1u);
+    PairRec x;
+    x.o0 = offOut[p];
+    x.l0 = offL[p];
+    x.r0s = r0 | ((u64)f.shift << 56);
+    x.t2m = (u64)(t2 ? t2 : 1u) | ((u64)f.magic << 32);
+    rec[p] = x;
+}
+
+template <typename Unit, int C>
+__global__ void __launch_bounds__(256) k_mul_ragged_rec(const Unit *__restrict__ L, const Unit *__restrict__ R,
+                                                        Unit *__restrict__ out, const u64 *__restrict__ offOut,
+                                                        const PairRec *__restrict__ rec, u32 batch, u64 unit_base,
+                                                        u64 total_units, u32 U, FastDiv dU)
+{
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 g_begin = unit_base + (u64)bid * (256u * C);
+    if (g_begin >= total_units)
+        return;
+    const u64 term0 = g_begin / U;                              // workgroup-uniform
+    const u32 r0blk = (u32)(g_begin - term0 * U);
+    u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+        if (g_begin + (u32)c * 256u >= total_units)
+            break;
+        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
+        const u32 dt = csgn_fastdiv(r, dU);
+        const u64 term = term0 + dt;
+        const u32 k = r - dt * U;
+        u32 p = pw;
+        if (g < total_units) {
+            p = csr_gallop(offOut, pw, batch, term);            // runs of empty pairs are walked over
+            const PairRec x = rec[p];                           // one 32-byte load
+            FastDiv f;
+            f.d = (u32)x.t2m;
+            f.magic = (u32)(x.t2m >> 32);
+            f.shift = (u32)(x.r0s >> 56);
+            const u32 q = (u32)(term - x.o0);                   // product term index inside the pair
+            const u32 i = csgn_fastdiv(q, f), j = q - i * f.d;
+            const u64 r0 = x.r0s & 0x00FFFFFFFFFFFFFFull;
+            unit_store<Unit, true>(out + g, L[(x.l0 + i) * U + k] & R[(r0 + j) * U + k]);
+        }
+        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);       // later chunks start from here
+    }
+}
+
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
 // launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
 // and the fix-up -- 1M pairs plan in tens of microseconds.
@@ -885,12 +963,30 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const int chunks = ragged_chunks(total_units);
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
+    // Record form (opt-in, see k_mul_ragged_rec; knob ragged_rec: 1 = for outputs of 8 MB and more,
+    // -1 = always, 0 = never): 32 bytes per pair in a stream-ordered allocation, written by one small
+    // kernel per call
+    const int rec_knob = csgn::tune(TUNE_RAGGED_REC);
+    PairRec *rec = nullptr;
+    if (rec_knob != 0 && (rec_knob < 0 || total_units * (wide ? 16u : 8u) >= (8ull << 20))) {
+        if (hipMallocAsync((void **)&rec, batch * sizeof(PairRec), s) == hipSuccess) {
+            k_ragged_records<<<ceil_div_u64(batch, 256u), 256, 0, s>>>(offL, offR, offOut, (u32)batch, rec);
+            if (hipGetLastError() != hipSuccess) {
+                (void)hipFreeAsync(rec, s);
+                rec = nullptr;
+            }
+        } else {
+            (void)hipGetLastError();       // no stream-ordered allocator: the searching kernel needs none
+            rec = nullptr;
+        }
+    }
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
     // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
-    // an HBM miss under full write load, as in the uniform path.  CSGN_RAGGED_TOUCH=0 turns it off.
+    // an HBM miss under full write load, as in the uniform path.  Knob ragged_touch = 0 turns it off.
     const bool touch = wide && total_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
     const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
-    for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
+    hipError_t result = hipSuccess;
+    for (u64 u0 = 0; u0 < total_units && result == hipSuccess; u0 += per_launch) {
         const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
         const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
         if (touch)
@@ -899,7 +995,14 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                                                u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
-        if (wide)                                                                                   \
+        if (rec && wide)                                                                            \
+            k_mul_ragged_rec<unit16, CH><<<blocks, 256, 0, s>>>(                                    \
+                reinterpret_cast<const unit16 *>(L), reinterpret_cast<const unit16 *>(R),           \
+                reinterpret_cast<unit16 *>(out), offOut, rec, (u32)batch, u0, u0 + nu, U, dU);      \
+        else if (rec)                                                                               \
+            k_mul_ragged_rec<unit8, CH><<<blocks, 256, 0, s>>>(L, R, out, offOut, rec, (u32)batch,  \
+                                                               u0, u0 + nu, U, dU);                 \
+        else if (wide)                                                                              \
             k_mul_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
                 reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
@@ -916,11 +1019,14 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         default: CSGN_RAGGED_LAUNCH(8); break;
         }
 #undef CSGN_RAGGED_LAUNCH
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess)
-            return le;
+        result = hipGetLastError();
     }
-    return hipSuccess;
+    if (rec) {
+        const hipError_t fe = hipFreeAsync(rec, s);
+        if (result == hipSuccess)
+            result = fe;
+    }
+    return result;
 }
 
 } // namespace csgn

@@ -1574,16 +1574,24 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     knobs.set("CSGN_RAGGED_FLAT", "1")
     knobs.set("CSGN_RAGGED_TOUCH", "0")
     knobs.set("ragged_table", 0)                                # the searching kernel, unsliced
+    knobs.set("ragged_rec", 0)
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
     ref = ref.clone()
     knobs.set("CSGN_RAGGED_TOUCH", "1")                         # ... sliced with the touch pass
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
-    for tab, touch in ((1, 1), (1, 0), (8, 1)):                 # the indexed kernel (default for this size)
+    knobs.set("ragged_rec", 0)
+    for tab, touch in ((1, 1), (1, 0), (8, 1)):                 # the indexed kernel (opt-in)
         knobs.set("ragged_table", tab)
         knobs.set("CSGN_RAGGED_TOUCH", touch)
         out, off = hip.mul_ragged(n, L, dOL, R, dOR)
         assert torch.equal(out, ref) and torch.equal(off, ref_off), (tab, touch)
+    knobs.set("ragged_table", 0)
+    for rec, touch in ((1, 1), (1, 0)):                         # the record kernel (default for this size)
+        knobs.set("ragged_rec", rec)
+        knobs.set("CSGN_RAGGED_TOUCH", touch)
+        out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+        assert torch.equal(out, ref) and torch.equal(off, ref_off), ("rec", touch)
     mo = hip.download(off)
     assert np.array_equal(mo, csr((t1s * t2s).tolist()))
     cut_term = (1 << 26) // 10                                  # first term of the second slice
@@ -1627,8 +1635,11 @@ def test_ragged_forms_fuzz(hip, oracle, knobs):
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-4"},          # indexed form, whatever the size
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-2"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-8"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "0"}):
-            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE"):
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "0"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1"},            # record form, whatever the size
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1", "CSGN_RAGGED_C": "1"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "0"}):
+            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE", "CSGN_RAGGED_REC"):
                 knobs.unset(k)
             for k, v in env.items():
                 knobs.set(k, v)

@@ -7,8 +7,9 @@ from csgn_amd.batch import HipPath, check
 from csgn_amd import capi
 CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
-VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no slice touch',{'CSGN_RAGGED_TOUCH':'0'}),('cold M=2',{'CSGN_RAGGED_TABLE':'2'}),('cold M=8',{'CSGN_RAGGED_TABLE':'8'}),('cold M=8 no touch',{'CSGN_RAGGED_TABLE':'8','CSGN_RAGGED_TOUCH':'0'}),
-          ('r1 kernel: same',{'NSETS':'1','CSGN_RAGGED_TABLE':'0'}),('r1 kernel: cold',{'CSGN_RAGGED_TABLE':'0'}),('r1 kernel: cold, no touch',{'CSGN_RAGGED_TABLE':'0','CSGN_RAGGED_TOUCH':'0'})]
+VARIANTS=[('rec: same',{'NSETS':'1'}),('rec: cold',{}),('rec: cold, no touch',{'CSGN_RAGGED_TOUCH':'0'}),('rec C=4: cold',{'CSGN_RAGGED_C':'4'}),('rec C=16: cold',{'CSGN_RAGGED_C':'16'}),
+          ('r1 kernel: same',{'NSETS':'1','CSGN_RAGGED_REC':'0'}),('r1 kernel: cold',{'CSGN_RAGGED_REC':'0'}),('r1 kernel: cold, no touch',{'CSGN_RAGGED_REC':'0','CSGN_RAGGED_TOUCH':'0'}),
+          ('indexed M=8: cold',{'CSGN_RAGGED_REC':'0','CSGN_RAGGED_TABLE':'8'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
