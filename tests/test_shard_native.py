@@ -104,8 +104,15 @@ def test_tool_shards_a_fresh_batch_and_gathers_counts_over_rccl(tool, oracle):
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["n_gpus"] >= 1 and r["pairs"] == pairs and r["gathered_counts_wrong"] == 0
     assert r["gathered_counts_sum"] == pairs and r["shards"][0][0] == 0 and r["shards"][-1][1] == pairs
-    a = oracle.synth(0x43534743 + 1, n, 0, pairs * dl)
-    b = oracle.synth(0x43534743 + 2, n, 0, pairs * dl)
+    assert r["fresh_ciphertexts"] is True and r["decrypted_bits_wrong"] == 0
+    # the same fresh ciphertexts from the restated definition: key, bits, generator streams as in the tool
+    key = np.array([(i * (n // 16) + 3) % n for i in range(16)], dtype=np.uint64)
+    g = np.arange(pairs, dtype=np.uint64)
+    pa = ((g * np.uint64(2654435761)) >> np.uint64(13)) & np.uint64(1)
+    pb = ((g * np.uint64(40503) + np.uint64(7)) >> np.uint64(5)) & np.uint64(1)
+    (ka, na), (kb, nb) = oracle.rng_from_seed(1234), oracle.rng_from_seed(1235)
+    a = oracle.encrypt_keyed(n, key, pa.astype(np.uint8), ka, na, 8)
+    b = oracle.encrypt_keyed(n, key, pb.astype(np.uint8), kb, nb, 8)
     assert int(r["products_digest"], 16) == oracle.digest(a & b)
 
 

@@ -5,6 +5,11 @@
 // per-pair result term counts (csgn_comm_gather_counts -> ncclAllGather over xGMI).  No torch, no
 // Python, no MPI.  Operand words are a function of the GLOBAL pair index, so the digests printed
 // at the end are the same for any GPU count.
+// With --terms 1 (the default) the operands are FRESH ciphertexts, as in config 4: every step
+// encrypts both operands of the shard on its GPU with the keyed generator (csgn_encrypt_keyed,
+// first_ciphertext = the shard's first global pair index), multiplies, decrypts, and gathers the term
+// counts AND the decrypted bits; every gathered bit is checked against b1 & b0 computed in the clear.
+// With --terms T > 1 the operands are synthetic T-term ciphertexts (csgn_synth_fill).
 //
 //   hipcc -O2 -std=c++17 -Iinclude tools/shard_mul.cpp -Lcsgn_amd/lib -lcsgn_hip -lcsgn_shard \
 //         -Wl,-rpath,$PWD/csgn_amd/lib -lpthread -o tools/bin/shard_mul     (or: make tools)
@@ -36,8 +41,13 @@ struct RankResult {
     uint64_t out_digest = 0;      // digest of the products still in this rank's arena
     uint64_t counts_sum = 0;      // sum of ALL gathered counts (every rank must see the same)
     uint64_t counts_bad = 0;      // gathered counts that are not t1*t2
+    uint64_t bits_bad = 0;        // gathered decryptions that are not b1 & b0 (fresh mode)
     uint64_t lo = 0, hi = 0;
 };
+
+// plaintext bits of global pair g (any fixed functions of g will do)
+inline unsigned char bit_a(uint64_t g) { return (unsigned char)(((g * 2654435761ull) >> 13) & 1u); }
+inline unsigned char bit_b(uint64_t g) { return (unsigned char)(((g * 40503ull + 7u) >> 5) & 1u); }
 
 #define TRY(x)                                                                              \
     do {                                                                                    \
@@ -70,16 +80,65 @@ void rank_main(const Args &a, csgn_comm *comm, RankResult &res, std::atomic<bool
     TRY(csgn_malloc(&counts, (mine ? mine : 1) * 8));
     TRY(csgn_malloc(&all, a.pairs * 8));
     TRY(csgn_malloc(&dig, 8));
-    // operands = f(global pair index): word w of the global operand stream
-    TRY(csgn_synth_fill(0x43534743 + 1, n, lo * T * dl, opw, (uint64_t *)L, stream));
-    TRY(csgn_synth_fill(0x43534743 + 2, n, lo * T * dl, opw, (uint64_t *)R, stream));
+    const bool fresh = (T == 1);
+    // fresh mode: key, plaintext bits of the shard, decrypt scratch, gathered bits
+    const uint64_t D = 16;
+    void *d_key = nullptr, *d_mask = nullptr, *d_pa = nullptr, *d_pb = nullptr, *d_bits = nullptr, *d_allbits = nullptr,
+         *d_scratch = nullptr;
+    csgn_rng rng_a, rng_b;
+    if (fresh) {
+        std::vector<uint64_t> key(D), mask(dl);
+        for (uint64_t i = 0; i < D; ++i)
+            key[i] = (i * (n / D) + 3) % n;                   // D distinct positions
+        TRY(csgn_key_mask(n, key.data(), D, mask.data()));
+        std::vector<unsigned char> pa(mine ? mine : 1), pb(mine ? mine : 1);
+        for (uint64_t i = 0; i < mine; ++i) {
+            pa[i] = bit_a(lo + i);
+            pb[i] = bit_b(lo + i);
+        }
+        TRY(csgn_malloc(&d_key, D * 8));
+        TRY(csgn_malloc(&d_mask, dl * 8));
+        TRY(csgn_malloc(&d_pa, pa.size()));
+        TRY(csgn_malloc(&d_pb, pb.size()));
+        TRY(csgn_malloc(&d_bits, mine ? mine : 1));
+        TRY(csgn_malloc(&d_allbits, a.pairs));
+        TRY(csgn_malloc(&d_scratch, csgn_decrypt_scratch_bytes(mine, mine)));
+        TRY(csgn_memcpy_h2d(d_key, key.data(), D * 8, stream));
+        TRY(csgn_memcpy_h2d(d_mask, mask.data(), dl * 8, stream));
+        TRY(csgn_memcpy_h2d(d_pa, pa.data(), pa.size(), stream));
+        TRY(csgn_memcpy_h2d(d_pb, pb.data(), pb.size(), stream));
+        TRY(csgn_stream_sync(stream));
+        TRY(csgn_rng_from_seed(&rng_a, 1234, 8));             // reproducible streams: the digest is checkable
+        TRY(csgn_rng_from_seed(&rng_b, 1235, 8));
+    } else {
+        // operands = f(global pair index): word w of the global operand stream
+        TRY(csgn_synth_fill(0x43534743 + 1, n, lo * T * dl, opw, (uint64_t *)L, stream));
+        TRY(csgn_synth_fill(0x43534743 + 2, n, lo * T * dl, opw, (uint64_t *)R, stream));
+    }
 
     auto step = [&]() -> int {
+        if (fresh) {
+            // ciphertext i of the shard draws stream position lo + i: the same words for any GPU count
+            if (int rc = csgn_encrypt_keyed(n, D, mine, lo, (const uint8_t *)d_pa, (const uint64_t *)d_key,
+                                            (const uint64_t *)d_mask, &rng_a, (uint64_t *)L, stream))
+                return rc;
+            if (int rc = csgn_encrypt_keyed(n, D, mine, lo, (const uint8_t *)d_pb, (const uint64_t *)d_key,
+                                            (const uint64_t *)d_mask, &rng_b, (uint64_t *)R, stream))
+                return rc;
+        }
         if (int rc = csgn_mul_uniform(n, mine, T, T, (const uint64_t *)L, (const uint64_t *)R, (uint64_t *)arena, slots, stream))
             return rc;
         if (int rc = csgn_shard_product_counts(mine, nullptr, nullptr, T, T, (uint64_t *)counts, stream))
             return rc;
-        return csgn_comm_gather_counts(comm, (const uint64_t *)counts, a.pairs, (uint64_t *)all, stream);
+        if (int rc = csgn_comm_gather_counts(comm, (const uint64_t *)counts, a.pairs, (uint64_t *)all, stream))
+            return rc;
+        if (fresh && slots == mine) {
+            if (int rc = csgn_decrypt_uniform(n, mine, 1, (const uint64_t *)arena, (const uint64_t *)d_mask,
+                                              (uint8_t *)d_bits, d_scratch, stream))
+                return rc;
+            return csgn_comm_gather_bytes(comm, (const uint8_t *)d_bits, a.pairs, (uint8_t *)d_allbits, stream);
+        }
+        return CSGN_OK;
     };
     for (int w = 0; w < a.warmup; ++w)
         TRY(step());
@@ -97,6 +156,12 @@ void rank_main(const Args &a, csgn_comm *comm, RankResult &res, std::atomic<bool
         res.counts_sum += c;
         res.counts_bad += (c != T * T);
     }
+    if (fresh && slots == mine) {                    // every rank holds every pair's decrypted bit
+        std::vector<unsigned char> h_bits(a.pairs);
+        TRY(csgn_memcpy_d2h(h_bits.data(), d_allbits, a.pairs, stream));
+        for (uint64_t g = 0; g < a.pairs; ++g)
+            res.bits_bad += (h_bits[g] != (unsigned char)(bit_a(g) & bit_b(g)));
+    }
     // digest of the products this rank still holds (the last `slots` pairs of its shard), indexed by
     // their GLOBAL word position so that the sum over ranks does not depend on the GPU count when
     // slots == 0
@@ -113,6 +178,13 @@ void rank_main(const Args &a, csgn_comm *comm, RankResult &res, std::atomic<bool
     csgn_free(counts);
     csgn_free(all);
     csgn_free(dig);
+    csgn_free(d_key);
+    csgn_free(d_mask);
+    csgn_free(d_pa);
+    csgn_free(d_pb);
+    csgn_free(d_bits);
+    csgn_free(d_allbits);
+    csgn_free(d_scratch);
 }
 
 } // namespace
@@ -156,7 +228,7 @@ int main(int argc, char **argv)
         t.join();
     int rc = 0;
     double tmax = 0;
-    uint64_t digest = 0, bad = 0;
+    uint64_t digest = 0, bad = 0, bits_bad = 0;
     for (int r = 0; r < world; ++r) {
         if (res[r].rc) {
             fprintf(stderr, "rank %d failed [%d]: %s\n", r, res[r].rc, res[r].error.c_str());
@@ -165,6 +237,7 @@ int main(int argc, char **argv)
         tmax = res[r].seconds > tmax ? res[r].seconds : tmax;
         digest += res[r].out_digest;
         bad += res[r].counts_bad;
+        bits_bad += res[r].bits_bad;
         if (res[r].counts_sum != res[0].counts_sum)
             rc = 1;                                   // every rank must have received the same vector
     }
@@ -177,12 +250,13 @@ int main(int argc, char **argv)
     const double mults = (double)a.pairs * a.steps / tmax;
     printf("{\"tool\": \"shard_mul\", \"n_gpus\": %d, \"pairs\": %llu, \"terms\": %llu, \"n_bits\": %llu, \"steps\": %d, "
            "\"seconds\": %.6f, \"mult_per_s\": %.1f, \"algorithmic_GBps\": %.1f, \"collective\": \"ncclAllGather(term counts, %llu x u64)\", "
-           "\"gathered_counts_sum\": %llu, \"gathered_counts_wrong\": %llu, \"products_digest\": \"%016llx\", \"shards\": [",
+           "\"gathered_counts_sum\": %llu, \"gathered_counts_wrong\": %llu, \"fresh_ciphertexts\": %s, "
+           "\"decrypted_bits_wrong\": %llu, \"products_digest\": \"%016llx\", \"shards\": [",
            world, (unsigned long long)a.pairs, (unsigned long long)T, (unsigned long long)a.nbits, a.steps, tmax, mults,
            mults * bytes / 1e9, (unsigned long long)a.pairs, (unsigned long long)res[0].counts_sum,
-           (unsigned long long)bad, (unsigned long long)digest);
+           (unsigned long long)bad, T == 1 ? "true" : "false", (unsigned long long)bits_bad, (unsigned long long)digest);
     for (int r = 0; r < world; ++r)
         printf("%s[%llu, %llu]", r ? ", " : "", (unsigned long long)res[r].lo, (unsigned long long)res[r].hi);
     printf("]}\n");
-    return (bad == 0 && res[0].counts_sum == a.pairs * T * T) ? 0 : 1;
+    return (bad == 0 && bits_bad == 0 && res[0].counts_sum == a.pairs * T * T) ? 0 : 1;
 }
