@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
 // A workgroup owns C consecutive 4 KiB chunks of the flattened output: one uniform search for its
 // first term, then every wave walks forward from the pair it was in (csr_gallop), so the
 // log2(batch) dependent loads are paid once per C chunks instead of twice per chunk.
-template <typename Unit, int C>
+template <typename Unit, int C, int M>
 __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R,
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU,
                                                          u32 pf_pairs)
 {
+    static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const u64 g_begin = unit_base + (u64)bid * (256u * C);
     if (g_begin >= total_units)
@@ -235,26 +236,62 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             asm volatile("" ::"v"(v));
         }
     }
+    // The kernel is bound by its chain of dependent loads (PMC, profiles/r02/ragged_pmc_summary.json:
+    // walk -> offsets -> operands -> store, three round trips per KiB of output against one in the
+    // uniform kernel).  Two remedies:
+    //   * bet on the pair the wave was in: its offsets are wave-uniform addresses (scalar loads, one
+    //     round trip together with the end-of-pair test); only lanes whose term lies beyond that pair
+    //     walk on and fetch again;
+    //   * M chunks per turn share that one bet, and their 2M operand loads travel together: M KiB of
+    //     output per wave and round trip.
 #pragma unroll 1
-    for (int c = 0; c < C; ++c) {
-        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
-        if (g_begin + (u32)c * 256u >= total_units)
+    for (int c0 = 0; c0 < C; c0 += M) {
+        if (g_begin + (u32)c0 * 256u >= total_units)
             break;
-        // this lane's term: a 32-bit division of its distance from the workgroup's first term
-        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
-        const u32 dt = csgn_fastdiv(r, dU);
-        const u64 term = term0 + dt;
-        const u32 k = r - dt * U;
-        u32 p = pw;
-        if (g < total_units) {
-            p = csr_gallop(offOut, pw, batch, term);            // runs of empty pairs are walked over
-            const u64 l0 = offL[p], rr0 = offR[p];
-            const u32 t2 = (u32)(offR[p + 1] - rr0);
-            const u32 q = (u32)(term - offOut[p]);              // product term index inside the pair
-            const u32 i = q / t2, j = q - i * t2;
-            unit_store<Unit, true>(out + g, L[(l0 + i) * U + k] & R[(rr0 + j) * U + k]);
+        const u64 s_o0 = offOut[pw], s_o1 = offOut[pw + 1];
+        const u64 s_l0 = offL[pw], s_r0 = offR[pw], s_r1 = offR[pw + 1];
+        u32 p[M];
+        u64 la[M], ra[M];                                       // operand unit indices
+        bool live[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int c = c0 + m;
+            const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+            live[m] = g < total_units;
+            // this lane's term: a 32-bit division of its distance from the workgroup's first term
+            const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
+            const u32 dt = csgn_fastdiv(r, dU);
+            const u64 term = term0 + dt;
+            const u32 k = r - dt * U;
+            p[m] = pw;
+            la[m] = ra[m] = 0;
+            if (live[m]) {
+                u64 o0 = s_o0, l0 = s_l0, rr0 = s_r0;
+                u32 t2 = (u32)(s_r1 - s_r0);
+                if (term >= s_o1) {                             // past the end of pair pw
+                    p[m] = csr_gallop(offOut, pw, batch, term); // runs of empty pairs are walked over
+                    o0 = offOut[p[m]];
+                    l0 = offL[p[m]];
+                    rr0 = offR[p[m]];
+                    t2 = (u32)(offR[p[m] + 1] - rr0);
+                }
+                const u32 q = (u32)(term - o0);                 // product term index inside the pair
+                const u32 i = q / t2, j = q - i * t2;
+                la[m] = (l0 + i) * U + k;
+                ra[m] = (rr0 + j) * U + k;
+            }
         }
-        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);       // later chunks start from here
+        Unit lv[M], rv[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {                           // unconditional (index 0 for dead lanes): in flight together
+            lv[m] = L[la[m]];
+            rv[m] = R[ra[m]];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            if (live[m])
+                unit_store<Unit, true>(out + g_begin + (u32)(c0 + m) * 256u + threadIdx.x, lv[m] & rv[m]);
+        pw = (u32)__builtin_amdgcn_readfirstlane((int)p[M - 1]);   // the next turn starts from the last chunk's pair
     }
 }
 
@@ -961,8 +998,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         }
         (void)hipGetLastError();        // no stream-ordered allocator: the searching kernel below needs none
     }
-    const int chunks = ragged_chunks(total_units);
+    // 4 KiB chunks per workgroup: at most 4 here since the per-chunk lookup became one scalar round trip
+    // (measured cold, log-normal batch: C=4 5.65 TB/s, C=8 5.24, C=16 4.94, C=2 4.18, C=1 2.48)
+    const int chunks = csgn::tune(TUNE_RAGGED_C) ? ragged_chunks(total_units) : std::min(4, ragged_chunks(total_units));
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
+    const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
     // Record form (opt-in, see k_mul_ragged_rec; knob ragged_rec: 1 = for outputs of 8 MB and more,
     // -1 = always, 0 = never): 32 bytes per pair in a stream-ordered allocation, written by one small
     // kernel per call
@@ -993,6 +1033,17 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
                                                reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
                                                u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
+#define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
+    do {                                                                                            \
+        if (wide)                                                                                   \
+            k_mul_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                               \
+                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
+        else                                                                                        \
+            k_mul_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
+                                                                    (u32)batch, u0, u0 + nu, U, dU, \
+                                                                    pf_pairs);                      \
+    } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
         if (rec && wide)                                                                            \
@@ -1002,14 +1053,12 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         else if (rec)                                                                               \
             k_mul_ragged_rec<unit8, CH><<<blocks, 256, 0, s>>>(L, R, out, offOut, rec, (u32)batch,  \
                                                                u0, u0 + nu, U, dU);                 \
-        else if (wide)                                                                              \
-            k_mul_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
-                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
+        else if (turn >= 4 && (CH) % 4 == 0)                                                        \
+            CSGN_RAGGED_FLAT(CH, ((CH) % 4 == 0 ? 4 : 1));                                          \
+        else if (turn >= 2 && (CH) % 2 == 0)                                                        \
+            CSGN_RAGGED_FLAT(CH, ((CH) % 2 == 0 ? 2 : 1));                                          \
         else                                                                                        \
-            k_mul_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
-                                                                (u32)batch, u0, u0 + nu, U, dU,     \
-                                                                pf_pairs);                          \
+            CSGN_RAGGED_FLAT(CH, 1);                                                                \
     } while (0)
         switch (chunks) {
         case 1: CSGN_RAGGED_LAUNCH(1); break;
@@ -1018,6 +1067,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         case 16: CSGN_RAGGED_LAUNCH(16); break;
         default: CSGN_RAGGED_LAUNCH(8); break;
         }
+#undef CSGN_RAGGED_FLAT
 #undef CSGN_RAGGED_LAUNCH
         result = hipGetLastError();
     }

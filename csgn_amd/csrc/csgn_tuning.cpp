@@ -21,7 +21,7 @@ const Knob kKnobs[TUNE_COUNT] = {
     {"mul_m", 0},        {"mul_ti", 4},        {"mul_nt", 1},        {"mul_flat", 0},
     {"mul_bs", 0},       {"mul_xcd", 1},       {"mul_touch", -1},    {"mul_pf_kb", -1},
     {"stream_xcd", -1},  {"ragged_c", 0},      {"ragged_flat", 0},   {"ragged_pf", 32},
-    {"ragged_touch", 1}, {"ragged_table", 0},  {"ragged_rec", 0},    {"perm_ballot", 0},   {"perm_narrow", 0},
+    {"ragged_touch", 1}, {"ragged_table", 0},  {"ragged_m", 4},      {"ragged_rec", 0},    {"perm_ballot", 0},   {"perm_narrow", 0},
     {"perm_waves", 0},   {"perm_v1", 0},       {"perm_persist", 1},  {"dec_loop", 0},
     {"enc_lds", 0},      {"enc_wave", 1},      {"enc_compact", -1},
 };

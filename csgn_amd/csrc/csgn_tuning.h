@@ -24,6 +24,7 @@ enum TuneKey {
     TUNE_RAGGED_PF,      // ragged multiply: operand prefetch distance in pairs, 0 = off
     TUNE_RAGGED_TOUCH,   // ragged multiply: 1 = touch pass per 1 GiB output slice
     TUNE_RAGGED_TABLE,   // ragged multiply, indexed form (pair-of-every-32nd-term table; measured SLOWER than the searching kernel, kept as an experiment): 0 = off (default), 1 = on for outputs >= 32 MB, 2/4/8 = units per lane, negative = no size threshold
+    TUNE_RAGGED_M,       // flat ragged multiply: 4 KiB chunks per turn that share one speculative pair lookup and whose operand loads travel together: 1, 2 or 4
     TUNE_RAGGED_REC,     // ragged multiply, record form (32-byte record per pair: offsets + division constants; measured no faster than the searching kernel, kept as an experiment): 0 = never (default), 1 = outputs >= 8 MB, -1 = always
     TUNE_PERM_BALLOT,    // 1 = ballot bit-gather permutation kernel instead of the bit-plane kernel
     TUNE_PERM_NARROW,    // 1 = 8-byte staging accesses in the bit-plane kernel

@@ -1638,8 +1638,11 @@ def test_ragged_forms_fuzz(hip, oracle, knobs):
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "0"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1"},            # record form, whatever the size
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1", "CSGN_RAGGED_C": "1"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "0"}):
-            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE", "CSGN_RAGGED_REC"):
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "0"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "1", "CSGN_RAGGED_C": "8"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "2", "CSGN_RAGGED_C": "2"},
+                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "4", "CSGN_RAGGED_C": "16"}):
+            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE", "CSGN_RAGGED_REC", "CSGN_RAGGED_M"):
                 knobs.unset(k)
             for k, v in env.items():
                 knobs.set(k, v)

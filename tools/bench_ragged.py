@@ -7,9 +7,10 @@ from csgn_amd.batch import HipPath, check
 from csgn_amd import capi
 CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
-VARIANTS=[('rec: same',{'NSETS':'1'}),('rec: cold',{}),('rec: cold, no touch',{'CSGN_RAGGED_TOUCH':'0'}),('rec C=4: cold',{'CSGN_RAGGED_C':'4'}),('rec C=16: cold',{'CSGN_RAGGED_C':'16'}),
-          ('r1 kernel: same',{'NSETS':'1','CSGN_RAGGED_REC':'0'}),('r1 kernel: cold',{'CSGN_RAGGED_REC':'0'}),('r1 kernel: cold, no touch',{'CSGN_RAGGED_REC':'0','CSGN_RAGGED_TOUCH':'0'}),
-          ('indexed M=8: cold',{'CSGN_RAGGED_REC':'0','CSGN_RAGGED_TABLE':'8'})]
+VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_RAGGED_TOUCH':'0'}),
+          ('cold C=1',{'CSGN_RAGGED_C':'1'}),('cold C=2',{'CSGN_RAGGED_C':'2'}),('cold C=4',{'CSGN_RAGGED_C':'4'}),('cold C=4 M=2',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'2'}),('cold C=4 M=1',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'1'}),
+          ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
+          ('record form: cold',{'CSGN_RAGGED_REC':'1'}),('indexed M=8: cold',{'CSGN_RAGGED_TABLE':'8'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
