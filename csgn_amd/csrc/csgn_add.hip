@@ -33,10 +33,17 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
         const u32 k = r - dt * U;
         u32 p = pw;
         if (g < total_units) {
-            p = csr_gallop(offOut, pw, batch, term);
-            const u64 l0 = offL[p], rr0 = offR[p];
-            const u64 t1 = offL[p + 1] - l0;
-            const u64 q = term - offOut[p];                     // offOut[p] = l0 + rr0
+            // bet on the pair the wave was in (as k_mul_ragged_flat): its offsets are wave-uniform scalar
+            // loads that arrive in one round trip with the end-of-pair test; lanes beyond it walk on
+            const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_r0 = offR[pw], s_r1 = offR[pw + 1];
+            u64 l0 = s_l0, rr0 = s_r0, t1 = s_l1 - s_l0;
+            if (term >= s_l1 + s_r1) {                          // offOut[pw + 1] = offL[pw + 1] + offR[pw + 1]
+                p = csr_gallop(offOut, pw, batch, term);
+                l0 = offL[p];
+                rr0 = offR[p];
+                t1 = offL[p + 1] - l0;
+            }
+            const u64 q = term - (l0 + rr0);                    // offOut[p] = l0 + rr0
             const Unit v = (q < t1) ? L[(l0 + q) * U + k] : R[(rr0 + (q - t1)) * U + k];
             unit_store<Unit, true>(out + g, v);
         }
