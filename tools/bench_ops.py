@@ -89,17 +89,19 @@ for n, d in [(1247, 16), (4096, 32)]:
         report(f"decrypt T={terms} N={n} batch={batch}", batch * terms, "term", batch * terms * 8 * dl,
                lambda: hip.decrypt_uniform(n, batch, terms, W, dmask))
         del W
-    # encrypt (device RNG) and permutation
-    batch = 1 << 20
-    plain = hip.upload(np.random.default_rng(2).integers(0, 2, batch).astype(np.uint8))
-    report(f"encrypt(device rng) N={n} batch={batch}", batch, "ct", batch * 8 * dl,
-           lambda: hip.encrypt_device_rng(n, d, plain, dkey, dmask, 7))
-    fresh = hip.encrypt_device_rng(n, d, plain, dkey, dmask, 7)
-    perm = hip.upload(np.random.default_rng(3).permutation(n).astype(np.uint32))
-    report(f"permute N={n} batch={batch}", batch, "ct", batch * 2 * 8 * dl,
-           lambda: hip.permute_uniform(n, batch, 1, fresh, perm))
-    del fresh, plain
-    torch.cuda.empty_cache()
+    # encrypt (keyed device generator: ChaCha8; VALU-issue-bound) and permutation, at 1 M and 4 M
+    # ciphertexts (a 1 M launch is 50-80 us: launch ramp and the persistent workgroups' set-up are 10 %+ of it)
+    for batch in (1 << 20, 1 << 22):
+        plain = hip.upload(np.random.default_rng(2).integers(0, 2, batch).astype(np.uint8))
+        fresh = hip.empty_words(batch * dl)
+        rng = hip.rng_from_seed(7, 8)
+        report(f"encrypt(keyed ChaCha8) N={n} batch={batch}", batch, "ct", batch * 8 * dl,
+               lambda: hip.encrypt_keyed(n, d, plain, dkey, dmask, rng, out=fresh))
+        perm = hip.upload(np.random.default_rng(3).permutation(n).astype(np.uint32))
+        report(f"permute N={n} batch={batch}", batch, "ct", batch * 2 * 8 * dl,
+               lambda: hip.permute_uniform(n, batch, 1, fresh, perm))
+        del fresh, plain
+        torch.cuda.empty_cache()
 
 if args.json:
     with open(args.json, "w") as f:
