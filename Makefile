@@ -1,6 +1,8 @@
-# Builds the two native libraries without Python (same commands as `python -m csgn_amd.build`):
-#   csgn_amd/lib/libcsgn_hip.so   the C ABI (include/csgn_hip.h): hand-written gfx950 kernels
-#   csgn_amd/lib/libcertFHE.so    the drop-in certFHE:: classes (include/certfhe/) over that ABI
+# Builds the native libraries without Python (same commands as `python -m csgn_amd.build`):
+#   csgn_amd/lib/libcsgn_hip.so    the C ABI (include/csgn_hip.h): hand-written gfx950 kernels
+#   csgn_amd/lib/libcsgn_shard.so  batch sharding + RCCL all-gather of term counts (include/csgn_shard.h)
+#   csgn_amd/lib/libcertFHE.so     the drop-in certFHE:: classes (include/certfhe/) over that ABI
+# `make tools` adds tools/bin/shard_mul (thread-per-GPU driver) and tools/bin/bench_mul.
 # hipcc cross-compiles for gfx950 without a GPU.  `make check` also builds the test-only oracle.
 HIPCC   ?= $(or $(shell command -v hipcc 2>/dev/null),/opt/rocm/bin/hipcc)
 CXX     ?= g++
@@ -12,8 +14,25 @@ HIP_HDR := $(wildcard $(CSRC)/*.h) include/csgn_hip.h
 CLS_SRC := $(sort $(wildcard $(CSRC)/certfhe/*.cpp))
 CLS_HDR := $(wildcard include/certfhe/*.h) $(wildcard $(CSRC)/certfhe/*.h)
 
-.PHONY: all check clean
-all: $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcertFHE.so
+ROCM_LIB ?= $(dir $(HIPCC))../lib
+
+.PHONY: all tools check clean
+all: $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so
+
+$(LIBDIR)/libcsgn_shard.so: $(CSRC)/csgn_shard.hip include/csgn_shard.h include/csgn_hip.h
+	mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared -Iinclude -o $@ $(CSRC)/csgn_shard.hip -L$(ROCM_LIB) -lrccl
+
+tools: tools/bin/shard_mul tools/bin/bench_mul
+
+tools/bin/shard_mul: tools/shard_mul.cpp $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so
+	mkdir -p tools/bin
+	$(CXX) -std=c++11 -O2 -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_hip -lcsgn_shard -lpthread \
+	    '-Wl,-rpath,$(abspath $(LIBDIR))' '-Wl,-rpath,$(abspath $(ROCM_LIB))'
+
+tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
+	mkdir -p tools/bin
+	$(CXX) -std=c++11 -O2 -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_hip '-Wl,-rpath,$(abspath $(LIBDIR))'
 
 $(LIBDIR)/libcsgn_hip.so: $(HIP_SRC) $(HIP_HDR)
 	mkdir -p $(LIBDIR)
@@ -28,4 +47,4 @@ check: all
 	python -m pytest tests -q -m "not gpu"
 
 clean:
-	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcertFHE.so
+	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so tools/bin/shard_mul tools/bin/bench_mul

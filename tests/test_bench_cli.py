@@ -34,3 +34,47 @@ def test_parent_of_a_multi_rank_run_makes_no_gpu_call():
     spawn = src[src.index("def spawn_ranks"):src.index("def cpu_baseline")]
     assert "device_count()" in spawn and "HipPath" not in spawn and "set_device" not in spawn
     assert "torch.distributed.run" in spawn and "subprocess.call" in spawn
+
+
+import json
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_contract_line_on_the_gpu():
+    """A short run of bench.py (reduced batch; the real shape per pair) prints exactly ONE JSON line on
+    stdout with the contract's keys, a roofline object, a cpu_baseline object, and verified results."""
+    p = run(["--batch", "512", "--slots", "32", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1.5",
+             "--no-cpu-all-cores"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[:500]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "mult/s" and d["dtype"] == "u64"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["verified_vs_oracle"] is True and len(d["config"]["verified_slots"]) >= 2
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
+    assert r["kernel"] == "k_touch+k_mul_flat"
+    c = d["cpu_baseline"]
+    assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_spawned_rank_with_the_rccl_gather():
+    """--spawn: the parent starts one rank through torch.distributed.run; --force-collective puts the
+    native RCCL all-gather of the term counts into the timed region."""
+    p = run(["--gpus", "1", "--spawn", "--force-collective", "--batch", "256", "--slots", "32", "--steps", "2",
+             "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[:500]                     # RCCL's banner must not reach stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "ncclAllGather" in d["config"]["collective"] and d["config"]["verified_vs_oracle"] is True
