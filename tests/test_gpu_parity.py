@@ -511,6 +511,37 @@ def test_encrypt_keyed_rounds_and_a_million_ciphertexts(hip, oracle, rounds):
     assert np.array_equal(hip.download(hip.decrypt_uniform(n, batch, 1, out, dmask)), plain)
 
 
+def test_encrypt_keyed_fuzz(hip, oracle, knobs):
+    """60 random (N, D, batch, first ciphertext, rounds) cases, keys with repeated indices among them:
+    the wave kernel with compact and with full LDS tables and the one-lane-per-ciphertext kernel
+    against the restated definition, word for word."""
+    rng = np.random.default_rng(909 + FUZZ_SEED)
+    for it in range(60):
+        n = int(rng.choice([int(rng.integers(16, 4300)), 1247, 4096, 128, 640, 2560, 8192, 384]))
+        d = int(rng.integers(1, min(n, 40) + 1))
+        key = rng.permutation(n)[:d].astype(np.uint64)
+        if it % 6 == 0 and d > 2:
+            key[1] = key[0]                                   # setKey allows repeated indices
+        if it % 11 == 0:
+            key[:] = key[0]                                   # a single distinct position: never cleared
+        batch = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 500, 1500]))
+        first = int(rng.choice([0, 1, int(rng.integers(0, 1 << 20)), int(rng.integers(0, 1 << 40))]))
+        rounds = int(rng.choice([8, 8, 12, 20]))
+        plain = rng.integers(0, 2, batch).astype(np.uint8)
+        if d <= 3:
+            plain[:] = 0                                      # make the clear frequent
+        seed = int(rng.integers(0, 1 << 62))
+        grng = hip.rng_from_seed(seed, rounds)
+        rk, nonce = oracle.rng_from_seed(seed)
+        want = oracle.encrypt_keyed(n, key, plain, rk, nonce, rounds, first_ciphertext=first)
+        dmask, dkey, dplain = hip.upload(hip.key_mask(n, key)), hip.upload(key), hip.upload(plain)
+        for wave, compact in ((1, 1), (1, 0), (0, -1)):
+            knobs.set("enc_wave", wave)
+            knobs.set("enc_compact", compact)
+            got = hip.download(hip.encrypt_keyed(n, d, dplain, dkey, dmask, grng, first_ciphertext=first))
+            assert np.array_equal(got, want), (it, n, d, batch, first, rounds, wave, compact)
+
+
 def test_encrypt_keyed_os_entropy_and_argument_checks(hip, oracle):
     import ctypes as C
     from csgn_amd import capi
