@@ -2,6 +2,7 @@
 #   csgn_amd/lib/libcsgn_hip.so    the C ABI (include/csgn_hip.h): hand-written gfx950 kernels
 #   csgn_amd/lib/libcsgn_shard.so  batch sharding + RCCL all-gather of term counts (include/csgn_shard.h)
 #   csgn_amd/lib/libcertFHE.so     the drop-in certFHE:: classes (include/certfhe/) over that ABI
+#   csgn_amd/lib/libcertFHE_shard.so  certFHE::ShardGroup / ShardedBatch: one batch over the GPUs of a node
 # `make tools` adds tools/bin/shard_mul (thread-per-GPU driver) and tools/bin/bench_mul.
 # hipcc cross-compiles for gfx950 without a GPU.  `make check` also builds the test-only oracle.
 HIPCC   ?= $(or $(shell command -v hipcc 2>/dev/null),/opt/rocm/bin/hipcc)
@@ -17,7 +18,7 @@ CLS_HDR := $(wildcard include/certfhe/*.h) $(wildcard $(CSRC)/certfhe/*.h)
 ROCM_LIB ?= $(dir $(HIPCC))../lib
 
 .PHONY: all tools check clean
-all: $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so
+all: $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcertFHE_shard.so
 
 $(LIBDIR)/libcsgn_shard.so: $(CSRC)/csgn_shard.hip include/csgn_shard.h include/csgn_hip.h
 	mkdir -p $(LIBDIR)
@@ -25,10 +26,17 @@ $(LIBDIR)/libcsgn_shard.so: $(CSRC)/csgn_shard.hip include/csgn_shard.h include/
 
 tools: tools/bin/shard_mul tools/bin/bench_mul
 
-tools/bin/shard_mul: tools/shard_mul.cpp $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so
+tools/bin/shard_mul: tools/shard_mul.cpp $(LIBDIR)/libcertFHE_shard.so
 	mkdir -p tools/bin
-	$(CXX) -std=c++11 -O2 -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_hip -lcsgn_shard -lpthread \
-	    '-Wl,-rpath,$(abspath $(LIBDIR))' '-Wl,-rpath,$(abspath $(ROCM_LIB))'
+	$(CXX) -std=c++11 -O2 -Iinclude -Iinclude/certfhe -o $@ $< -L$(LIBDIR) -lcertFHE_shard -lcertFHE -lcsgn_shard -lcsgn_hip \
+	    -lpthread '-Wl,-rpath,$(abspath $(LIBDIR))' '-Wl,-rpath,$(abspath $(ROCM_LIB))'
+
+# certFHE::ShardGroup / ShardedBatch over libcsgn_shard.so (RCCL); apart from libcertFHE.so so that
+# single-GPU users never map RCCL
+$(LIBDIR)/libcertFHE_shard.so: $(wildcard $(CSRC)/certfhe_shard/*.cpp) $(CLS_HDR) include/csgn_shard.h \
+        $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcsgn_shard.so
+	$(CXX) -std=c++11 -O2 -fPIC -shared -pthread -Iinclude -Iinclude/certfhe -o $@ $(wildcard $(CSRC)/certfhe_shard/*.cpp) \
+	    -L$(LIBDIR) -lcertFHE -lcsgn_shard -lcsgn_hip '-Wl,-rpath,$$ORIGIN'
 
 tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
 	mkdir -p tools/bin
@@ -47,4 +55,4 @@ check: all
 	python -m pytest tests -q -m "not gpu"
 
 clean:
-	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so tools/bin/shard_mul tools/bin/bench_mul
+	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcertFHE_shard.so tools/bin/shard_mul tools/bin/bench_mul

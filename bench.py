@@ -20,8 +20,13 @@ visible (exit 2 otherwise -- never a silent fall back to fewer GPUs) and runs
 `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a child process.  Under an
 external torchrun, --gpus must equal WORLD_SIZE (exit 2 otherwise).
 The gather goes through the native C ABI (csgn_comm_gather_counts of libcsgn_shard.so ->
-ncclAllGather, include/csgn_shard.h) on the launch stream; if that communicator cannot be formed
-the same gather runs through torch.distributed's RCCL backend, and `config.collective` says which.
+ncclAllGather, include/csgn_shard.h) on the SAME explicit HIP stream as the multiply and the events
+that time it.  The ranks rendezvous over gloo (the ncclUniqueId is 128 bytes; barrier and the
+max-over-ranks time are host-side too), so a rank holds ONE RCCL communicator -- the native one --
+and no torch NCCL process group; `config.collective` names the RCCL version and file the process
+bound.  A rank that fails aborts its communicator and exits non-zero (torchrun then ends the
+others): no fall-back to another collective path once RCCL initialisation has begun.
+`--collective torch` is the opt-in alternative (torch.distributed's own RCCL process group).
 
 Rank 0 prints ONE JSON line (contract in the task description), including
   "roofline":     algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak
@@ -255,20 +260,30 @@ def main():
         print(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
     use_dist = world > 1 or args.force_collective
+    native = use_dist and args.collective == "native" and not args.dev_ranks_share_gpu
     if use_dist:
         if not in_rank:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dev_ranks_share_gpu:
+        # Native collective: the process group is only the out-of-band channel (128-byte id, host
+        # barrier, max of a double), so it runs on gloo and the rank's ONE RCCL communicator is the
+        # native one.  --collective torch builds torch's RCCL process group instead.
+        if native or args.dev_ranks_share_gpu:
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never resolve the hostname
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    host_group = native or args.dev_ranks_share_gpu          # collectives of `dist` take host tensors
     n_gpus = world
 
     hip = HipPath(local_rank)
     dev = hip.device
+    # Everything of a step -- multiply, term counts, the gather, the events -- goes on ONE explicit
+    # stream (a non-zero handle: NULL would mean the legacy default stream to the C ABI).
+    run_stream = torch.cuda.Stream(device=dev)
     T = args.terms
     dl = hip.default_len(N_BITS)
     batch = args.batch
@@ -291,42 +306,64 @@ def main():
     gathered = torch.empty((total_pairs,), dtype=torch.int64, device=dev) if use_dist else None
 
     # ---- the one exchange: all-gather of per-pair result term counts.  Native = the C ABI's own
-    # RCCL communicator (libcsgn_shard.so); the 128-byte ncclUniqueId travels over the process
-    # group torchrun already set up. ----
+    # RCCL communicator (libcsgn_shard.so).  Set-up is phased so that the ranks cannot drift apart:
+    # (1) local load + id on rank 0, (2) agree that every rank got there, (3) ship the id and join,
+    # (4) agree again.  A failure after (3) has begun is fatal for the job (exit 1), never a silent
+    # switch to another path on some ranks only. ----
     collective = "none"
     comm = None
     shard_lib = None
-    if use_dist:
-        collective = "torch.distributed.all_gather_into_tensor(result term counts) [RCCL]"
-        if args.collective == "native" and not args.dev_ranks_share_gpu:
-            try:
-                shard_lib = capi.load_shard_library()
-                ident = [None]
-                if rank == 0:
-                    buf = ctypes.create_string_buffer(capi.CSGN_COMM_ID_BYTES)
-                    capi.check_shard(shard_lib.csgn_comm_unique_id(buf))
-                    ident = [bytes(buf.raw)]
-                dist.broadcast_object_list(ident, src=0, device=dev)
-                h = ctypes.c_void_p()
-                capi.check_shard(shard_lib.csgn_comm_init_rank(ident[0], rank, world, local_rank, ctypes.byref(h)))
-                comm = h
-                collective = "csgn_comm_gather_counts -> ncclAllGather(result term counts) [RCCL, native C ABI]"
-            except Exception as e:           # a second RCCL path exists: say so and use it
-                print(f"# rank {rank}: native communicator unavailable ({e!r}); using torch.distributed", file=sys.stderr)
-                comm = None
-        cdev = torch.device("cpu") if args.dev_ranks_share_gpu else dev     # gloo reduces host tensors
-        ok_native = torch.tensor([1 if comm is not None else 0], device=cdev)
-        dist.all_reduce(ok_native, op=dist.ReduceOp.MIN)      # all ranks must take the same path
-        if int(ok_native.item()) == 0 and comm is not None:
-            shard_lib.csgn_comm_destroy(comm)
-            comm = None
-        if comm is None:
-            collective = "torch.distributed.all_gather_into_tensor(result term counts) [%s]" % (
-                "gloo, DEVELOPMENT rehearsal: ranks share one GPU" if args.dev_ranks_share_gpu else "RCCL")
+
+    def all_ok(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], device=(torch.device("cpu") if host_group else dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    if use_dist and not native:
+        collective = "torch.distributed.all_gather_into_tensor(result term counts) [%s]" % (
+            "gloo, DEVELOPMENT rehearsal: ranks share one GPU" if args.dev_ranks_share_gpu else "RCCL, torch process group")
+    if native:
+        ident, err = [None], None
+        try:                                                      # phase 1: local, cannot block
+            shard_lib = capi.load_shard_library()
+            rt_code, hd_code, rccl_path = capi.rccl_info()
+            if rank == 0:
+                buf = ctypes.create_string_buffer(capi.CSGN_COMM_ID_BYTES)
+                capi.check_shard(shard_lib.csgn_comm_unique_id(buf))
+                ident = [bytes(buf.raw)]
+        except Exception as e:
+            err = e
+            print(f"# rank {rank}: native communicator unavailable: {e!r}", file=sys.stderr)
+        if not all_ok(err is None):                               # phase 2
+            if rank == 0:
+                print("bench.py: libcsgn_shard.so / RCCL could not be set up on every rank; refusing to run "
+                      "(use --collective torch for torch.distributed's own RCCL group)", file=sys.stderr)
+            sys.exit(1)
+        dist.broadcast_object_list(ident, src=0)                  # phase 3: from here on failure is fatal
+        h = ctypes.c_void_p()
+        # a torch process has torch/lib/librccl.so mapped already; binding to that one copy is what
+        # keeps ONE RCCL in the process, so a minor-version skew against the build header is accepted
+        # and REPORTED (a major skew is refused by the library)
+        rc = shard_lib.csgn_comm_init_rank_ex(ident[0], rank, world, local_rank, capi.CSGN_COMM_ALLOW_MINOR_SKEW,
+                                              ctypes.byref(h))
+        if rc != 0:
+            print(f"# rank {rank}: csgn_comm_init_rank_ex failed [{rc}]: "
+                  f"{shard_lib.csgn_shard_last_error().decode(errors='replace')}", file=sys.stderr)
+        else:
+            comm = h
+        if not all_ok(comm is not None):                          # phase 4
+            if comm is not None:
+                shard_lib.csgn_comm_abort(comm)
+                shard_lib.csgn_comm_destroy(comm)
+            sys.exit(1)
+        collective = ("csgn_comm_gather_counts -> ncclAllGather(result term counts) [RCCL %s from %s, native C ABI "
+                      "built against %s; rendezvous over gloo, no torch NCCL group]" % (
+                          capi.rccl_version_text(rt_code), rccl_path, capi.rccl_version_text(hd_code)))
     torch.cuda.synchronize()
 
     def gather():
         if comm is not None:
+            assert hip.stream == run_stream.cuda_stream and hip.stream != 0
             capi.check_shard(shard_lib.csgn_comm_gather_counts(comm, counts.data_ptr(), total_pairs,
                                                                gathered.data_ptr(), hip.stream))
         elif args.dev_ranks_share_gpu:
@@ -340,6 +377,10 @@ def main():
             capi.check_shard(shard_lib.csgn_shard_product_counts(batch, None, None, T, T, counts.data_ptr(), hip.stream))
         else:
             counts.fill_(T * T)
+
+    def host_barrier():
+        if use_dist:
+            dist.barrier()
 
     def step(e_mul=None, e_step=None):
         if e_step:
@@ -355,24 +396,34 @@ def main():
         if e_step:
             e_step[1].record()
 
-    for _ in range(args.warmup):
-        step()
-
     mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev_mul = [mk() for _ in range(args.steps)]
     ev_step = [mk() for _ in range(args.steps)]
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev_mul[k], ev_step[k])
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    try:
+        with torch.cuda.stream(run_stream):                 # hip.stream is now run_stream's handle
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            host_barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step(ev_mul[k], ev_step[k])
+            torch.cuda.synchronize()
+            host_barrier()
+            elapsed = time.perf_counter() - t0
+        if comm is not None:
+            capi.check_shard(shard_lib.csgn_comm_check(comm))      # an asynchronous RCCL error is a failed run
+    except BaseException as e:
+        # a failing rank must take the job down, not leave its peers inside a collective: abort the
+        # communicator (releases them) and exit non-zero (torchrun ends the remaining ranks)
+        print(f"# rank {rank}: FAILED in the timed loop: {e!r}", file=sys.stderr)
+        if comm is not None:
+            shard_lib.csgn_comm_abort(comm)
+        sys.stderr.flush()
+        os._exit(1)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=(torch.device("cpu") if args.dev_ranks_share_gpu else dev))
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=(torch.device("cpu") if host_group else dev))
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())

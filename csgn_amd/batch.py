@@ -208,6 +208,21 @@ class HipPath:
                                           C.byref(rng), _ptr(out), self.stream))
         return out[: batch * dl]
 
+    def encrypt_mul_keyed(self, n_bits: int, d: int, plain_a: torch.Tensor, plain_b: torch.Tensor, key: torch.Tensor,
+                          mask: torch.Tensor, rng_a: "capi.CsgnRng", rng_b: "capi.CsgnRng", first_ciphertext: int = 0,
+                          with_bits: bool = True):
+        """Fused fresh chain: product b = Enc_A(plain_a[b]) & Enc_B(plain_b[b]) in one kernel
+        (csgn_encrypt_mul_keyed); returns (products, Dec bits or None)."""
+        batch = plain_a.numel()
+        assert plain_b.numel() == batch
+        dl = self.default_len(n_bits)
+        out = self.empty_words(max(batch * dl, 1))
+        bits = torch.full((max(batch, 1),), 7, dtype=torch.uint8, device=self.device) if with_bits else None
+        check(self.lib.csgn_encrypt_mul_keyed(n_bits, d, batch, first_ciphertext, _ptr(plain_a), _ptr(plain_b), _ptr(key),
+                                              _ptr(mask), C.byref(rng_a), C.byref(rng_b), _ptr(out), _ptr(bits),
+                                              self.stream))
+        return out[: batch * dl], (bits[:batch] if with_bits else None)
+
     # -- permutation --------------------------------------------------------------------
     def permute_uniform(self, n_bits: int, batch: int, terms_in: int, words: torch.Tensor,
                         perm: torch.Tensor, per_term: bool = False) -> torch.Tensor:

@@ -21,6 +21,7 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(LIBDIR, "libcsgn_hip.so")
 CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
 SHARD_LIB = os.path.join(LIBDIR, "libcsgn_shard.so")
+CERTFHE_SHARD_LIB = os.path.join(LIBDIR, "libcertFHE_shard.so")
 
 HIP_SOURCES = ["csgn_capi.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
                "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip", "csgn_bitlen.hip", "csgn_tuning.cpp"]
@@ -90,11 +91,30 @@ def build_certfhe(force: bool = False, verbose: bool = False):
     return CERTFHE_LIB
 
 
+def build_certfhe_shard(force: bool = False, verbose: bool = False):
+    """certFHE::ShardGroup / ShardedBatch (include/certfhe/ShardedBatch.h): the class-level face of the
+    sharded batch, over libcsgn_hip.so + libcsgn_shard.so.  A library of its own so that
+    libcertFHE.so does not pull in RCCL."""
+    src_dir = os.path.join(CSRC, "certfhe_shard")
+    srcs = sorted(os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith(".cpp"))
+    hdr_dir = os.path.join(INCLUDE, "certfhe")
+    hdrs = [os.path.join(hdr_dir, f) for f in os.listdir(hdr_dir)] + [os.path.join(INCLUDE, "csgn_shard.h")]
+    if force or _stale(CERTFHE_SHARD_LIB, srcs + hdrs + [HIP_LIB, SHARD_LIB, CERTFHE_LIB]):
+        cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-pthread", "-I" + INCLUDE, "-I" + hdr_dir,
+               "-o", CERTFHE_SHARD_LIB] + srcs + ["-L" + LIBDIR, "-lcertFHE", "-lcsgn_shard", "-lcsgn_hip",
+                                                  "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CERTFHE_SHARD_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False):
     out = [build_hip(force, verbose), build_shard(force, verbose)]
     c = build_certfhe(force, verbose)
     if c:
         out.append(c)
+        out.append(build_certfhe_shard(force, verbose))
     return out
 
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "csgn_rng_from_seed": (C.c_int, [vp, u64, C.c_uint32]),
     "csgn_encrypt_keyed_layout": (C.c_int, [u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "csgn_encrypt_keyed": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_encrypt_mul_keyed": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_device_rng": (C.c_int, [u64, u64, u64, vp, vp, vp, u64, vp, vp]),
     "csgn_permute_uniform": (C.c_int, [u64, u64, u64, C.c_int, vp, vp, vp, vp]),
     "csgn_bitlen_scratch_bytes": (C.c_size_t, [u64]),
@@ -187,16 +188,29 @@ def tuning_names():
 # -- libcsgn_shard.so (include/csgn_shard.h): partition + RCCL all-gather of term counts ---------
 _SHARD_LIB_PATH = os.path.join(PKG, "lib", "libcsgn_shard.so")
 CSGN_COMM_ID_BYTES = 128
+CSGN_STREAM_OF_COMM = C.c_void_p(-1).value        # (void *)-1: the communicator's own stream
+CSGN_ERR_TIMEOUT = -5
+CSGN_COMM_STRICT = 0
+CSGN_COMM_ALLOW_MINOR_SKEW = 1
+CSGN_COMM_OPT_FORCE_GROUPED_BROADCAST = 1
 
 SHARD_SIGNATURES = {
     "csgn_shard_last_error": (C.c_char_p, []),
     "csgn_shard_range": (C.c_int, [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]),
     "csgn_shard_owner": (C.c_int, [u64, u64, C.c_int]),
     "csgn_comm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "csgn_comm_rccl_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "csgn_shard_gather_plan": (C.c_int, [u64, C.c_int, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
     "csgn_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    "csgn_comm_init_all_ex": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_uint, C.POINTER(vp)]),
     "csgn_comm_unique_id": (C.c_int, [C.c_char_p]),
     "csgn_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "csgn_comm_init_rank_ex": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(vp)]),
     "csgn_comm_destroy": (C.c_int, [vp]),
+    "csgn_comm_abort": (C.c_int, [vp]),
+    "csgn_comm_check": (C.c_int, [vp]),
+    "csgn_comm_set_timeout_ms": (C.c_int, [vp, u64]),
+    "csgn_comm_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
     "csgn_comm_rank": (C.c_int, [vp]),
     "csgn_comm_world": (C.c_int, [vp]),
     "csgn_comm_device": (C.c_int, [vp]),
@@ -229,6 +243,19 @@ def load_shard_library() -> C.CDLL:
         fn.argtypes = args
     _shard_lib = lib
     return lib
+
+
+def rccl_info():
+    """(runtime version code, header version code, path of the librccl the process bound)."""
+    lib = load_shard_library()
+    rt, hd = C.c_int(0), C.c_int(0)
+    path = C.create_string_buffer(1024)
+    check_shard(lib.csgn_comm_rccl_info(C.byref(rt), C.byref(hd), path, len(path)))
+    return rt.value, hd.value, path.value.decode()
+
+
+def rccl_version_text(code: int) -> str:
+    return "%d.%d.%d" % (code // 10000, (code // 100) % 100, code % 100)
 
 
 def check_shard(rc: int) -> None:

@@ -599,6 +599,33 @@ int csgn_encrypt_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t fir
     return CSGN_OK;
 }
 
+int csgn_encrypt_mul_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t first_ciphertext,
+                           const uint8_t *d_plain_a, const uint8_t *d_plain_b, const uint64_t *d_key,
+                           const uint64_t *d_mask, const csgn_rng *h_rng_a, const csgn_rng *h_rng_b,
+                           uint64_t *d_out, uint8_t *d_bits, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(h_rng_a && h_rng_b, "h_rng is null");
+    REQUIRE(h_rng_a->rounds == 8 || h_rng_a->rounds == 12 || h_rng_a->rounds == 20, "rng rounds must be 8, 12 or 20");
+    REQUIRE(h_rng_a->rounds == h_rng_b->rounds, "both generators must use the same number of rounds");
+    REQUIRE(memcmp(h_rng_a->key, h_rng_b->key, sizeof(h_rng_a->key)) != 0 || h_rng_a->nonce != h_rng_b->nonce,
+            "the two operands must draw from different streams (same key AND nonce given)");
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
+    REQUIRE(d_plain_a && d_plain_b && d_key && d_mask && d_out, "null device pointer");
+    REQUIRE(first_ciphertext + batch >= first_ciphertext && first_ciphertext + batch < (1ull << 56),
+            "ciphertext index range too large");
+    hipError_t e = csgn::encrypt_mul_keyed(n_bits, d, batch, first_ciphertext, d_plain_a, d_plain_b, (const u64 *)d_key,
+                                           (const u64 *)d_mask, h_rng_a->key, h_rng_a->nonce, h_rng_b->key,
+                                           h_rng_b->nonce, h_rng_a->rounds, nullptr, (u64 *)d_out, d_bits, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "batch too large for one launch");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
 int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,
                             const uint8_t *d_plain, const uint64_t *d_key,
                             const uint64_t *d_mask, uint64_t seed, uint64_t *d_out, void *stream)

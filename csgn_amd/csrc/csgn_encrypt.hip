@@ -228,8 +228,11 @@ __global__ void __launch_bounds__(256) k_encrypt_seg(u64 n_bits, u32 dL, u32 U, 
 // layout, ROUNDS = 8, 12 or 20) in counter mode under a 256-bit SECRET key.  The output cannot be
 // inverted to the key or to other outputs (the round-1 generator, splitmix64 of seed + index, was a
 // bijection of its state: one mask-free ciphertext word gave away the seed and with it the secret
-// positions -- ADVICE r1).  Pure 32-bit add / xor / rotate: every instruction is full rate on the
-// CDNA4 VALU (v_add_u32, v_xor_b32, v_alignbit_b32), no quarter-rate multiplies.
+// positions -- ADVICE r1).  Pure 32-bit add / xor / rotate.  Measured on gfx950 (tools/valu_bench.hip,
+// profiles/r03/valu_issue.txt): v_add_u32 and v_xor_b32 issue at 2.25 cycles per wave64 instruction and
+// SIMD with two or more waves resident, v_alignbit_b32 -- like every shift, permute and 3-operand
+// integer op -- at 4.25, and the ChaCha mix of the three at 3.7-3.9: that, not 2, is the issue ceiling
+// this kernel is priced against.
 //
 // Keystream layout (restated independently in oracle/csgn_oracle.c): a ciphertext is U = ceil(dL/2)
 // 16-byte units; P = U / gcd(U, 256) and Gc = 256*P/U, so that a GROUP of Gc ciphertexts is exactly
@@ -304,6 +307,7 @@ struct EncWaveArgs {
     u64 first_ct, batch;          // global index of plain[0] / out[0], ciphertext count
     u64 group0, ngroups;          // first group and number of groups the launch covers
     u32 U, Gc, D, iters;          // iters: groups per wave (every wave of the grid runs the same count)
+    u32 n_bits;
     u32 tail_lo, tail_hi;         // the last word's valid-bit mask
     FastDiv dU;
 };
@@ -328,10 +332,14 @@ __device__ inline bool unit_covers_chain(unit16 v, unit16 m)
 // N=1247 group, four workgroups per CU) ONE 4-byte entry per unit -- local ciphertext number, byte
 // offset of its key-mask unit, "last unit of a ciphertext" flag -- and the U mask units themselves
 // (5.3 KB): five more VALU instructions per unit, four times the resident waves.
+// plw: the plaintext bytes of the group's Gc ciphertexts, put into LDS by the wave before the call
+// (0 for ciphertexts outside the launch's range).  NOTHING in the unit loop loads from global memory:
+// a load's s_waitcnt vmcnt() also waits for the non-temporal stores issued before it, i.e. for an HBM
+// write round trip per unit (round 2's form did exactly that and sat at 67 % of the issue rate).
 template <int ROUNDS, int P, bool FULL, bool COMPACT>
 __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, const uint2 *ttab,
-                                     const unsigned short *ctab, u64 *cover, u32 lane, u64 group, u32 nonce_lo,
-                                     u32 nonce_hi)
+                                     const unsigned short *ctab, u64 *cover, const unsigned char *plw, u32 lane,
+                                     u64 group, u32 nonce_lo, u32 nonce_hi)
 {
     const u32 U = a.U;
     const u64 cbase = group * a.Gc;                        // first ciphertext of the group (global index)
@@ -345,7 +353,6 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
     // first group; only in-range elements are touched)
     const long long origin = (long long)cbase - (long long)a.first_ct;
     unit16 *outg = a.out + origin * (long long)U;
-    const uint8_t *plaing = a.plain + origin;
     const u64 blk0 = group * (u64)P * 64u + lane;
     u32 acc_lo = 0, acc_hi = 0;                            // lane s keeps the cover ballot of slot s = p*4+q
 #pragma unroll
@@ -373,7 +380,7 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
                 cl = ctab[r];
             }
             const bool inr = FULL || (cl - cl_lo < cl_hi - cl_lo);
-            const u32 pl = plaing[FULL ? cl : min(max(cl, cl_lo), cl_hi - 1u)];
+            const u32 pl = plw[cl];
             unit16 v;
             v.x = x[4 * q];
             v.y = x[4 * q + 1];
@@ -408,7 +415,8 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
     uint2 *ttab = reinterpret_cast<uint2 *>(smem_raw + m_bytes);
     const size_t t_bytes = COMPACT ? (size_t)R * 4u : (size_t)R * 8u;
     u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + ((m_bytes + t_bytes + 7u) & ~(size_t)7u));
-    unsigned short *ctab = reinterpret_cast<unsigned short *>(cover_all + 4u * P * 4u);
+    unsigned char *plw = reinterpret_cast<unsigned char *>(cover_all + 4u * P * 4u) + wave * 256u;   // Gc <= 256 bytes per wave
+    unsigned short *ctab = reinterpret_cast<unsigned short *>(cover_all + 4u * P * 4u + 4u * 32u);
     if (COMPACT) {
         for (u32 k = tid; k < U; k += 256u)
             mtab[k] = a.mask[k];
@@ -443,10 +451,17 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
         const u64 group = a.group0 + gi;
         const u64 cbase = group * a.Gc;
         const bool full = cbase >= a.first_ct && cbase + a.Gc <= a.first_ct + a.batch;
+        // the group's plaintext bytes -> LDS (the one global read of the group, before any of its stores)
+        for (u32 cl = lane; cl < a.Gc; cl += kWave) {
+            const u64 c = cbase + cl;
+            const bool in = c >= a.first_ct && c < a.first_ct + a.batch;
+            plw[cl] = in ? (unsigned char)(a.plain[c - a.first_ct] & 1u) : (unsigned char)0;
+        }
+        __builtin_amdgcn_wave_barrier();
         if (full)
-            encrypt_group<ROUNDS, P, true, COMPACT>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
+            encrypt_group<ROUNDS, P, true, COMPACT>(a, mtab, ttab, ctab, cover, plw, lane, group, nonce_lo, nonce_hi);
         else
-            encrypt_group<ROUNDS, P, false, COMPACT>(a, mtab, ttab, ctab, cover, lane, group, nonce_lo, nonce_hi);
+            encrypt_group<ROUNDS, P, false, COMPACT>(a, mtab, ttab, ctab, cover, plw, lane, group, nonce_lo, nonce_hi);
         __builtin_amdgcn_wave_barrier();        // cover[] is private to this wave; its LDS operations run in order
         // src/SecretKey.cpp:51-76 for plaintext 0: if ALL D secret positions came out 1 the chosen one is
         // cleared (the reference draws the chosen position first and forces it to 0 when the others are
@@ -464,7 +479,7 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
                 bit += take;
                 left -= take;
             }
-            if (!all || (a.plain[c - a.first_ct] & 1u))
+            if (!all || plw[cl])
                 continue;
             // with a single distinct secret position there are no "other" positions and the reference
             // never clears (its v stays 0, src/SecretKey.cpp:55-76)
@@ -474,6 +489,8 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
             if (secret_bits < 2u)
                 continue;
             const u32 pos = keyed_draw_pos<ROUNDS>(a.rng, nonce_lo, nonce_hi, c, a.key_idx, a.D);
+            if (pos >= a.n_bits)
+                continue;                                       // a corrupt d_key must not write outside the ciphertext
             __threadfence();                                    // this wave's stores of the word have landed
             u64 *word = reinterpret_cast<u64 *>(a.out) + (c - a.first_ct) * (u64)(2u * U) + (pos >> 6);
             atomicAnd(reinterpret_cast<unsigned long long *>(word), ~(1ull << (63u - (pos & 63u))));
@@ -543,8 +560,268 @@ __global__ void __launch_bounds__(256) k_encrypt_keyed_ct(EncKeyed rng, const u6
     }
     if (!pl && all && secret_bits >= 2u) {     // one distinct position: the reference never clears
         const u32 pos = keyed_draw_pos<ROUNDS>(rng, nonce_lo, nonce_hi, c, key_idx, D);
-        o[pos >> 6] &= ~(1ull << (63u - (pos & 63u)));     // same lane wrote the word: program order holds
+        if ((pos >> 6) < dL)                               // a corrupt d_key must not write outside the ciphertext
+            o[pos >> 6] &= ~(1ull << (63u - (pos & 63u)));     // same lane wrote the word: program order holds
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused fresh chain (SURVEY 8f-2 "fused chains"; the reference's canonical flow
+// tests/basic_operations.cpp:26-40: encrypt, encrypt, operator*, decrypt): pair c's product
+//     out_c = Enc_A(plain_a[c]) & Enc_B(plain_b[c])
+// with BOTH operands generated in registers -- operand A from (rng_a, position c), operand B from
+// (rng_b, position c), each exactly the ciphertext csgn_encrypt_keyed would have written -- ANDed
+// (Ciphertext::defaultN_multiply, src/Ciphertext.cpp:124-131) and stored once: 8*dL bytes of HBM
+// traffic per pair where the unfused chain makes five passes (two ciphertexts written, both read
+// back, the product written).  Optionally the product is decrypted on the spot: a 1x1 product
+// decrypts to 1 iff every unit of BOTH operands covers the key mask (src/SecretKey.cpp:82-102 on a
+// word-wise AND), which the kernel knows from the cover ballots it needs for the plaintext-0 rule
+// anyway.  That rule (clear the drawn position when all D came out 1) is applied to the PRODUCT:
+// clearing a bit of one factor clears the same bit of the AND.
+// ---------------------------------------------------------------------------------------
+struct EncMulArgs {
+    EncKeyed rng_a, rng_b;
+    const u64 *epoch;
+    const uint8_t *plain_a, *plain_b;
+    const u64 *key_idx;
+    const unit16 *mask;
+    unit16 *out;
+    uint8_t *bits;                // optional: Dec(out_c), one byte per pair
+    u64 first_ct, batch, group0, ngroups;
+    u32 U, Gc, D, iters, n_bits;
+    u32 tail_lo, tail_hi;
+    FastDiv dU;
+};
+
+struct EncMulPassCtx {
+    const EncMulArgs &a;
+    const unit16 *mtab;
+    const u32 *etab;
+    const unsigned char *plw_a, *plw_b;
+    unit16 *outg;
+    u64 blk0;
+    u32 lane, cl_lo, cl_hi, na_lo, na_hi, nb_lo, nb_hi;
+};
+
+template <int Q, int PI>
+__device__ __forceinline__ void encmul_unit(const EncMulPassCtx &c, const u32 (&xa)[16], const u32 (&xb)[16], u32 &aa_lo,
+                                            u32 &aa_hi, u32 &ab_lo, u32 &ab_hi)
+{
+    const u32 r = (u32)PI * 256u + (u32)Q * 64u + c.lane;
+    const u32 e = c.etab[r];
+    const u32 cl = e & 0xFFFFu;
+    const unit16 m = *reinterpret_cast<const unit16 *>(reinterpret_cast<const unsigned char *>(c.mtab) + ((e >> 16) & 0x7FFFu));
+    const u32 lastm = (u32)((int)e >> 31);                         // ~0 on a ciphertext's last unit
+    const u32 tlx = c.a.tail_lo | ~lastm, tly = c.a.tail_hi | ~lastm;
+    unit16 va, vb;
+    va.x = xa[4 * Q]; va.y = xa[4 * Q + 1]; va.z = xa[4 * Q + 2] & tlx; va.w = xa[4 * Q + 3] & tly;
+    vb.x = xb[4 * Q]; vb.y = xb[4 * Q + 1]; vb.z = xb[4 * Q + 2] & tlx; vb.w = xb[4 * Q + 3] & tly;
+    write_lane64(__ballot(unit_covers_chain(va, m)), PI * 4 + Q, aa_lo, aa_hi);
+    write_lane64(__ballot(unit_covers_chain(vb, m)), PI * 4 + Q, ab_lo, ab_hi);
+    const u32 pma = 0u - (u32)c.plw_a[cl], pmb = 0u - (u32)c.plw_b[cl];   // plaintext 1: OR the key mask in (src/SecretKey.cpp:44-45)
+    unit16 v;                                                      // Ciphertext::defaultN_multiply, src/Ciphertext.cpp:124-131
+    v.x = (va.x | (m.x & pma)) & (vb.x | (m.x & pmb));
+    v.y = (va.y | (m.y & pma)) & (vb.y | (m.y & pmb));
+    v.z = (va.z | (m.z & pma)) & (vb.z | (m.z & pmb));
+    v.w = (va.w | (m.w & pma)) & (vb.w | (m.w & pmb));
+    if (cl - c.cl_lo < c.cl_hi - c.cl_lo)
+        unit_store<unit16, true>(c.outg + r, v);
+}
+
+template <int ROUNDS, int PI>
+__device__ __forceinline__ void encmul_pass(const EncMulPassCtx &c, u32 &aa_lo, u32 &aa_hi, u32 &ab_lo, u32 &ab_hi)
+{
+    const u64 ctr = c.blk0 + (u64)PI * 64u;
+    u32 xa[16], xb[16];
+    chacha_block<ROUNDS>(c.a.rng_a, c.na_lo, c.na_hi, (u32)ctr, (u32)(ctr >> 32), xa);
+    chacha_block<ROUNDS>(c.a.rng_b, c.nb_lo, c.nb_hi, (u32)ctr, (u32)(ctr >> 32), xb);
+    encmul_unit<0, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
+    encmul_unit<1, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
+    encmul_unit<2, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
+    encmul_unit<3, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
+}
+
+template <int ROUNDS, int P>
+__global__ void __launch_bounds__(256) k_encrypt_mul_wave(EncMulArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr u32 R = 256u * P;
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const u32 U = a.U;
+    // [mtab: U mask units][etab: R u32][cover_a, cover_b: 4 waves x P*4 words each][plw_a, plw_b: 4 x 256 bytes][secret bit count]
+    unit16 *mtab = reinterpret_cast<unit16 *>(smem_raw);
+    u32 *etab = reinterpret_cast<u32 *>(smem_raw + (size_t)U * 16u);
+    u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (((size_t)U * 16u + (size_t)R * 4u + 7u) & ~(size_t)7u));
+    u64 *cover_a = cover_all + wave * (P * 4), *cover_b = cover_all + (4u + wave) * (P * 4);
+    unsigned char *plw_a = reinterpret_cast<unsigned char *>(cover_all + 8u * P * 4u) + wave * 256u;
+    unsigned char *plw_b = plw_a + 4u * 256u;
+    u32 *secret_bits = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(cover_all + 8u * P * 4u) + 8u * 256u);
+    if (tid == 0)
+        *secret_bits = 0;
+    __syncthreads();
+    u32 pop = 0;
+    for (u32 k = tid; k < U; k += 256u) {
+        const unit16 m = a.mask[k];
+        mtab[k] = m;
+        pop += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+    }
+    if (pop)
+        atomicAdd(secret_bits, pop);
+    for (u32 r = tid; r < R; r += 256u) {
+        const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
+        etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    // with a single distinct secret position the reference never clears (src/SecretKey.cpp:55-76)
+    const bool fixable = *secret_bits >= 2u;
+
+    u32 na_lo = a.rng_a.nonce_lo, na_hi = a.rng_a.nonce_hi, nb_lo = a.rng_b.nonce_lo, nb_hi = a.rng_b.nonce_hi;
+    if (a.epoch) {
+        const u64 e = *a.epoch;
+        const u64 na = (((u64)na_hi << 32) | na_lo) + e, nb = (((u64)nb_hi << 32) | nb_lo) + e;
+        na_lo = (u32)na; na_hi = (u32)(na >> 32);
+        nb_lo = (u32)nb; nb_hi = (u32)(nb >> 32);
+    }
+    for (u32 it = 0; it < a.iters; ++it) {
+        const u64 gi = ((u64)it * gridDim.x + blockIdx.x) * 4u + wave;
+        if (gi >= a.ngroups)
+            break;
+        const u64 group = a.group0 + gi;
+        const u64 cbase = group * a.Gc;
+        const u64 end = a.first_ct + a.batch;
+        const u32 cl_lo = cbase < a.first_ct ? (u32)(a.first_ct - cbase) : 0u;
+        const u32 cl_hi = cbase + a.Gc > end ? (u32)(end - cbase) : a.Gc;
+        for (u32 cl = lane; cl < a.Gc; cl += kWave) {
+            const bool in = cl - cl_lo < cl_hi - cl_lo;
+            const u64 i = cbase + cl - a.first_ct;
+            plw_a[cl] = in ? (unsigned char)(a.plain_a[i] & 1u) : (unsigned char)0;
+            plw_b[cl] = in ? (unsigned char)(a.plain_b[i] & 1u) : (unsigned char)0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long long origin = (long long)cbase - (long long)a.first_ct;
+        unit16 *outg = a.out + origin * (long long)U;
+        const u64 blk0 = group * (u64)P * 64u + lane;
+        u32 aa_lo = 0, aa_hi = 0, ab_lo = 0, ab_hi = 0;      // lane s keeps the cover ballots of slot s = p*4+q
+        EncMulPassCtx cx{a, mtab, etab, plw_a, plw_b, outg, blk0, lane, cl_lo, cl_hi, na_lo, na_hi, nb_lo, nb_hi};
+        // passes expanded by template index, not by a loop: the v_writelane lane numbers must be literal
+        // constants, and hipcc does not promise to unroll a loop whose body holds two ChaCha blocks
+        encmul_pass<ROUNDS, 0>(cx, aa_lo, aa_hi, ab_lo, ab_hi);
+        if (P > 1) encmul_pass<ROUNDS, 1>(cx, aa_lo, aa_hi, ab_lo, ab_hi);
+        if (P > 2) encmul_pass<ROUNDS, 2>(cx, aa_lo, aa_hi, ab_lo, ab_hi);
+        if (P > 3) encmul_pass<ROUNDS, 3>(cx, aa_lo, aa_hi, ab_lo, ab_hi);
+        if (P > 4) encmul_pass<ROUNDS, 4>(cx, aa_lo, aa_hi, ab_lo, ab_hi);
+        if (lane < (u32)P * 4u) {
+            cover_a[lane] = ((u64)aa_hi << 32) | aa_lo;
+            cover_b[lane] = ((u64)ab_hi << 32) | ab_lo;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (u32 cl = lane; cl < a.Gc; cl += kWave) {
+            if (!(cl - cl_lo < cl_hi - cl_lo))
+                continue;
+            const u64 c = cbase + cl;
+            bool all_a = true, all_b = true;
+            for (u32 bit = cl * U, left = U; left;) {
+                const u32 w = bit >> 6, sh = bit & 63u, take = min(left, 64u - sh);
+                const u64 need = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
+                all_a = all_a && ((cover_a[w] >> sh) & need) == need;
+                all_b = all_b && ((cover_b[w] >> sh) & need) == need;
+                bit += take;
+                left -= take;
+            }
+            const bool pl_a = plw_a[cl] != 0, pl_b = plw_b[cl] != 0;
+            const bool fix_a = all_a && !pl_a && fixable, fix_b = all_b && !pl_b && fixable;
+            if (fix_a || fix_b) {                             // probability 2^-D per operand
+                __threadfence();                              // this wave's stores of the product have landed
+                u64 *ct = reinterpret_cast<u64 *>(a.out) + (c - a.first_ct) * (u64)(2u * U);
+                if (fix_a) {
+                    const u32 pos = keyed_draw_pos<ROUNDS>(a.rng_a, na_lo, na_hi, c, a.key_idx, a.D);
+                    if (pos < a.n_bits)
+                        atomicAnd(reinterpret_cast<unsigned long long *>(ct + (pos >> 6)), ~(1ull << (63u - (pos & 63u))));
+                }
+                if (fix_b) {
+                    const u32 pos = keyed_draw_pos<ROUNDS>(a.rng_b, nb_lo, nb_hi, c, a.key_idx, a.D);
+                    if (pos < a.n_bits)
+                        atomicAnd(reinterpret_cast<unsigned long long *>(ct + (pos >> 6)), ~(1ull << (63u - (pos & 63u))));
+                }
+            }
+            if (a.bits)                                       // Dec of the product = both factors cover the key mask
+                a.bits[c - a.first_ct] = ((pl_a || (all_a && !fix_a)) && (pl_b || (all_b && !fix_b))) ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// General form of the fused chain (odd dL, P > 5, unaligned buffers): one lane per pair.
+template <int ROUNDS>
+__global__ void __launch_bounds__(256) k_encrypt_mul_keyed_ct(EncKeyed rng_a, EncKeyed rng_b, const u64 *__restrict__ epoch,
+                                                              const uint8_t *__restrict__ plain_a,
+                                                              const uint8_t *__restrict__ plain_b,
+                                                              const u64 *__restrict__ key_idx,
+                                                              const u64 *__restrict__ mask, u64 *__restrict__ out,
+                                                              uint8_t *__restrict__ bits, u64 first_ct, u64 batch,
+                                                              u32 dL, u32 U, u32 P, u32 Gc, u32 D, u64 tail)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= batch)
+        return;
+    u32 na_lo = rng_a.nonce_lo, na_hi = rng_a.nonce_hi, nb_lo = rng_b.nonce_lo, nb_hi = rng_b.nonce_hi;
+    if (epoch) {
+        const u64 e = *epoch;
+        const u64 na = (((u64)na_hi << 32) | na_lo) + e, nb = (((u64)nb_hi << 32) | nb_lo) + e;
+        na_lo = (u32)na; na_hi = (u32)(na >> 32);
+        nb_lo = (u32)nb; nb_hi = (u32)(nb >> 32);
+    }
+    const u64 c = first_ct + i, g = c / Gc;
+    const u32 r0 = (u32)(c - g * Gc) * U;
+    const bool pl_a = plain_a[i] & 1u, pl_b = plain_b[i] & 1u;
+    const u64 pma = pl_a ? ~0ull : 0ull, pmb = pl_b ? ~0ull : 0ull;
+    u64 *o = out + i * dL;
+    bool all_a = true, all_b = true;
+    u32 secret_bits = 0;
+    for (u32 j = 0; j < U; ++j) {
+        const u32 r = r0 + j, p = r >> 8, q = (r >> 6) & 3u, L = r & 63u;
+        const u64 ctr = (g * P + p) * 64u + L;
+        u32 xa[16], xb[16];
+        chacha_block<ROUNDS>(rng_a, na_lo, na_hi, (u32)ctr, (u32)(ctr >> 32), xa);
+        chacha_block<ROUNDS>(rng_b, nb_lo, nb_hi, (u32)ctr, (u32)(ctr >> 32), xb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32 alo = 0, ahi = 0, blo = 0, bhi = 0;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)                   // static register indices only
+                if ((u32)qq == q) {
+                    alo = xa[4 * qq + 2 * h]; ahi = xa[4 * qq + 2 * h + 1];
+                    blo = xb[4 * qq + 2 * h]; bhi = xb[4 * qq + 2 * h + 1];
+                }
+            const u32 k = 2u * j + (u32)h;
+            if (k >= dL)
+                continue;
+            u64 va = ((u64)ahi << 32) | alo, vb = ((u64)bhi << 32) | blo;
+            if (k == dL - 1u) {
+                va &= tail;
+                vb &= tail;
+            }
+            const u64 m = mask[k];
+            secret_bits += (u32)__popcll(m);
+            all_a = all_a && ((va & m) == m);
+            all_b = all_b && ((vb & m) == m);
+            o[k] = (va | (m & pma)) & (vb | (m & pmb));
+        }
+    }
+    const bool fixable = secret_bits >= 2u;
+    const bool fix_a = all_a && !pl_a && fixable, fix_b = all_b && !pl_b && fixable;
+    if (fix_a) {
+        const u32 pos = keyed_draw_pos<ROUNDS>(rng_a, na_lo, na_hi, c, key_idx, D);
+        if ((pos >> 6) < dL)
+            o[pos >> 6] &= ~(1ull << (63u - (pos & 63u)));
+    }
+    if (fix_b) {
+        const u32 pos = keyed_draw_pos<ROUNDS>(rng_b, nb_lo, nb_hi, c, key_idx, D);
+        if ((pos >> 6) < dL)
+            o[pos >> 6] &= ~(1ull << (63u - (pos & 63u)));
+    }
+    if (bits)
+        bits[i] = ((pl_a || (all_a && !fix_a)) && (pl_b || (all_b && !fix_b))) ? 1 : 0;
 }
 
 } // namespace
@@ -682,6 +959,7 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
         a.U = U;
         a.Gc = Gc;
         a.D = (u32)d;
+        a.n_bits = (u32)n_bits;
         a.tail_lo = (u32)tail;
         a.tail_hi = (u32)(tail >> 32);
         a.dU = csgn_fastdiv_make(U);
@@ -706,7 +984,8 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
         a.iters = (u32)((wg_needed + blocks - 1) / blocks);
         blocks = (wg_needed + a.iters - 1) / a.iters;         // equal trip counts
         const size_t lds = (compact ? (((size_t)U * 16u + 256u * P * 4u + 7u) & ~(size_t)7u)
-                                    : (size_t)256u * P * 24u) + 4u * P * 4u * 8u + (compact ? 0u : (size_t)256u * P * 2u);
+                                    : (size_t)256u * P * 24u) + 4u * P * 4u * 8u + 4u * 256u /* plw */ +
+                           (compact ? 0u : (size_t)256u * P * 2u);
 #define CSGN_ENC_WAVE(R, PP)                                                \
     do {                                                                    \
         if (compact)                                                        \
@@ -746,6 +1025,99 @@ hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8
     else
         CSGN_ENC_CT(20);
 #undef CSGN_ENC_CT
+    return hipGetLastError();
+}
+
+hipError_t encrypt_mul_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain_a,
+                             const uint8_t *plain_b, const u64 *key_idx, const u64 *mask, const u32 key_a[8],
+                             u64 nonce_a, const u32 key_b[8], u64 nonce_b, u32 rounds, const u64 *d_epoch, u64 *out,
+                             uint8_t *bits, hipStream_t s)
+{
+    if (batch == 0)
+        return hipSuccess;
+    if (rounds != 8 && rounds != 12 && rounds != 20)
+        return hipErrorInvalidValue;
+    const u64 dL = (n_bits + 63) / 64;
+    u32 U, P, Gc;
+    encrypt_keyed_layout(n_bits, &U, &P, &Gc);
+    const u32 rem = (u32)(n_bits & 63);
+    const u64 tail = rem ? ~0ull << (64 - rem) : ~0ull;
+    EncKeyed ra, rb;
+    for (int i = 0; i < 8; ++i) {
+        ra.key[i] = key_a[i];
+        rb.key[i] = key_b[i];
+    }
+    ra.nonce_lo = (u32)nonce_a;
+    ra.nonce_hi = (u32)(nonce_a >> 32);
+    rb.nonce_lo = (u32)nonce_b;
+    rb.nonce_hi = (u32)(nonce_b >> 32);
+    const bool wave_ok = dL % 2 == 0 && P <= 5 && U * 16u <= 32768u && aligned16(out) && aligned16(mask) &&
+                         tune(TUNE_ENC_WAVE) != 0;
+    if (wave_ok) {
+        EncMulArgs a;
+        a.rng_a = ra;
+        a.rng_b = rb;
+        a.epoch = d_epoch;
+        a.plain_a = plain_a;
+        a.plain_b = plain_b;
+        a.key_idx = key_idx;
+        a.mask = reinterpret_cast<const unit16 *>(mask);
+        a.out = reinterpret_cast<unit16 *>(out);
+        a.bits = bits;
+        a.first_ct = first_ct;
+        a.batch = batch;
+        a.group0 = first_ct / Gc;
+        a.ngroups = (first_ct + batch - 1) / Gc - a.group0 + 1;
+        a.U = U;
+        a.Gc = Gc;
+        a.D = (u32)d;
+        a.n_bits = (u32)n_bits;
+        a.tail_lo = (u32)tail;
+        a.tail_hi = (u32)(tail >> 32);
+        a.dU = csgn_fastdiv_make(U);
+        int cus = 256;
+        {
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess)
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        }
+        const u64 wg_needed = (a.ngroups + 3) / 4;
+        const u64 resident = (u64)cus * 4u;      // 98-122 VGPRs: four workgroups of four waves per CU
+        u64 blocks = wg_needed <= resident ? wg_needed : resident;
+        a.iters = (u32)((wg_needed + blocks - 1) / blocks);
+        blocks = (wg_needed + a.iters - 1) / a.iters;
+        const size_t lds = (((size_t)U * 16u + 256u * P * 4u + 7u) & ~(size_t)7u) + 8u * P * 4u * 8u + 8u * 256u + 8u;
+#define CSGN_ENCMUL_P(R)                                                                 \
+    switch (P) {                                                                         \
+    case 1: k_encrypt_mul_wave<R, 1><<<(u32)blocks, 256, lds, s>>>(a); break;            \
+    case 2: k_encrypt_mul_wave<R, 2><<<(u32)blocks, 256, lds, s>>>(a); break;            \
+    case 3: k_encrypt_mul_wave<R, 3><<<(u32)blocks, 256, lds, s>>>(a); break;            \
+    case 4: k_encrypt_mul_wave<R, 4><<<(u32)blocks, 256, lds, s>>>(a); break;            \
+    default: k_encrypt_mul_wave<R, 5><<<(u32)blocks, 256, lds, s>>>(a); break;           \
+    }
+        if (rounds == 8) {
+            CSGN_ENCMUL_P(8)
+        } else if (rounds == 12) {
+            CSGN_ENCMUL_P(12)
+        } else {
+            CSGN_ENCMUL_P(20)
+        }
+#undef CSGN_ENCMUL_P
+        return hipGetLastError();
+    }
+    const u64 blocks = (batch + 255) / 256;
+    if (blocks > kMaxBlocks256)
+        return hipErrorInvalidValue;
+#define CSGN_ENCMUL_CT(R)                                                                                      \
+    k_encrypt_mul_keyed_ct<R><<<(u32)blocks, 256, 0, s>>>(ra, rb, d_epoch, plain_a, plain_b, key_idx, mask, out, \
+                                                          bits, first_ct, batch, (u32)dL, U, P, Gc, (u32)d, tail)
+    if (rounds == 8)
+        CSGN_ENCMUL_CT(8);
+    else if (rounds == 12)
+        CSGN_ENCMUL_CT(12);
+    else
+        CSGN_ENCMUL_CT(20);
+#undef CSGN_ENCMUL_CT
     return hipGetLastError();
 }
 

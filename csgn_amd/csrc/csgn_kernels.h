@@ -48,6 +48,11 @@ void encrypt_keyed_layout(u64 n_bits, u32 *U, u32 *P, u32 *Gc);
 hipError_t encrypt_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain, const u64 *key_idx,
                          const u64 *mask, const u32 rng_key[8], u64 nonce, u32 rounds,
                          const u64 *d_epoch, u64 *out, hipStream_t s);
+// Fused fresh chain: out_c = Enc_A(plain_a[c]) & Enc_B(plain_b[c]) in one kernel, optional Dec of it.
+hipError_t encrypt_mul_keyed(u64 n_bits, u64 d, u64 batch, u64 first_ct, const uint8_t *plain_a,
+                             const uint8_t *plain_b, const u64 *key_idx, const u64 *mask, const u32 key_a[8],
+                             u64 nonce_a, const u32 key_b[8], u64 nonce_b, u32 rounds, const u64 *d_epoch, u64 *out,
+                             uint8_t *bits, hipStream_t s);
 hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64 *terms,
                    const u32 *perm, u64 *out, hipStream_t s);
 // one ciphertext with an explicit bitlen side array (csgn_bitlen.hip)

@@ -8,9 +8,14 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 static_assert(CSGN_COMM_ID_BYTES == sizeof(ncclUniqueId), "id buffer must hold an ncclUniqueId");
@@ -20,6 +25,10 @@ struct csgn_comm {
     hipStream_t stream = nullptr;
     int rank = 0, world = 1, device = 0;
     int *d_flag = nullptr;          // 1-element buffer of the barrier all-reduce
+    hipEvent_t done = nullptr;      // marks the end of the barrier's all-reduce (bounded wait)
+    std::atomic<bool> aborted{false};
+    std::atomic<uint64_t> timeout_ms{120000};
+    std::atomic<int> force_grouped{0};
 };
 
 namespace {
@@ -69,6 +78,37 @@ int finish_comm(csgn_comm *c)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&c->d_flag, sizeof(int)));
     HIP_TRY(hipMemset(c->d_flag, 0, sizeof(int)));
+    HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    return CSGN_OK;
+}
+
+// `stream` of the C ABI -> hipStream_t: NULL is the legacy default stream, as everywhere in
+// csgn_hip.h; the communicator's own stream has to be asked for by name.
+inline hipStream_t pick_stream(const csgn_comm *c, void *stream)
+{
+    return stream == CSGN_STREAM_OF_COMM ? c->stream : reinterpret_cast<hipStream_t>(stream);
+}
+
+// One RCCL per process, and the one this file was compiled for: compare the library the dynamic
+// loader really bound with the header's version.
+int check_rccl(unsigned flags)
+{
+    int runtime = 0;
+    NCCL_TRY(ncclGetVersion(&runtime));
+    const int header = NCCL_VERSION_CODE;
+    const int rmaj = runtime / 10000, rmin = (runtime / 100) % 100;
+    const int hmaj = header / 10000, hmin = (header / 100) % 100;
+    Dl_info info;
+    const char *path = (dladdr(reinterpret_cast<void *>(&ncclGetVersion), &info) && info.dli_fname) ? info.dli_fname : "?";
+    if (rmaj != hmaj)
+        return fail(CSGN_ERR_UNSUPPORTED, "RCCL major version mismatch: runtime %d.%d.%d (%s) vs header %d.%d.%d",
+                    rmaj, rmin, runtime % 100, path, hmaj, hmin, header % 100);
+    if (rmin != hmin && !(flags & CSGN_COMM_ALLOW_MINOR_SKEW))
+        return fail(CSGN_ERR_UNSUPPORTED,
+                    "RCCL minor version mismatch: runtime %d.%d.%d (%s) vs header %d.%d.%d; the process bound a "
+                    "different librccl than libcsgn_shard.so was built for (pass CSGN_COMM_ALLOW_MINOR_SKEW to "
+                    "accept the one already mapped)",
+                    rmaj, rmin, runtime % 100, path, hmaj, hmin, header % 100);
     return CSGN_OK;
 }
 
@@ -81,31 +121,49 @@ __global__ void __launch_bounds__(256) k_product_counts(uint64_t batch, const ui
         counts[b] = offL ? (offL[b + 1] - offL[b]) * (offR[b + 1] - offR[b]) : uniform;
 }
 
+int gather_plan(uint64_t total, int world, uint64_t *lo, uint64_t *len, int *equal)
+{
+    REQUIRE(world > 0 && lo && len, "bad gather plan arguments");
+    bool eq = true;
+    for (int r = 0; r < world; ++r) {
+        uint64_t l = 0, h = 0;
+        csgn_shard_range(total, r, world, &l, &h);
+        lo[r] = l;
+        len[r] = h - l;
+        eq = eq && len[r] == len[0];
+    }
+    if (equal)
+        *equal = eq ? 1 : 0;
+    return CSGN_OK;
+}
+
 template <typename T>
 int gather(csgn_comm *c, const T *d_local, uint64_t total, T *d_all, ncclDataType_t dt, void *stream)
 {
     REQUIRE(c && c->nccl, "null communicator");
+    REQUIRE(!c->aborted.load(), "communicator was aborted");
     if (total == 0)
         return CSGN_OK;
     REQUIRE(d_all, "d_all is null");
-    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
-    uint64_t lo = 0, hi = 0;
-    csgn_shard_range(total, c->rank, c->world, &lo, &hi);
-    REQUIRE(d_local || hi == lo, "d_local is null");
-    if (total % (uint64_t)c->world == 0) {
+    hipStream_t s = pick_stream(c, stream);
+    std::vector<uint64_t> lo(c->world), len(c->world);
+    int equal = 0;
+    if (int rc = gather_plan(total, c->world, lo.data(), len.data(), &equal))
+        return rc;
+    REQUIRE(d_local || len[c->rank] == 0, "d_local is null");
+    if (equal && !c->force_grouped.load()) {
         // equal shards: the slices of d_all are exactly the all-gather layout
-        NCCL_TRY(ncclAllGather(d_local, d_all, (size_t)(hi - lo), dt, c->nccl, s));
+        NCCL_TRY(ncclAllGather(d_local, d_all, (size_t)len[c->rank], dt, c->nccl, s));
         return CSGN_OK;
     }
-    // uneven shards: rank r broadcasts its hi_r - lo_r counts into d_all[lo_r..hi_r); one group
+    // uneven shards: rank r broadcasts its len[r] elements into d_all[lo[r] ..); one group.  A rank's own
+    // slice is sent from d_local (out of place); the others receive in place.
     NCCL_TRY(ncclGroupStart());
     for (int r = 0; r < c->world; ++r) {
-        uint64_t rlo = 0, rhi = 0;
-        csgn_shard_range(total, r, c->world, &rlo, &rhi);
-        if (rhi == rlo)
+        if (len[r] == 0)
             continue;
-        const ncclResult_t res = ncclBroadcast(r == c->rank ? (const void *)d_local : (const void *)(d_all + rlo),
-                                               d_all + rlo, (size_t)(rhi - rlo), dt, r, c->nccl, s);
+        const ncclResult_t res = ncclBroadcast(r == c->rank ? (const void *)d_local : (const void *)(d_all + lo[r]),
+                                               d_all + lo[r], (size_t)len[r], dt, r, c->nccl, s);
         if (res != ncclSuccess) {
             (void)ncclGroupEnd();
             return fail(CSGN_ERR_HIP, "ncclBroadcast: %s", ncclGetErrorString(res));
@@ -151,9 +209,37 @@ int csgn_comm_device_count(int *h_count)
     return CSGN_OK;
 }
 
+int csgn_comm_rccl_info(int *h_runtime, int *h_header, char *h_path, size_t cap)
+{
+    int runtime = 0;
+    NCCL_TRY(ncclGetVersion(&runtime));
+    if (h_runtime)
+        *h_runtime = runtime;
+    if (h_header)
+        *h_header = NCCL_VERSION_CODE;
+    if (h_path && cap) {
+        Dl_info info;
+        const char *path = (dladdr(reinterpret_cast<void *>(&ncclGetVersion), &info) && info.dli_fname) ? info.dli_fname : "";
+        snprintf(h_path, cap, "%s", path);
+    }
+    return CSGN_OK;
+}
+
+int csgn_shard_gather_plan(uint64_t total_pairs, int world, uint64_t *h_lo, uint64_t *h_len, int *h_equal)
+{
+    return gather_plan(total_pairs, world, h_lo, h_len, h_equal);
+}
+
 int csgn_comm_init_all(int ndev, const int *devices, csgn_comm **comms)
 {
+    return csgn_comm_init_all_ex(ndev, devices, CSGN_COMM_STRICT, comms);
+}
+
+int csgn_comm_init_all_ex(int ndev, const int *devices, unsigned flags, csgn_comm **comms)
+{
     REQUIRE(comms && ndev > 0, "bad arguments");
+    if (int rc = check_rccl(flags))
+        return rc;
     int have = 0;
     HIP_TRY(hipGetDeviceCount(&have));
     std::vector<int> devs(ndev);
@@ -189,8 +275,16 @@ int csgn_comm_unique_id(unsigned char h_id[CSGN_COMM_ID_BYTES])
 int csgn_comm_init_rank(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
                         csgn_comm **comm)
 {
+    return csgn_comm_init_rank_ex(h_id, rank, world, device, CSGN_COMM_STRICT, comm);
+}
+
+int csgn_comm_init_rank_ex(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
+                           unsigned flags, csgn_comm **comm)
+{
     REQUIRE(h_id && comm, "null argument");
     *comm = nullptr;
+    if (int rc = check_rccl(flags))
+        return rc;
     REQUIRE(world > 0 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
     int have = 0;
     HIP_TRY(hipGetDeviceCount(&have));
@@ -218,15 +312,55 @@ int csgn_comm_destroy(csgn_comm *c)
     if (!c)
         return CSGN_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream)
+    const bool aborted = c->aborted.load();
+    if (c->stream && !aborted)
         (void)hipStreamSynchronize(c->stream);
-    if (c->nccl)
-        (void)ncclCommDestroy(c->nccl);
+    if (c->nccl && !aborted)
+        (void)ncclCommDestroy(c->nccl);         // an aborted communicator was already freed by ncclCommAbort
     if (c->d_flag)
         (void)hipFree(c->d_flag);
+    if (c->done)
+        (void)hipEventDestroy(c->done);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
+    return CSGN_OK;
+}
+
+int csgn_comm_abort(csgn_comm *c)
+{
+    REQUIRE(c, "null communicator");
+    if (c->aborted.exchange(true))
+        return CSGN_OK;                          // once: ncclCommAbort frees the communicator
+    if (c->nccl)
+        NCCL_TRY(ncclCommAbort(c->nccl));
+    return CSGN_OK;
+}
+
+int csgn_comm_check(csgn_comm *c)
+{
+    REQUIRE(c && c->nccl, "null communicator");
+    if (c->aborted.load())
+        return fail(CSGN_ERR_HIP, "communicator was aborted");
+    ncclResult_t async = ncclSuccess;
+    NCCL_TRY(ncclCommGetAsyncError(c->nccl, &async));
+    if (async != ncclSuccess && async != ncclInProgress)
+        return fail(CSGN_ERR_HIP, "RCCL asynchronous error: %s", ncclGetErrorString(async));
+    return CSGN_OK;
+}
+
+int csgn_comm_set_timeout_ms(csgn_comm *c, uint64_t timeout_ms)
+{
+    REQUIRE(c, "null communicator");
+    c->timeout_ms.store(timeout_ms);
+    return CSGN_OK;
+}
+
+int csgn_comm_set_option(csgn_comm *c, int option, int value)
+{
+    REQUIRE(c, "null communicator");
+    REQUIRE(option == CSGN_COMM_OPT_FORCE_GROUPED_BROADCAST, "unknown option %d", option);
+    c->force_grouped.store(value);
     return CSGN_OK;
 }
 
@@ -250,9 +384,38 @@ int csgn_comm_gather_bytes(csgn_comm *c, const uint8_t *d_local, uint64_t total_
 int csgn_comm_barrier(csgn_comm *c, void *stream)
 {
     REQUIRE(c && c->nccl, "null communicator");
-    hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    REQUIRE(!c->aborted.load(), "communicator was aborted");
+    hipStream_t s = pick_stream(c, stream);
     NCCL_TRY(ncclAllReduce(c->d_flag, c->d_flag, 1, ncclInt32, ncclSum, c->nccl, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(c->done, s));
+    // bounded wait: a peer that never arrives must not hold this rank for ever
+    const uint64_t limit = c->timeout_ms.load();
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(c->done);
+        if (q == hipSuccess)
+            break;
+        if (q != hipErrorNotReady)
+            return fail(CSGN_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        if (c->aborted.load())
+            return fail(CSGN_ERR_HIP, "communicator was aborted while waiting in the barrier");
+        if (++spins > 2000) {                    // past the first ~ms: look at the clock and at RCCL, then sleep
+            ncclResult_t async = ncclSuccess;
+            if (ncclCommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                (void)csgn_comm_abort(c);
+                return fail(CSGN_ERR_HIP, "RCCL asynchronous error in the barrier: %s", ncclGetErrorString(async));
+            }
+            const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(
+                                    std::chrono::steady_clock::now() - t0).count();
+            if (limit && ms > limit) {
+                (void)csgn_comm_abort(c);
+                return fail(CSGN_ERR_TIMEOUT, "barrier: rank %d of %d waited %llu ms for its peers; communicator aborted",
+                            c->rank, c->world, (unsigned long long)ms);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
     return CSGN_OK;
 }
 
@@ -266,6 +429,7 @@ int csgn_shard_product_counts(uint64_t batch, const uint64_t *d_off_left, const 
     REQUIRE(batch < (1ull << 40), "batch too large");
     const uint64_t blocks = (batch + 255) / 256;
     REQUIRE(blocks < (1ull << 24), "batch too large for one launch");
+    REQUIRE(stream != CSGN_STREAM_OF_COMM, "csgn_shard_product_counts takes a real stream (no communicator here)");
     k_product_counts<<<(unsigned)blocks, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
         batch, d_off_left, d_off_right, t1 * t2, d_counts);
     HIP_TRY(hipGetLastError());

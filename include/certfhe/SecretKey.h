@@ -23,6 +23,7 @@ using namespace std;
 namespace certFHE {
 
 class CiphertextBatch;
+class ShardedBatch;
 
 class SecretKey {
     uint64_t *s;      // D secret positions in [0, N), in generation order
@@ -36,6 +37,7 @@ class SecretKey {
     void ensureMask() const;
     friend class CiphertextBatch;      // extension (Batch.h): reads the device-resident key mask
     friend class BatchCircuit;         // extension (Batch.h)
+    friend class ShardedBatch;         // extension (ShardedBatch.h): reads the key's Context
 
   public:
     SecretKey() = delete;

@@ -254,6 +254,20 @@ int csgn_encrypt_keyed_layout(uint64_t n_bits, uint32_t *h_units, uint32_t *h_pa
 int csgn_encrypt_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t first_ciphertext,
                        const uint8_t *d_plain, const uint64_t *d_key, const uint64_t *d_mask,
                        const csgn_rng *h_rng, uint64_t *d_out, void *stream);
+/* FUSED FRESH CHAIN (the reference's canonical flow tests/basic_operations.cpp:26-40:
+ * encrypt, encrypt, operator*, decrypt).  For every pair b < batch
+ *     d_out_b = Enc_A(d_plain_a[b]) & Enc_B(d_plain_b[b])          one term, dL words
+ * where Enc_A / Enc_B are EXACTLY the ciphertexts csgn_encrypt_keyed(..., h_rng_a / h_rng_b, ...)
+ * writes for position first_ciphertext + b and & is Ciphertext::defaultN_multiply
+ * (src/Ciphertext.cpp:124-131).  One kernel: both operands live in registers only and the product is
+ * written once -- 8*dL bytes per pair instead of the five HBM passes of encrypt, encrypt, multiply.
+ * d_bits (optional, may be NULL) receives Dec(d_out_b) under the same key, one byte per pair, computed
+ * from the generated words (a 1x1 product decrypts to 1 iff both factors cover the key mask,
+ * src/SecretKey.cpp:82-102).  The two generators must differ in key or nonce. */
+int csgn_encrypt_mul_keyed(uint64_t n_bits, uint64_t d, uint64_t batch, uint64_t first_ciphertext,
+                           const uint8_t *d_plain_a, const uint8_t *d_plain_b, const uint64_t *d_key,
+                           const uint64_t *d_mask, const csgn_rng *h_rng_a, const csgn_rng *h_rng_b,
+                           uint64_t *d_out, uint8_t *d_bits, void *stream);
 /* = csgn_encrypt_keyed with csgn_rng_from_seed(seed, 8 rounds) and first_ciphertext 0: the
  * reproducible test/benchmark form (see csgn_rng_from_seed: NOT for secrets). */
 int csgn_encrypt_device_rng(uint64_t n_bits, uint64_t d, uint64_t batch,

@@ -542,6 +542,82 @@ def test_encrypt_keyed_fuzz(hip, oracle, knobs):
             assert np.array_equal(got, want), (it, n, d, batch, first, rounds, wave, compact)
 
 
+@pytest.mark.parametrize("n,d", KEYED_CONTEXTS)
+@pytest.mark.parametrize("wave", [1, 0])
+def test_fused_fresh_chain_matches_encrypt_encrypt_multiply(hip, oracle, knobs, n, d, wave):
+    """csgn_encrypt_mul_keyed (the reference's flow tests/basic_operations.cpp:26-40 as ONE
+    kernel): the product words equal the restated definition's Enc_A & Enc_B (oracle.encrypt_keyed x2,
+    src/Ciphertext.cpp:124-131), equal csgn_encrypt_keyed x2 + csgn_mul_uniform on the device, and the
+    optional bits equal csgn_decrypt_uniform of the product and b1 & b0.  Windows of the stream that
+    start and end inside a group; small D makes the clear-the-drawn-position rule frequent, in either
+    factor and in both at once."""
+    import torch
+    knobs.set("enc_wave", wave)                              # 1: wave kernel, 0: one lane per pair
+    key = make_key(n, d, 16)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    units, passes, group = oracle.keyed_layout(n)
+    ra, rb = hip.rng_from_seed(300 + n, 8), hip.rng_from_seed(301 + n, 8)
+    (ka, na), (kb, nb) = oracle.rng_from_seed(300 + n), oracle.rng_from_seed(301 + n)
+    prng = np.random.default_rng(d + 1)
+    for first, batch in [(0, 3 * group + 5), (1, 1), (group - 1, 2), (5 * group + 7, 2 * group), (2**33 + 3, group + 9)]:
+        pa = prng.integers(0, 2, batch).astype(np.uint8)
+        pb = prng.integers(0, 2, batch).astype(np.uint8)
+        if d <= 3:
+            pa[: batch // 2] = 0                              # many plaintext-0 operands: the rule fires often
+            pb[batch // 4:] = 0
+        da, db = hip.upload(pa), hip.upload(pb)
+        got, bits = hip.encrypt_mul_keyed(n, d, da, db, dkey, dmask, ra, rb, first_ciphertext=first)
+        wa = oracle.encrypt_keyed(n, key, pa, ka, na, 8, first_ciphertext=first)
+        wb = oracle.encrypt_keyed(n, key, pb, kb, nb, 8, first_ciphertext=first)
+        assert np.array_equal(hip.download(got), wa & wb), (n, d, wave, first, batch)
+        ea = hip.encrypt_keyed(n, d, da, dkey, dmask, ra, first_ciphertext=first)
+        eb = hip.encrypt_keyed(n, d, db, dkey, dmask, rb, first_ciphertext=first)
+        unfused = hip.mul_uniform(n, batch, 1, 1, ea, eb)
+        assert torch.equal(got, unfused)
+        want_bits = hip.download(hip.decrypt_uniform(n, batch, 1, unfused, dmask))
+        assert np.array_equal(hip.download(bits), want_bits), (n, d, wave, first, batch)
+        if len(set(int(k) for k in key)) > 1:
+            assert np.array_equal(want_bits, pa & pb)
+        # bits are optional
+        got2, none = hip.encrypt_mul_keyed(n, d, da, db, dkey, dmask, ra, rb, first_ciphertext=first, with_bits=False)
+        assert none is None and torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("rounds", [8, 20])
+def test_fused_fresh_chain_a_million_pairs(hip, oracle, rounds):
+    """BASELINE config 4's shape on one GPU: 1 M fresh pairs at N=1247 in one kernel; digest of the products
+    equal to the restated definition's, bits equal b1 & b0 (about 16 of the 2 M operands hit the
+    clear-the-drawn-position rule)."""
+    n, d = 1247, 16
+    batch = (1 << 20) if rounds == 8 else (1 << 16)
+    key = make_key(n, d, 3)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    prng = np.random.default_rng(rounds)
+    pa, pb = prng.integers(0, 2, batch).astype(np.uint8), prng.integers(0, 2, batch).astype(np.uint8)
+    ra, rb = hip.rng_from_seed(5, rounds), hip.rng_from_seed(6, rounds)
+    (ka, na), (kb, nb) = oracle.rng_from_seed(5), oracle.rng_from_seed(6)
+    got, bits = hip.encrypt_mul_keyed(n, d, hip.upload(pa), hip.upload(pb), dkey, dmask, ra, rb, first_ciphertext=999)
+    wa = oracle.encrypt_keyed(n, key, pa, ka, na, rounds, first_ciphertext=999)
+    wb = oracle.encrypt_keyed(n, key, pb, kb, nb, rounds, first_ciphertext=999)
+    assert hip.digest(got) == oracle.digest(wa & wb)
+    assert np.array_equal(hip.download(bits), pa & pb)
+
+
+def test_fused_fresh_chain_argument_checks(hip):
+    from csgn_amd import capi
+    n, d = 1247, 16
+    key = make_key(n, d, 1)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    plain = hip.upload(np.ones(8, dtype=np.uint8))
+    ra = hip.rng_from_seed(1, 8)
+    with pytest.raises(capi.CsgnError, match="different streams"):
+        hip.encrypt_mul_keyed(n, d, plain, plain, dkey, dmask, ra, ra)          # the same stream twice
+    with pytest.raises(capi.CsgnError, match="same number of rounds"):
+        hip.encrypt_mul_keyed(n, d, plain, plain, dkey, dmask, ra, hip.rng_from_seed(2, 12))
+    out, bits = hip.encrypt_mul_keyed(n, d, plain[:0], plain[:0], dkey, dmask, ra, hip.rng_from_seed(2, 8))
+    assert out.numel() == 0
+
+
 def test_encrypt_keyed_os_entropy_and_argument_checks(hip, oracle):
     import ctypes as C
     from csgn_amd import capi

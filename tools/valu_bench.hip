@@ -1,0 +1,356 @@
+// valu_bench.hip -- what does the CDNA4 (gfx950) VALU issue per SIMD for the integer instructions the
+// keyed encrypt (ChaCha: v_add_u32 / v_xor_b32 / v_alignbit_b32) and the permutation are made of?
+//
+//   hipcc --offload-arch=gfx950 -O2 -o tools/bin/valu_bench tools/valu_bench.hip
+//   tools/bin/valu_bench > profiles/r03/valu_issue.txt
+//
+// For each instruction (and for the real ChaCha double round) a kernel runs a long register-only loop
+// of `ILP` independent dependency chains (ILP = 1: every instruction waits for the one before it)
+// on every CU, at 1, 2, 4 and 8 waves per SIMD.  It reports wave-instructions per second for the
+// whole chip and, with the in-kernel clock (s_memtime / s_memrealtime, 100 MHz real-time counter),
+// cycles per wave-instruction per SIMD.  2.0 = the SIMD-32 rate for wave64, 4.0 = the cost of one
+// wave issuing alone (guide: MI355X_MICROARCH.md, per-instruction cycle constants).
+// Register-only: no memory traffic inside the timed loop, so the HBM plays no part.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x)                                                                         \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+
+enum Op { OP_ADD = 0, OP_XOR = 1, OP_ALIGNBIT = 2, OP_CHACHA = 3, OP_CHACHA2 = 4, OP_MIX = 5 };
+
+struct Stamp {
+    unsigned long long cyc, rt;
+};
+
+__device__ inline unsigned rotl32(unsigned x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+
+#define QR(a, b, c, d)                 \
+    a += b; d ^= a; d = rotl32(d, 16); \
+    c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  \
+    c += d; b ^= c; b = rotl32(b, 7)
+
+#define DOUBLE_ROUND(x)                 \
+    QR(x[0], x[4], x[8], x[12]);        \
+    QR(x[1], x[5], x[9], x[13]);        \
+    QR(x[2], x[6], x[10], x[14]);       \
+    QR(x[3], x[7], x[11], x[15]);       \
+    QR(x[0], x[5], x[10], x[15]);       \
+    QR(x[1], x[6], x[11], x[12]);       \
+    QR(x[2], x[7], x[8], x[13]);        \
+    QR(x[3], x[4], x[9], x[14])
+
+// ILP independent chains of ONE instruction; 64 instructions per loop trip (64/ILP per chain), all in
+// ONE asm statement (between separate asm statements hipcc pads with s_nop, which costs issue slots).
+#define I1(OPS, a) OPS(a)
+#define REP16_1(OPS) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0) OPS(0)
+#define REP16_4(OPS) OPS(0) OPS(1) OPS(2) OPS(3) OPS(0) OPS(1) OPS(2) OPS(3) OPS(0) OPS(1) OPS(2) OPS(3) OPS(0) OPS(1) OPS(2) OPS(3)
+#define REP16_8(OPS) OPS(0) OPS(1) OPS(2) OPS(3) OPS(4) OPS(5) OPS(6) OPS(7) OPS(0) OPS(1) OPS(2) OPS(3) OPS(4) OPS(5) OPS(6) OPS(7)
+#define S_ADD(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define S_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define S_ROT(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
+#define BODY64(REP, OPS)                                                                                     \
+    asm volatile(REP(OPS) REP(OPS) REP(OPS) REP(OPS)                                                         \
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
+                 : "v"(k))
+
+template <int OP, int ILP>
+__global__ void __launch_bounds__(1024) k_chain(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];      // only there to pin the number of workgroups per CU
+    unsigned r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r[i] = seed * (threadIdx.x + 1u) + (unsigned)i * 0x9E3779B9u;
+    unsigned k = seed | 1u;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; ++t) {
+        if (OP == OP_ADD) {
+            if (ILP == 1) BODY64(REP16_1, S_ADD); else if (ILP == 4) BODY64(REP16_4, S_ADD); else BODY64(REP16_8, S_ADD);
+        } else if (OP == OP_XOR) {
+            if (ILP == 1) BODY64(REP16_1, S_XOR); else if (ILP == 4) BODY64(REP16_4, S_XOR); else BODY64(REP16_8, S_XOR);
+        } else {
+            if (ILP == 1) BODY64(REP16_1, S_ROT); else if (ILP == 4) BODY64(REP16_4, S_ROT); else BODY64(REP16_8, S_ROT);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        acc ^= r[i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
+// The ChaCha double round as the compiler schedules it (BLOCKS = 1: four independent quarter rounds
+// at a time, ILP 4; BLOCKS = 2: two blocks per lane interleaved, ILP 8).  96 instructions per
+// double round and block.
+template <int BLOCKS>
+__global__ void __launch_bounds__(1024) k_chacha(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];
+    unsigned x[BLOCKS][16];
+#pragma unroll
+    for (int b = 0; b < BLOCKS; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            x[b][i] = seed * (threadIdx.x + 1u) + (unsigned)(b * 16 + i) * 0x9E3779B9u;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int b = 0; b < BLOCKS; ++b) {
+            DOUBLE_ROUND(x[b]);
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = 0;
+#pragma unroll
+    for (int b = 0; b < BLOCKS; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc ^= x[b][i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
+
+// Other instructions and mixes, 8 independent chains (registers %0..%7, %8 = a constant VGPR): what is
+// the rate of the 64-bit ENCODINGS (VOP3, VOP2 + literal, SDWA, DPP) against the 32-bit ones, and what
+// does a stream that alternates them issue at?  PAT(i) expands to the instruction(s) for register i.
+#define REP8(PAT) PAT(0) PAT(1) PAT(2) PAT(3) PAT(4) PAT(5) PAT(6) PAT(7)
+#define P_ADD_E64(i) "v_add_u32_e64 %" #i ", %" #i ", %8\n"
+#define P_ADD_LIT(i) "v_add_u32 %" #i ", 0x12345678, %" #i "\n"
+#define P_PERM(i) "v_perm_b32 %" #i ", %" #i ", %" #i ", %8\n"
+#define P_ALIGNBYTE(i) "v_alignbyte_b32 %" #i ", %" #i ", %" #i ", 1\n"
+#define P_LSHL_OR(i) "v_lshl_or_b32 %" #i ", %" #i ", 3, %8\n"
+#define P_XAD(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
+#define P_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %8\n"
+#define P_BFI(i) "v_bfi_b32 %" #i ", %8, %" #i ", %" #i "\n"
+#define P_LSHL(i) "v_lshlrev_b32 %" #i ", 7, %" #i "\n"
+#define P_XOR_SDWA(i) "v_xor_b32_sdwa %" #i ", %" #i ", %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define P_MOV_DPP(i) "v_mov_b32_dpp %" #i ", %" #i " row_ror:1 row_mask:0xf bank_mask:0xf\n"
+#define P_PK_ADD16(i) "v_pk_add_u16 %" #i ", %" #i ", %8\n"
+#define P_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define P_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n"
+#define P_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define P_AXR(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\nv_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
+#define P_AX(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\n"
+#define P_AR(i) "v_add_u32 %" #i ", %" #i ", %8\nv_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
+#define P_AAR(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %8\nv_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
+#define P_ROT2(i) "v_lshrrev_b32 %9, 25, %" #i "\nv_lshl_or_b32 %" #i ", %" #i ", 7, %9\n"
+#define P_AX_PERM(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\nv_perm_b32 %" #i ", %" #i ", %" #i ", %8\n"
+#define P_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %8 bitop3:0x96\n"
+
+enum Pat { PT_ADD_E64, PT_ADD_LIT, PT_PERM, PT_ALIGNBYTE, PT_LSHL_OR, PT_XAD, PT_ADD3, PT_BFI, PT_LSHL, PT_XOR_SDWA,
+           PT_MOV_DPP, PT_PK_ADD16, PT_MUL24, PT_MAD24, PT_MULLO, PT_AXR, PT_AX, PT_AR, PT_AAR, PT_ROT2, PT_AX_PERM,
+           PT_BITOP3 };
+
+#define PBODY(PAT, N)                                                                                        \
+    asm volatile(N(PAT)                                                                                      \
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
+                 : "v"(k), "v"(tmp))
+#define X8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT)
+#define X4(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT)
+#define X2(PAT) REP8(PAT) REP8(PAT)
+
+template <int PT>
+__global__ void __launch_bounds__(1024) k_pattern(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];
+    unsigned r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r[i] = seed * (threadIdx.x + 1u) + (unsigned)i * 0x9E3779B9u;
+    unsigned k = seed | 0x01020301u, tmp = 0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; ++t) {
+        // every body is 64 instructions
+        if (PT == PT_ADD_E64) PBODY(P_ADD_E64, X8);
+        else if (PT == PT_ADD_LIT) PBODY(P_ADD_LIT, X8);
+        else if (PT == PT_PERM) PBODY(P_PERM, X8);
+        else if (PT == PT_ALIGNBYTE) PBODY(P_ALIGNBYTE, X8);
+        else if (PT == PT_LSHL_OR) PBODY(P_LSHL_OR, X8);
+        else if (PT == PT_XAD) PBODY(P_XAD, X8);
+        else if (PT == PT_ADD3) PBODY(P_ADD3, X8);
+        else if (PT == PT_BFI) PBODY(P_BFI, X8);
+        else if (PT == PT_LSHL) PBODY(P_LSHL, X8);
+        else if (PT == PT_XOR_SDWA) PBODY(P_XOR_SDWA, X8);
+        else if (PT == PT_MOV_DPP) PBODY(P_MOV_DPP, X8);
+        else if (PT == PT_PK_ADD16) PBODY(P_PK_ADD16, X8);
+        else if (PT == PT_MUL24) PBODY(P_MUL24, X8);
+        else if (PT == PT_MAD24) PBODY(P_MAD24, X8);
+        else if (PT == PT_MULLO) PBODY(P_MULLO, X8);
+        else if (PT == PT_AX) PBODY(P_AX, X4);
+        else if (PT == PT_AR) PBODY(P_AR, X4);
+        else if (PT == PT_ROT2) PBODY(P_ROT2, X4);
+        else if (PT == PT_AAR) PBODY(P_AAR, X2);
+        else if (PT == PT_BITOP3) PBODY(P_BITOP3, X8);
+        else if (PT == PT_AXR) { PBODY(P_AXR, X2); PBODY(P_AX, REP8); }          // 48 + 16
+        else if (PT == PT_AX_PERM) { PBODY(P_AX_PERM, X2); PBODY(P_AX, REP8); }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = tmp;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        acc ^= r[i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
+struct Result {
+    double ginstr_s, cyc_per_instr_simd, clock_ghz, ms;
+};
+
+template <typename Launch>
+static Result run(const void *func, Launch launch, int waves_per_simd, double instr_per_trip, int trips, int cus, unsigned *d_out,
+                  Stamp *d_stamps)
+{
+    // waves per SIMD w: w <= 4 -> one workgroup of 256*w threads per CU; w = 8 -> two of 1024.
+    const int threads = waves_per_simd <= 4 ? 256 * waves_per_simd : 1024;
+    const int wg_per_cu = waves_per_simd <= 4 ? 1 : 2;
+    const size_t lds = wg_per_cu == 1 ? 96 * 1024 : 64 * 1024;     // 160 KB per CU: pins wg_per_cu
+    const int grid = cus * wg_per_cu;
+    CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    launch(grid, threads, lds, trips / 8 + 1);                     // warm-up
+    CHECK(hipDeviceSynchronize());
+    std::vector<double> ms_all;
+    std::vector<Stamp> st((size_t)grid * threads / 64);
+    double clock = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        launch(grid, threads, lds, trips);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms_all.push_back(ms);
+    }
+    CHECK(hipMemcpy(st.data(), d_stamps, st.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
+    std::vector<double> clk;
+    for (auto &s : st)
+        if (s.rt)
+            clk.push_back((double)s.cyc / (double)s.rt * 0.1);     // 100 MHz real-time counter -> GHz
+    std::sort(clk.begin(), clk.end());
+    clock = clk.empty() ? 0 : clk[clk.size() / 2];
+    std::sort(ms_all.begin(), ms_all.end());
+    const double ms = ms_all[ms_all.size() / 2];
+    const double waves = (double)grid * threads / 64.0;
+    const double instr = waves * instr_per_trip * trips;
+    Result r;
+    r.ms = ms;
+    r.ginstr_s = instr / (ms * 1e-3) / 1e9;
+    r.clock_ghz = clock;
+    // per SIMD: instructions issued per second / (SIMDs) -> cycles per instruction = clock / rate
+    const double per_simd = instr / (ms * 1e-3) / ((double)cus * 4.0);
+    r.cyc_per_instr_simd = clock * 1e9 / per_simd;
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+    return r;
+}
+
+int main(int argc, char **argv)
+{
+    int dev = 0, cus = 256;
+    CHECK(hipSetDevice(dev));
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, dev));
+    printf("# device %s, %d CUs, clockRate %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
+    unsigned *d_out;
+    Stamp *d_stamps;
+    CHECK(hipMalloc(&d_out, (size_t)cus * 2 * 1024 * sizeof(unsigned)));
+    CHECK(hipMalloc(&d_stamps, (size_t)cus * 2 * 16 * sizeof(Stamp)));
+    const int trips = argc > 1 ? atoi(argv[1]) : 40000;            // 64 instr per trip -> 2.56 M instr per wave
+    printf("# %-22s %5s %8s %12s %10s %12s\n", "stream", "w/SIMD", "ms", "Gwave-instr/s", "clock GHz",
+           "cyc/instr/SIMD");
+    const int wlist[4] = {1, 2, 4, 8};
+#define RUN_CHAIN(OP, ILP, NAME)                                                                              \
+    for (int w : wlist) {                                                                                     \
+        Result r = run((const void *)k_chain<OP, ILP>, [&](int g, int t, size_t l, int tr) {                  \
+            hipLaunchKernelGGL((k_chain<OP, ILP>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);      \
+        }, w, 64.0, trips, cus, d_out, d_stamps);                                                             \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_CHAIN(OP_ADD, 1, "v_add_u32 chain1")
+    RUN_CHAIN(OP_ADD, 4, "v_add_u32 chain4")
+    RUN_CHAIN(OP_ADD, 8, "v_add_u32 indep8")
+    RUN_CHAIN(OP_XOR, 1, "v_xor_b32 chain1")
+    RUN_CHAIN(OP_XOR, 4, "v_xor_b32 chain4")
+    RUN_CHAIN(OP_XOR, 8, "v_xor_b32 indep8")
+    RUN_CHAIN(OP_ALIGNBIT, 1, "v_alignbit_b32 chain1")
+    RUN_CHAIN(OP_ALIGNBIT, 4, "v_alignbit_b32 chain4")
+    RUN_CHAIN(OP_ALIGNBIT, 8, "v_alignbit_b32 indep8")
+#define RUN_CHACHA(B, NAME)                                                                                   \
+    for (int w : wlist) {                                                                                     \
+        Result r = run((const void *)k_chacha<B>, [&](int g, int t, size_t l, int tr) {                       \
+            hipLaunchKernelGGL((k_chacha<B>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);           \
+        }, w, 96.0 * B, trips / (2 * B) + 1, cus, d_out, d_stamps);                                           \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_CHACHA(1, "chacha dround 1 blk")
+    RUN_CHACHA(2, "chacha dround 2 blk")
+#define RUN_PAT(PT, NAME)                                                                                    \
+    for (int w : {1, 4, 8}) {                                                                                 \
+        Result r = run((const void *)k_pattern<PT>, [&](int g, int t, size_t l, int tr) {                     \
+            hipLaunchKernelGGL((k_pattern<PT>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);         \
+        }, w, 64.0, trips / 2, cus, d_out, d_stamps);                                                         \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_PAT(PT_ADD_E64, "v_add_u32_e64 (VOP3)")
+    RUN_PAT(PT_ADD_LIT, "v_add_u32 +literal")
+    RUN_PAT(PT_LSHL, "v_lshlrev_b32")
+    RUN_PAT(PT_PERM, "v_perm_b32")
+    RUN_PAT(PT_ALIGNBYTE, "v_alignbyte_b32")
+    RUN_PAT(PT_LSHL_OR, "v_lshl_or_b32")
+    RUN_PAT(PT_XAD, "v_xad_u32")
+    RUN_PAT(PT_ADD3, "v_add3_u32")
+    RUN_PAT(PT_BFI, "v_bfi_b32")
+    RUN_PAT(PT_BITOP3, "v_bitop3_b32")
+    RUN_PAT(PT_XOR_SDWA, "v_xor_b32_sdwa")
+    RUN_PAT(PT_MOV_DPP, "v_mov_b32_dpp row_ror")
+    RUN_PAT(PT_PK_ADD16, "v_pk_add_u16")
+    RUN_PAT(PT_MUL24, "v_mul_u32_u24")
+    RUN_PAT(PT_MAD24, "v_mad_u32_u24")
+    RUN_PAT(PT_MULLO, "v_mul_lo_u32")
+    RUN_PAT(PT_AX, "mix add,xor")
+    RUN_PAT(PT_AR, "mix add,alignbit")
+    RUN_PAT(PT_AAR, "mix add,xor,add,alignbit")
+    RUN_PAT(PT_AXR, "mix add,xor,alignbit")
+    RUN_PAT(PT_AX_PERM, "mix add,xor,perm")
+    RUN_PAT(PT_ROT2, "rot = lshr + lshl_or")
+    CHECK(hipFree(d_out));
+    CHECK(hipFree(d_stamps));
+    return 0;
+}
