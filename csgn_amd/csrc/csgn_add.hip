@@ -2,11 +2,22 @@
 // Hand-written CDNA4 (gfx950) HIP; shared helpers in csgn_device.h, design notes in DESIGN.md.
 #include "csgn_device.h"
 
+#include <algorithm>
+
 namespace csgn {
 
 namespace {
 
-template <typename Unit, int C>
+// Ragged add (CSR offsets): out_b = L_b || R_b (src/Ciphertext.cpp:107-122, no XOR, no de-duplication).
+// Same skeleton as the ragged multiply (csgn_mul.hip, k_mul_ragged_flat): the grid covers the flattened
+// output, a workgroup owns C consecutive 4 KiB chunks and takes them M at a time; its first pair comes
+// from a 64-ary wave search; per turn it bets on the pair it was in (scalar offset loads) and, when that
+// pair does not own the whole turn, stages the offsets of the next 256 pairs in LDS with one coalesced
+// load per thread and array, where every lane finds its pair by an LDS binary search.  offOut = offL +
+// offR, so two windows suffice.
+constexpr u32 kAddWin = 256;
+
+template <typename Unit, int C, int M>
 __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R,
@@ -15,39 +26,98 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
                                                          const u64 *__restrict__ offOut, u32 batch,
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU)
 {
+    static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
+    __shared__ u64 w_l[kAddWin + 2], w_r[kAddWin + 2];
+    __shared__ u32 s_next;
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const u64 g_begin = unit_base + (u64)bid * (256u * C);
     if (g_begin >= total_units)
         return;
     const u64 term0 = g_begin / U;
     const u32 r0blk = (u32)(g_begin - term0 * U);
-    u32 pw = csr_find(offOut, 0u, batch, term0);
+    u32 pw = wave_find(offOut, 0u, batch, term0);               // the same answer in every wave
 #pragma unroll 1
-    for (int c = 0; c < C; ++c) {
-        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
-        if (g_begin + (u32)c * 256u >= total_units)
+    for (int c0 = 0; c0 < C; c0 += M) {
+        if (g_begin + (u32)c0 * 256u >= total_units)
             break;
-        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
-        const u32 dt = csgn_fastdiv(r, dU);
-        const u64 term = term0 + dt;
-        const u32 k = r - dt * U;
-        u32 p = pw;
-        if (g < total_units) {
-            // bet on the pair the wave was in (as k_mul_ragged_flat): its offsets are wave-uniform scalar
-            // loads that arrive in one round trip with the end-of-pair test; lanes beyond it walk on
-            const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_r0 = offR[pw], s_r1 = offR[pw + 1];
-            u64 l0 = s_l0, rr0 = s_r0, t1 = s_l1 - s_l0;
-            if (term >= s_l1 + s_r1) {                          // offOut[pw + 1] = offL[pw + 1] + offR[pw + 1]
-                p = csr_gallop(offOut, pw, batch, term);
-                l0 = offL[p];
-                rr0 = offR[p];
-                t1 = offL[p + 1] - l0;
+        const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_r0 = offR[pw], s_r1 = offR[pw + 1];
+        const u64 s_o1 = s_l1 + s_r1;                           // offOut[pw + 1]
+        const u64 turn_end = min(g_begin + (u64)(c0 + M) * 256u, total_units);
+        const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
+        const bool whole = last_term < s_o1;                    // workgroup-uniform
+        if (!whole) {
+            const u32 i = threadIdx.x;
+            const u32 pi = min(pw + i, batch);
+            w_l[i] = offL[pi];
+            w_r[i] = offR[pi];
+            if (i < 2u) {
+                const u32 pe = min(pw + kAddWin + i, batch);
+                w_l[kAddWin + i] = offL[pe];
+                w_r[kAddWin + i] = offR[pe];
             }
-            const u64 q = term - (l0 + rr0);                    // offOut[p] = l0 + rr0
-            const Unit v = (q < t1) ? L[(l0 + q) * U + k] : R[(rr0 + (q - t1)) * U + k];
-            unit_store<Unit, true>(out + g, v);
+            __syncthreads();
         }
-        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);
+        u32 p[M];
+        u64 src[M];                                             // unit index into L (from_l) or R
+        bool from_l[M], live[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int c = c0 + m;
+            const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
+            live[m] = g < total_units;
+            // lanes past the end (last workgroup only) redo the LAST unit: their loads stay unconditional
+            // and in range whichever of L and R is empty; they store nothing
+            const u32 back = live[m] ? 0u : (u32)(g - (total_units - 1u));
+            const u32 r = r0blk + (u32)c * 256u + threadIdx.x - back;
+            const u32 dt = csgn_fastdiv(r, dU);
+            const u64 term = term0 + dt;
+            const u32 k = r - dt * U;
+            p[m] = pw;
+            src[m] = 0;
+            from_l[m] = true;
+            {
+                u64 l0 = s_l0, rr0 = s_r0, t1 = s_l1 - s_l0;
+                if (!whole && term >= s_o1) {
+                    // largest j in [0, kAddWin] with w_l[j] + w_r[j] <= term
+                    u32 lo = 0, hi = kAddWin + 1u;
+#pragma unroll
+                    for (int step = 0; step < 9; ++step) {
+                        const u32 mid = (lo + hi) >> 1;
+                        const bool le = w_l[mid] + w_r[mid] <= term;
+                        lo = le ? mid : lo;
+                        hi = le ? hi : mid;
+                    }
+                    if (lo == kAddWin && pw + kAddWin < batch) { // beyond the window (long runs of empty pairs)
+                        p[m] = csr_gallop(offOut, pw + kAddWin, batch, term);
+                        l0 = offL[p[m]];
+                        rr0 = offR[p[m]];
+                        t1 = offL[p[m] + 1] - l0;
+                    } else {
+                        p[m] = pw + lo;
+                        l0 = w_l[lo];
+                        rr0 = w_r[lo];
+                        t1 = w_l[lo + 1] - l0;
+                    }
+                }
+                const u64 q = term - (l0 + rr0);                // offOut[p] = l0 + rr0
+                from_l[m] = q < t1;
+                src[m] = from_l[m] ? (l0 + q) * U + k : (rr0 + (q - t1)) * U + k;
+            }
+        }
+        Unit v[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            v[m] = from_l[m] ? L[src[m]] : R[src[m]];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            if (live[m])
+                unit_store<Unit, true>(out + g_begin + (u32)(c0 + m) * 256u + threadIdx.x, v[m]);
+        if (!whole) {
+            if (threadIdx.x == 255u)
+                s_next = p[M - 1];
+            __syncthreads();
+            pw = s_next;
+        }
     }
 }
 
@@ -130,20 +200,32 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u32 U = (u32)(wide ? dL / 2 : dL);
     const u64 total_units = total_terms_out * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    const int chunks = ragged_chunks(total_units);
+    // at most 4 chunks per workgroup unless the knob says otherwise (as the ragged multiply: with the
+    // 64-ary start-up search more chunks only coarsen the write front); M = min(4, C) chunks per turn
+    const int chunks = csgn::tune(TUNE_RAGGED_C) ? ragged_chunks(total_units) : std::min(4, ragged_chunks(total_units));
+    const int turn = csgn::tune(TUNE_RAGGED_M);
     const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
     for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {
         const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
         const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
-#define CSGN_RAGGED_LAUNCH(CH)                                                                      \
+#define CSGN_RAGGED_ADD(CH, MM)                                                                     \
     do {                                                                                            \
         if (wide)                                                                                   \
-            k_add_ragged_flat<unit16, CH><<<blocks, 256, 0, s>>>(                                  \
+            k_add_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                              \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
                 reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU);           \
         else                                                                                        \
-            k_add_ragged_flat<unit8, CH><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,     \
-                                                                (u32)batch, u0, u0 + nu, U, dU);    \
+            k_add_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, \
+                                                                    (u32)batch, u0, u0 + nu, U, dU); \
+    } while (0)
+#define CSGN_RAGGED_LAUNCH(CH)                                   \
+    do {                                                         \
+        if (turn >= 4 && (CH) % 4 == 0)                          \
+            CSGN_RAGGED_ADD(CH, ((CH) % 4 == 0 ? 4 : 1));        \
+        else if (turn >= 2 && (CH) % 2 == 0)                     \
+            CSGN_RAGGED_ADD(CH, ((CH) % 2 == 0 ? 2 : 1));        \
+        else                                                     \
+            CSGN_RAGGED_ADD(CH, 1);                              \
     } while (0)
         switch (chunks) {
         case 1: CSGN_RAGGED_LAUNCH(1); break;
@@ -153,6 +235,7 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         default: CSGN_RAGGED_LAUNCH(8); break;
         }
 #undef CSGN_RAGGED_LAUNCH
+#undef CSGN_RAGGED_ADD
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess)
             return le;

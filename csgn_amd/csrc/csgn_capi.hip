@@ -59,6 +59,48 @@ bool product_below(uint64_t a, uint64_t b, uint64_t c, uint64_t limit)
     return abc < limit;
 }
 
+// ChaCha20 block on the host (D. J. Bernstein's function, 64-bit counter / 64-bit nonce layout) with
+// caller-chosen constant words: only used to derive a circuit encrypt node's key.
+void host_chacha20(const uint32_t sigma[4], const uint32_t key[8], uint64_t nonce, uint64_t counter, uint32_t out[16])
+{
+    uint32_t in[16], x[16];
+    for (int i = 0; i < 4; ++i)
+        in[i] = sigma[i];
+    for (int i = 0; i < 8; ++i)
+        in[4 + i] = key[i];
+    in[12] = (uint32_t)counter;
+    in[13] = (uint32_t)(counter >> 32);
+    in[14] = (uint32_t)nonce;
+    in[15] = (uint32_t)(nonce >> 32);
+    memcpy(x, in, sizeof(x));
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12);
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+    };
+    for (int r = 0; r < 20; r += 2) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; ++i)
+        out[i] = x[i] + in[i];
+}
+
+// key of a circuit's encrypt node = words 0..7 of ChaCha20(constants "csgn node key v1", key, nonce, counter 0)
+void node_key_from(const csgn_rng &rng, uint32_t node_key[8])
+{
+    static const uint32_t sigma[4] = {0x6e677363u, 0x646f6e20u, 0x656b2065u, 0x31762079u};   // "csgn node key v1"
+    uint32_t block[16];
+    host_chacha20(sigma, rng.key, rng.nonce, 0, block);
+    for (int i = 0; i < 8; ++i)
+        node_key[i] = block[i];
+    volatile uint32_t *wipe = block;
+    for (int i = 0; i < 16; ++i)
+        wipe[i] = 0;
+}
+
 // Shape limits shared by every compute entry point.
 int check_n(uint64_t n_bits)
 {
@@ -983,13 +1025,25 @@ int csgn_circuit_encrypt(csgn_circuit *c, uint64_t d, const uint8_t *d_plain, co
     op.key = d_key;
     op.d = d;
     op.first = first_ciphertext;
+    // The node encrypts under its OWN key, derived here from (h_rng->key, h_rng->nonce), and uses the
+    // nonce words for nothing but the run number: run r of the node draws from (node key, nonce = r).
+    // Round 2 added r to the caller's nonce, so run 2 under nonce N was run 1 under N + 1.
     op.rng = *h_rng;
+    node_key_from(*h_rng, op.rng.key);
+    op.rng.nonce = 0;
     c->ops.push_back(op);
     *value = out;
     return CSGN_OK;
 }
 
 uint64_t csgn_circuit_epoch(const csgn_circuit *c) { return c ? c->runs : 0; }
+
+int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8])
+{
+    REQUIRE(h_rng && h_node_key, "null argument");
+    node_key_from(*h_rng, h_node_key);
+    return CSGN_OK;
+}
 
 int csgn_circuit_build(csgn_circuit *c)
 {
@@ -1039,7 +1093,7 @@ int csgn_circuit_build(csgn_circuit *c)
     }
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess && c->has_encrypt)
-        e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under nonce + its own run number
+        e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under (node key, nonce = its own run number)
     for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
         const csgn_circuit::Op &op = c->ops[i];
         if (op.kind == 4) {

@@ -127,14 +127,27 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
 // decrypt, pass 2: XOR over the terms of each ciphertext = parity of the popcount of its
 // bit range (src/SecretKey.cpp:139, `_dec = (dec + _dec) % 2`).  G lanes per ciphertext:
 // 1 for small term counts, a whole wave (with a __ballot/__popcll fold) for large ones.
-// MODE 0: every ciphertext; 1: only those of at most kLongTerms terms, the longer ones are queued
-// for k_hits_parity_long (ragged batches: one huge ciphertext among many small ones costs neither).
+// MODE 0: every ciphertext; 1 (ragged batches): only those of at most kLongTerms terms; a longer one
+// gets a slot (its index, a parity word) and one work-list entry per 65 536-term chunk of its bit
+// range, which k_hits_parity_chunks folds -- one huge ciphertext among many small ones costs neither
+// a wave per small one nor one lonely workgroup for the big one (round 2: a single workgroup walked
+// the 128 KB bitmap of a 1 M-term ciphertext, 3.1 TB/s for the batch).
 constexpr u64 kLongTerms = 4096;
+constexpr u64 kChunkTerms = 65536;
+
+// work area of the ragged pass 2 (after the hit bitmap): [n_long, n_entries, pad, pad][slot -> ciphertext:
+// max_long u32][slot parity: max_long u32][entries: (slot << 32) | chunk, max_entries u64]
+struct LongWork {
+    u32 *counters;
+    u32 *slot_ct;
+    u32 *slot_par;
+    u64 *entries;
+};
 
 template <int G, int MODE>
 __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hits,
                                                      const u64 *__restrict__ off, u64 T, u64 batch,
-                                                     uint8_t *__restrict__ bits, u32 *__restrict__ work)
+                                                     uint8_t *__restrict__ bits, LongWork work)
 {
     const u64 gid = (u64)blockIdx.x * 256u + threadIdx.x;
     const u64 b = gid / G;
@@ -144,7 +157,13 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
     const u64 s = off ? off[b] : b * T;
     const u64 e = off ? off[b + 1] : s + T;
     if (MODE == 1 && e - s > kLongTerms) {
-        work[1u + atomicAdd(work, 1u)] = (u32)b;    // left to k_hits_parity_long: work = [count][indices]
+        const u32 slot = atomicAdd(work.counters, 1u);
+        work.slot_ct[slot] = (u32)b;
+        work.slot_par[slot] = 0;
+        const u32 nch = (u32)((e - s + kChunkTerms - 1) / kChunkTerms);
+        const u32 base = atomicAdd(work.counters + 1, nch);
+        for (u32 c = 0; c < nch; ++c)
+            work.entries[base + c] = ((u64)slot << 32) | c;
         return;
     }
     u32 par = 0;
@@ -168,41 +187,49 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
     }
 }
 
-// decrypt, pass 2 of a ragged batch, the long ciphertexts: one workgroup per work-list entry (the
-// list is filled by the lane-per-ciphertext pass above), workgroups stride over the list, so a
-// batch of a million short ciphertexts does not pay for a million idle waves.
-__global__ void __launch_bounds__(256) k_hits_parity_long(const u64 *__restrict__ hits,
-                                                          const u64 *__restrict__ off,
-                                                          const u32 *__restrict__ work,
-                                                          uint8_t *__restrict__ bits)
+// The long ciphertexts of a ragged batch, chunk by chunk: workgroups stride over the work list (its
+// length is on the device), fold 1024 bitmap words each (four independent loads per lane) and XOR one
+// bit into the ciphertext's slot.
+__global__ void __launch_bounds__(256) k_hits_parity_chunks(const u64 *__restrict__ hits,
+                                                            const u64 *__restrict__ off, LongWork work)
 {
-    __shared__ u32 odd_waves;
-    const u32 lane = threadIdx.x & (kWave - 1);
-    const u32 n = work[0];
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {      // one workgroup per queued ciphertext
-        if (threadIdx.x == 0)
-            odd_waves = 0;
-        __syncthreads();
-        const u32 b = work[1u + i];
+    __shared__ u32 wave_par[4];
+    const u32 n = work.counters[1];
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u64 ent = work.entries[i];
+        const u32 slot = (u32)(ent >> 32), c = (u32)ent;
+        const u32 b = work.slot_ct[slot];
         const u64 s = off[b], e = off[b + 1];
-        const u64 w0 = s >> 6, w1 = (e - 1) >> 6;
+        const u64 cs = s + (u64)c * kChunkTerms, ce = min(e, cs + kChunkTerms);
+        const u64 w0 = cs >> 6, w1 = (ce - 1) >> 6;            // at most 1025 words
         u32 par = 0;
-        for (u64 w = w0 + threadIdx.x; w <= w1; w += 256u) {
-            u64 x = hits[w];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const u64 w = w0 + threadIdx.x + (u32)k * 256u;
+            u64 x = hits[min(w, w1)];                           // unconditional: all five in flight
+            if (w > w1)
+                x = 0;
             if (w == w0)
-                x &= ~0ull << (s & 63);
-            if (w == w1 && (e & 63))
-                x &= (1ull << (e & 63)) - 1;
+                x &= ~0ull << (cs & 63);
+            if (w == w1 && (ce & 63))
+                x &= (1ull << (ce & 63)) - 1;
             par ^= (u32)__popcll(x);
         }
         const u64 odd = __ballot(par & 1u);
-        if (lane == 0 && (__popcll(odd) & 1))
-            atomicXor(&odd_waves, 1u);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            wave_par[threadIdx.x >> 6] = (u32)__popcll(odd) & 1u;
         __syncthreads();
-        if (threadIdx.x == 0)
-            bits[b] = (uint8_t)(odd_waves & 1u);
+        if (threadIdx.x == 0 && (wave_par[0] ^ wave_par[1] ^ wave_par[2] ^ wave_par[3]))
+            atomicXor(work.slot_par + slot, 1u);
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(256) k_long_to_bits(LongWork work, uint8_t *__restrict__ bits)
+{
+    const u32 n = work.counters[0];
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        bits[work.slot_ct[i]] = (uint8_t)(work.slot_par[i] & 1u);
 }
 
 // decrypt, pass 2 for LONG uniform ciphertexts: a ciphertext's bit range is cut into chunks of
@@ -257,10 +284,27 @@ static size_t decrypt_bitmap_bytes(u64 total_terms)
     return (size_t)((total_terms + 255) / 256) * 32u + 64u;
 }
 
+// ragged batches: at most this many ciphertexts are "long" (> kLongTerms terms) ...
+static u64 decrypt_max_long(u64 batch, u64 total_terms)
+{
+    const u64 by_terms = total_terms / (kLongTerms + 1) + 1;
+    return batch < by_terms ? batch : by_terms;
+}
+// ... and their chunk lists have at most this many entries
+static u64 decrypt_max_entries(u64 batch, u64 total_terms)
+{
+    return decrypt_max_long(batch, total_terms) + total_terms / kChunkTerms + 1;
+}
+
 size_t decrypt_scratch_bytes(u64 batch, u64 total_terms)
 {
-    // [hit bitmap, one bit per term | pad][one u32 partial parity per ciphertext]
-    return decrypt_bitmap_bytes(total_terms) + (size_t)batch * 4u + 16u;
+    // [hit bitmap, one bit per term | pad] then the larger of
+    //   uniform long ciphertexts: one u32 partial parity per ciphertext
+    //   ragged batches: LongWork (4 counters, 2 u32 per long slot, one u64 per chunk entry)
+    const size_t uniform = (size_t)batch * 4u + 16u;
+    const size_t ragged = 16u + (size_t)decrypt_max_long(batch, total_terms) * 8u + 8u +
+                          (size_t)decrypt_max_entries(batch, total_terms) * 8u;
+    return decrypt_bitmap_bytes(total_terms) + (uniform > ragged ? uniform : ragged);
 }
 
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
@@ -331,19 +375,27 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
             return e;
     }
     if (off) {
-        // ragged: short ciphertexts one lane each; the long ones are queued and take one wave each
+        // ragged: short ciphertexts one lane each; the long ones are queued chunk by chunk
         if (batch >= (1ull << 32))
             return hipErrorInvalidValue;
-        u32 *work = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
-                                            decrypt_bitmap_bytes(total_terms));      // [count][batch indices]
-        hipError_t e = hipMemsetAsync(work, 0, 4, s);
+        unsigned char *wbase = reinterpret_cast<unsigned char *>(scratch) + decrypt_bitmap_bytes(total_terms);
+        LongWork work;
+        work.counters = reinterpret_cast<u32 *>(wbase);
+        work.slot_ct = work.counters + 4;
+        const u64 max_long = decrypt_max_long(batch, total_terms);
+        work.slot_par = work.slot_ct + max_long;
+        work.entries = reinterpret_cast<u64 *>(wbase + ((16u + max_long * 8u + 7u) & ~(size_t)7u));
+        hipError_t e = hipMemsetAsync(work.counters, 0, 16, s);
         if (e != hipSuccess)
             return e;
         k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits, work);
-        if (total_terms > kLongTerms)
-            k_hits_parity_long<<<(u32)std::min<u64>(4096, batch), 256, 0, s>>>(hits, off, work, bits);
+        if (total_terms > kLongTerms) {
+            const u64 max_entries = decrypt_max_entries(batch, total_terms);
+            k_hits_parity_chunks<<<(u32)std::min<u64>(8192, max_entries), 256, 0, s>>>(hits, off, work);
+            k_long_to_bits<<<(u32)std::min<u64>(64, (max_long + 255) / 256), 256, 0, s>>>(work, bits);
+        }
     } else if (terms_uniform <= kLongTerms) {
-        k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, nullptr);
+        k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, LongWork{});
     } else if (batch * ((terms_uniform + 65535) / 65536) <= kMaxBlocks256) {
         // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
         u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
@@ -357,7 +409,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     } else {
         if (batch * 64 > kMaxBlocks256 * 256u)
             return hipErrorInvalidValue;
-        k_hits_parity<64, 0><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, nullptr);
+        k_hits_parity<64, 0><<<ceil_div_u64(batch * 64, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, LongWork{});
     }
     return hipGetLastError();
 }

@@ -81,6 +81,26 @@ __device__ inline u32 csr_gallop(const u64 *__restrict__ off, u32 lo, u32 batch,
     return csr_find(off, lo, hi, term);
 }
 
+// The same answer as csr_find(off, lo, hi, term), computed by a whole WAVE: a 64-ary search, every
+// step one load per lane (64 probes spread over the range) and one __ballot -- log64(batch) dependent
+// round trips (3 for 65 536 pairs, 4 for 1 M) where the binary search makes 17 to 20.  The start-up
+// search of a ragged workgroup was ~10 us of a lifetime in which it writes 16 KiB (~5 us at full
+// rate): with few workgroup rounds (a 178 MB output) nothing hid it (round 2: 2.7 TB/s on one
+// 1024x1024 pair among 65 535 singles).  Requires off[lo] <= term; every lane returns the result.
+__device__ inline u32 wave_find(const u64 *__restrict__ off, u32 lo, u32 hi, u64 term)
+{
+    const u32 lane = threadIdx.x & (kWave - 1);
+    while (hi - lo > 1) {
+        const u32 n = hi - lo, s = (n + kWave - 1) / kWave;
+        const u64 idx = (u64)lo + (u64)lane * s;
+        const bool ok = idx < hi && off[idx] <= term;          // monotone in the lane number; lane 0 holds by the invariant
+        const u32 c = (u32)__popcll(__ballot(ok));             // >= 1
+        lo += (c - 1u) * s;
+        hi = min(lo + s, hi);
+    }
+    return lo;
+}
+
 template <int VEC>
 struct UnitWords {
     u64 w[VEC];

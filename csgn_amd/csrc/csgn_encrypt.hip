@@ -255,11 +255,17 @@ __device__ inline u32 rotl32(u32 x, int n) { return __builtin_amdgcn_alignbit(x,
     a += b; d ^= a; d = rotl32(d, 8);  \
     c += d; b ^= c; b = rotl32(b, 7)
 
-template <int ROUNDS>
+// DRAW selects the constant words of the state: the keystream proper uses ChaCha's own "expand 32-byte k";
+// the stream the plaintext-0 rule draws its position from uses "csgn draw pos v1".  Different
+// constants make the two streams of one (key, nonce) unrelated functions of the counter, so no value
+// of the nonce turns one into the other (round 2 separated them by flipping the nonce's top bit: the
+// draw stream of nonce N was the DATA stream of N ^ 2^63 -- ADVICE r2).
+template <int ROUNDS, bool DRAW = false>
 __device__ inline void chacha_block(const EncKeyed &k, u32 nonce_lo, u32 nonce_hi, u32 ctr_lo, u32 ctr_hi,
                                     u32 (&x)[16])
 {
-    const u32 c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;   // "expand 32-byte k"
+    const u32 c0 = DRAW ? 0x6e677363u : 0x61707865u, c1 = DRAW ? 0x61726420u : 0x3320646eu,
+              c2 = DRAW ? 0x6f702077u : 0x79622d32u, c3 = DRAW ? 0x31762073u : 0x6b206574u;
     x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -284,16 +290,15 @@ __device__ inline void chacha_block(const EncKeyed &k, u32 nonce_lo, u32 nonce_h
 }
 #undef CSGN_QR
 
-// The draw of src/SecretKey.cpp:51 for ciphertext c in keyed mode: a separate ChaCha stream (nonce
-// with its top bit flipped), block counter = c, first output word range-reduced to [0, D).
-constexpr u32 kDrawDomain = 0x80000000u;
+// The draw of src/SecretKey.cpp:51 for ciphertext c in keyed mode: a separate stream of the same key and
+// nonce (constants "csgn draw pos v1"), block counter = c, first output word range-reduced to [0, D).
 
 template <int ROUNDS>
 __device__ inline u32 keyed_draw_pos(const EncKeyed &k, u32 nonce_lo, u32 nonce_hi, u64 c,
                                      const u64 *__restrict__ key_idx, u32 D)
 {
     u32 x[16];
-    chacha_block<ROUNDS>(k, nonce_lo, nonce_hi ^ kDrawDomain, (u32)c, (u32)(c >> 32), x);
+    chacha_block<ROUNDS, true>(k, nonce_lo, nonce_hi, (u32)c, (u32)(c >> 32), x);
     return (u32)key_idx[__umulhi(x[0], D)];
 }
 

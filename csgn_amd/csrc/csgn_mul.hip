@@ -196,9 +196,18 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
 // few pairs one workgroup can span.
 // ---------------------------------------------------------------------------------------
 
-// A workgroup owns C consecutive 4 KiB chunks of the flattened output: one uniform search for its
-// first term, then every wave walks forward from the pair it was in (csr_gallop), so the
-// log2(batch) dependent loads are paid once per C chunks instead of twice per chunk.
+// A workgroup owns C consecutive 4 KiB chunks of the flattened output and takes them M at a time (a
+// "turn").  Start: the pair of its first term by a 64-ary wave search (wave_find).  Per turn:
+//   * bet on the pair the workgroup was in: its offsets are uniform addresses (scalar loads, one round
+//     trip); if that pair owns the whole turn -- any turn inside a large product -- nothing else is
+//     looked up;
+//   * otherwise the offsets of the next 256 pairs come into LDS in ONE coalesced round trip (three
+//     loads per thread) and every lane finds its pair there by an 8-step LDS binary search: no
+//     per-lane chain of dependent global loads whatever the pair sizes (round 2 walked the offsets
+//     lane by lane: 3.4 TB/s on a million 1x1 pairs);
+//   * the 2M operand loads of a lane travel together, then M non-temporal 16-byte stores.
+constexpr u32 kWin = 256;                                       // pairs per offset window
+
 template <typename Unit, int C, int M>
 __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
@@ -210,13 +219,15 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          u32 pf_pairs)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
+    __shared__ u64 w_out[kWin + 1], w_l[kWin + 1], w_r[kWin + 2];
+    __shared__ u32 s_next;
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const u64 g_begin = unit_base + (u64)bid * (256u * C);
     if (g_begin >= total_units)
         return;
     const u64 term0 = g_begin / U;                              // workgroup-uniform
     const u32 r0blk = (u32)(g_begin - term0 * U);
-    u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
+    u32 pw = wave_find(offOut, 0u, batch, term0);               // the same answer in every wave
     // The workgroup that holds the start of a pair pulls the operands of the pair `pf_pairs` further
     // on into the caches (one dword per 128-byte line, values unused): by the time that pair's
     // rows are written its left terms are hits instead of HBM misses under full write load.
@@ -236,20 +247,31 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             asm volatile("" ::"v"(v));
         }
     }
-    // The kernel is bound by its chain of dependent loads (PMC, profiles/r02/ragged_pmc_summary.json:
-    // walk -> offsets -> operands -> store, three round trips per KiB of output against one in the
-    // uniform kernel).  Two remedies:
-    //   * bet on the pair the wave was in: its offsets are wave-uniform addresses (scalar loads, one
-    //     round trip together with the end-of-pair test); only lanes whose term lies beyond that pair
-    //     walk on and fetch again;
-    //   * M chunks per turn share that one bet, and their 2M operand loads travel together: M KiB of
-    //     output per wave and round trip.
 #pragma unroll 1
     for (int c0 = 0; c0 < C; c0 += M) {
         if (g_begin + (u32)c0 * 256u >= total_units)
             break;
         const u64 s_o0 = offOut[pw], s_o1 = offOut[pw + 1];
         const u64 s_l0 = offL[pw], s_r0 = offR[pw], s_r1 = offR[pw + 1];
+        // last term of the turn (workgroup-uniform): does the bet pair own all of it?
+        const u64 turn_end = min(g_begin + (u64)(c0 + M) * 256u, total_units);          // one past the last unit
+        const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
+        const bool whole = last_term < s_o1;
+        if (!whole) {
+            const u32 i = threadIdx.x;
+            const u32 pi = min(pw + i, batch);                   // the offset arrays have batch + 1 entries
+            w_out[i] = offOut[pi];
+            w_l[i] = offL[pi];
+            w_r[i] = offR[pi];
+            if (i == 0) {
+                const u32 pe = min(pw + kWin, batch), pe1 = min(pw + kWin + 1u, batch);
+                w_out[kWin] = offOut[pe];
+                w_l[kWin] = offL[pe];
+                w_r[kWin] = offR[pe];
+                w_r[kWin + 1] = offR[pe1];
+            }
+            __syncthreads();
+        }
         u32 p[M];
         u64 la[M], ra[M];                                       // operand unit indices
         bool live[M];
@@ -268,12 +290,29 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             if (live[m]) {
                 u64 o0 = s_o0, l0 = s_l0, rr0 = s_r0;
                 u32 t2 = (u32)(s_r1 - s_r0);
-                if (term >= s_o1) {                             // past the end of pair pw
-                    p[m] = csr_gallop(offOut, pw, batch, term); // runs of empty pairs are walked over
-                    o0 = offOut[p[m]];
-                    l0 = offL[p[m]];
-                    rr0 = offR[p[m]];
-                    t2 = (u32)(offR[p[m] + 1] - rr0);
+                if (!whole && term >= s_o1) {                   // past the end of pair pw: look in the window
+                    // largest j in [0, kWin] with w_out[j] <= term (w_out[0] = s_o0 <= term)
+                    u32 lo = 0, hi = kWin + 1u;
+#pragma unroll
+                    for (int step = 0; step < 9; ++step) {      // 257 entries
+                        const u32 mid = (lo + hi) >> 1;
+                        const bool le = w_out[mid] <= term;
+                        lo = le ? mid : lo;
+                        hi = le ? hi : mid;
+                    }
+                    if (lo == kWin && pw + kWin < batch) {      // beyond the window (long runs of empty pairs): walk
+                        p[m] = csr_gallop(offOut, pw + kWin, batch, term);
+                        o0 = offOut[p[m]];
+                        l0 = offL[p[m]];
+                        rr0 = offR[p[m]];
+                        t2 = (u32)(offR[p[m] + 1] - rr0);
+                    } else {
+                        p[m] = pw + lo;
+                        o0 = w_out[lo];
+                        l0 = w_l[lo];
+                        rr0 = w_r[lo];
+                        t2 = (u32)(w_r[lo + 1] - rr0);
+                    }
                 }
                 const u32 q = (u32)(term - o0);                 // product term index inside the pair
                 const u32 i = q / t2, j = q - i * t2;
@@ -291,185 +330,12 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         for (int m = 0; m < M; ++m)
             if (live[m])
                 unit_store<Unit, true>(out + g_begin + (u32)(c0 + m) * 256u + threadIdx.x, lv[m] & rv[m]);
-        pw = (u32)__builtin_amdgcn_readfirstlane((int)p[M - 1]);   // the next turn starts from the last chunk's pair
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Ragged batches, indexed form (round 2).  The flat kernel above keeps ONE dependent chain of loads
-// in flight per wave (search -> operand offsets -> operand units -> store), 1 KiB of output per
-// chain: with cold operands every link is an L2 / HBM miss and a CU's 32 wave slots cannot keep
-// more than ~13 KB per microsecond moving (measured 3.3 TB/s cold, 5.5 warm).  Here
-//   * a side table built once per call -- the pair that owns every 32nd output term -- replaces the
-//     log2(batch)-deep search by one load, and makes every 4 KiB chunk independent of its neighbours;
-//   * each lane carries M units (one per 4 KiB chunk, so every wave instruction is still one
-//     coalesced 1 KiB access) through the chain STAGE BY STAGE: M table loads, then 5M offset loads
-//     (product and operand offsets of the table's pair together), then 2M operand loads, then M
-//     stores.  Three links instead of six to twenty, and M KiB of output per wave in flight on each.
-// Lanes whose term is not in the table's pair or its successor (runs of tiny or empty pairs) take
-// the galloping search between the stages.
-// MEASURED (profiles/r02/bench_ragged.log): it loses to the searching kernel on every batch tried --
-// log-normal batch 3.8 vs 4.8 TB/s with the operands cached, 3.1-3.5 vs 4.6 cold; 1 M ragged 1x1
-// pairs 2.6 vs 3.2 -- so it is OFF by default (knob ragged_table) and kept as the record of the
-// experiment VERDICT r1 #10 asked for.  The searching kernel's workgroup-uniform search runs on the
-// scalar unit and its per-chunk walk is one broadcast load; the table form pays a table build, a
-// stream-ordered allocation and 64-bit address arithmetic for five offset loads per unit.
-// ---------------------------------------------------------------------------------------
-constexpr u32 kTabShift = 5;                        // one table entry per 32 output terms
-
-__global__ void __launch_bounds__(256) k_ragged_table(const u64 *__restrict__ offOut, u32 batch, u64 nent,
-                                                      u32 *__restrict__ table)
-{
-    const u64 e = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (e < nent)
-        table[e] = csr_find(offOut, 0u, batch, e << kTabShift);
-}
-
-template <typename Unit, int M>
-__global__ void __launch_bounds__(256) k_mul_ragged_tab(const Unit *__restrict__ L,
-                                                        const u64 *__restrict__ offL,
-                                                        const Unit *__restrict__ R,
-                                                        const u64 *__restrict__ offR,
-                                                        Unit *__restrict__ out,
-                                                        const u64 *__restrict__ offOut,
-                                                        const u32 *__restrict__ table, u32 batch,
-                                                        u64 unit_base, u64 total_units, u32 U, FastDiv dU)
-{
-    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const u64 g_begin = unit_base + (u64)bid * (256u * M);
-    if (g_begin >= total_units)
-        return;
-    const u64 term0 = g_begin / U;                              // workgroup-uniform
-    const u32 r0blk = (u32)(g_begin - term0 * U);
-    const u64 last = total_units - 1;
-    u64 term[M];
-    u32 k[M], p[M];
-    bool live[M];
-    // A. table
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const u64 g = g_begin + (u32)m * 256u + threadIdx.x;
-        live[m] = g <= last;
-        const u32 r = r0blk + (u32)m * 256u + threadIdx.x;      // distance from the workgroup's first term, in units
-        const u32 dt = csgn_fastdiv(r, dU);
-        term[m] = min(term0 + dt, last / U);                    // lanes past the end repeat the last term
-        k[m] = live[m] ? r - dt * U : 0u;
-        p[m] = table[term[m] >> kTabShift];
-    }
-    // B. the table's pair owns term 32e; this lane's term (up to 31 further on) is in it unless the
-    //    next pair starts at or before the term.  The pair's operand offsets are fetched in the same
-    //    round trip, on the bet that the table's pair is the right one.
-    u64 o0[M], o1[M], l0[M], rr0[M], rr1[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        o0[m] = offOut[p[m]];
-        o1[m] = offOut[min(p[m] + 1u, batch)];
-        l0[m] = offL[p[m]];
-        rr0[m] = offR[p[m]];
-        rr1[m] = offR[min(p[m] + 1u, batch)];
-    }
-    // C. lost bets (rare for pairs of more than 32 product terms): search on, fetch again
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        if (p[m] + 1u < batch && o1[m] <= term[m]) {
-            p[m] = csr_gallop(offOut, p[m] + 1u, batch, term[m]);
-            o0[m] = offOut[p[m]];
-            l0[m] = offL[p[m]];
-            rr0[m] = offR[p[m]];
-            rr1[m] = offR[p[m] + 1u];
+        if (!whole) {                                           // the next turn starts from the last lane's pair
+            if (threadIdx.x == 255u)
+                s_next = p[M - 1];
+            __syncthreads();
+            pw = s_next;
         }
-    // D. operand units
-    Unit lv[M], rv[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const u32 t2 = max((u32)(rr1[m] - rr0[m]), 1u);
-        const u32 q = (u32)(term[m] - o0[m]);                   // product term index inside the pair
-        const u32 i = q / t2, j = q - i * t2;
-        lv[m] = L[(l0[m] + i) * U + k[m]];
-        rv[m] = R[(rr0[m] + j) * U + k[m]];
-    }
-    // E. the product
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        if (live[m])
-            unit_store<Unit, true>(out + g_begin + (u32)m * 256u + threadIdx.x, lv[m] & rv[m]);
-}
-
-// ---------------------------------------------------------------------------------------
-// Ragged batches, record form (round 2).  The flat kernel above spends most of its ~100 VALU
-// instructions per unit on bookkeeping: four 8-byte loads from three offset arrays with 64-bit
-// address arithmetic each, and a 32-bit division by a per-pair divisor (q / t2, ~30 instructions).
-// At 4.8 TB/s that is 0.6 of the VALU issue rate: the kernel is as much issue-bound as
-// memory-bound.  Here one small kernel first writes a 32-byte RECORD per pair -- product offset,
-// operand offsets, t2 and the multiply-shift constants that divide by it -- and the product
-// kernel then needs, per unit, the walk to its pair (as before), ONE 32-byte load and a
-// six-instruction division.
-// MEASURED (profiles/r02/bench_ragged.log): no gain -- log-normal batch 5.17 vs 5.10 TB/s with cached
-// operands, 4.61 vs 4.72 cold -- and a loss on small outputs, where the record kernel and the
-// stream-ordered allocation are a fifth of the call (one 1024x1024 pair among 65 535 singles 2.1 vs
-// 2.6).  So the kernel is not issue-bound on its bookkeeping either; OFF by default (knob ragged_rec).
-// ---------------------------------------------------------------------------------------
-struct __attribute__((aligned(32))) PairRec {
-    u64 o0;          // first product term of the pair
-    u64 l0;          // first left term
-    u64 r0s;         // first right term | fastdiv shift << 56
-    u64 t2m;         // t2 | fastdiv magic << 32
-};
-
-__global__ void __launch_bounds__(256) k_ragged_records(const u64 *__restrict__ offL, const u64 *__restrict__ offR,
-                                                        const u64 *__restrict__ offOut, u32 batch,
-                                                        PairRec *__restrict__ rec)
-{
-    const u32 p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= batch)
-        return;
-    const u64 r0 = offR[p];
-    const u32 t2 = (u32)(offR[p + 1] - r0);
-    const FastDiv f = csgn_fastdiv_make(t2 ? t2 : 1u);
-    PairRec x;
-    x.o0 = offOut[p];
-    x.l0 = offL[p];
-    x.r0s = r0 | ((u64)f.shift << 56);
-    x.t2m = (u64)(t2 ? t2 : 1u) | ((u64)f.magic << 32);
-    rec[p] = x;
-}
-
-template <typename Unit, int C>
-__global__ void __launch_bounds__(256) k_mul_ragged_rec(const Unit *__restrict__ L, const Unit *__restrict__ R,
-                                                        Unit *__restrict__ out, const u64 *__restrict__ offOut,
-                                                        const PairRec *__restrict__ rec, u32 batch, u64 unit_base,
-                                                        u64 total_units, u32 U, FastDiv dU)
-{
-    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const u64 g_begin = unit_base + (u64)bid * (256u * C);
-    if (g_begin >= total_units)
-        return;
-    const u64 term0 = g_begin / U;                              // workgroup-uniform
-    const u32 r0blk = (u32)(g_begin - term0 * U);
-    u32 pw = csr_find(offOut, 0u, batch, term0);                // uniform search: loads broadcast
-#pragma unroll 1
-    for (int c = 0; c < C; ++c) {
-        const u64 g = g_begin + (u32)c * 256u + threadIdx.x;
-        if (g_begin + (u32)c * 256u >= total_units)
-            break;
-        const u32 r = r0blk + (u32)c * 256u + threadIdx.x;
-        const u32 dt = csgn_fastdiv(r, dU);
-        const u64 term = term0 + dt;
-        const u32 k = r - dt * U;
-        u32 p = pw;
-        if (g < total_units) {
-            p = csr_gallop(offOut, pw, batch, term);            // runs of empty pairs are walked over
-            const PairRec x = rec[p];                           // one 32-byte load
-            FastDiv f;
-            f.d = (u32)x.t2m;
-            f.magic = (u32)(x.t2m >> 32);
-            f.shift = (u32)(x.r0s >> 56);
-            const u32 q = (u32)(term - x.o0);                   // product term index inside the pair
-            const u32 i = csgn_fastdiv(q, f), j = q - i * f.d;
-            const u64 r0 = x.r0s & 0x00FFFFFFFFFFFFFFull;
-            unit_store<Unit, true>(out + g, L[(x.l0 + i) * U + k] & R[(r0 + j) * U + k]);
-        }
-        pw = (u32)__builtin_amdgcn_readfirstlane((int)p);       // later chunks start from here
     }
 }
 
@@ -931,6 +797,12 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         return hipSuccess;
     if (batch >= (1ull << 32))
         return hipErrorInvalidValue;
+    // Every pair has the largest shape (t1_b <= max_t1, t2_b <= max_t2 and the products sum to
+    // batch * max_t1 * max_t2): the CSR arrays describe a UNIFORM batch, so no lane has to look
+    // anything up -- a million fresh 1x1 pairs given as a ragged batch run k_and_stream (6.2 TB/s
+    // instead of 3.4 through the CSR kernel).
+    if (total_out_terms == batch * max_t1 * max_t2 && csgn::tune(TUNE_RAGGED_FLAT) == 0)
+        return mul_uniform(n_bits, batch, max_t1, max_t2, L, R, out, 0, s);
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
     // Nearly uniform batches of large products keep the LDS-tiled kernel (one grid sized for the
@@ -952,74 +824,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    // Indexed form (opt-in, see k_mul_ragged_tab: measured slower): knob ragged_table = 1 uses it for
-    // outputs of 32 MB and more (the table costs one extra launch and a stream-ordered allocation of
-    // 4 bytes per 32 output terms), 2 / 4 / 8 set the units per lane (default 4), a negative value
-    // drops the size threshold.
-    const int tab_knob = csgn::tune(TUNE_RAGGED_TABLE);       // < 0: whatever the size (tests)
-    if (tab_knob != 0 && (tab_knob < 0 || total_units * (wide ? 16u : 8u) >= (32ull << 20)) &&
-        total_out_terms < (1ull << 37)) {
-        const u64 nent = (total_out_terms >> kTabShift) + 1;
-        u32 *table = nullptr;
-        if (hipMallocAsync((void **)&table, nent * sizeof(u32), s) == hipSuccess) {
-            k_ragged_table<<<ceil_div_u64(nent, 256u), 256, 0, s>>>(offOut, (u32)batch, nent, table);
-            const int mreq = tab_knob < 0 ? -tab_knob : tab_knob;
-            const int M = (mreq == 2 || mreq == 4 || mreq == 8) ? mreq : 4;
-            const bool touch = wide && total_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
-            const u64 per_launch = touch ? (1ull << 26) : (kMaxBlocks256 / 8u) * 256u * (u64)M;   // units
-            hipError_t le = hipGetLastError();
-            for (u64 u0 = 0; u0 < total_units && le == hipSuccess; u0 += per_launch) {
-                const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
-                const u32 blocks = ceil_div_u64(nu, 256u * (u32)M);
-                if (touch)
-                    k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
-                                                       reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
-                                                       u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
-#define CSGN_RAGGED_TAB(MM)                                                                             \
-    do {                                                                                                \
-        if (wide)                                                                                       \
-            k_mul_ragged_tab<unit16, MM><<<blocks, 256, 0, s>>>(                                        \
-                reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,   \
-                reinterpret_cast<unit16 *>(out), offOut, table, (u32)batch, u0, u0 + nu, U, dU);        \
-        else                                                                                            \
-            k_mul_ragged_tab<unit8, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, table,    \
-                                                               (u32)batch, u0, u0 + nu, U, dU);         \
-    } while (0)
-                switch (M) {
-                case 2: CSGN_RAGGED_TAB(2); break;
-                case 8: CSGN_RAGGED_TAB(8); break;
-                default: CSGN_RAGGED_TAB(4); break;
-                }
-#undef CSGN_RAGGED_TAB
-                le = hipGetLastError();
-            }
-            const hipError_t fe = hipFreeAsync(table, s);
-            return le != hipSuccess ? le : fe;
-        }
-        (void)hipGetLastError();        // no stream-ordered allocator: the searching kernel below needs none
-    }
     // 4 KiB chunks per workgroup: at most 4 here since the per-chunk lookup became one scalar round trip
     // (measured cold, log-normal batch: C=4 5.65 TB/s, C=8 5.24, C=16 4.94, C=2 4.18, C=1 2.48)
     const int chunks = csgn::tune(TUNE_RAGGED_C) ? ragged_chunks(total_units) : std::min(4, ragged_chunks(total_units));
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
-    // Record form (opt-in, see k_mul_ragged_rec; knob ragged_rec: 1 = for outputs of 8 MB and more,
-    // -1 = always, 0 = never): 32 bytes per pair in a stream-ordered allocation, written by one small
-    // kernel per call
-    const int rec_knob = csgn::tune(TUNE_RAGGED_REC);
-    PairRec *rec = nullptr;
-    if (rec_knob != 0 && (rec_knob < 0 || total_units * (wide ? 16u : 8u) >= (8ull << 20))) {
-        if (hipMallocAsync((void **)&rec, batch * sizeof(PairRec), s) == hipSuccess) {
-            k_ragged_records<<<ceil_div_u64(batch, 256u), 256, 0, s>>>(offL, offR, offOut, (u32)batch, rec);
-            if (hipGetLastError() != hipSuccess) {
-                (void)hipFreeAsync(rec, s);
-                rec = nullptr;
-            }
-        } else {
-            (void)hipGetLastError();       // no stream-ordered allocator: the searching kernel needs none
-            rec = nullptr;
-        }
-    }
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
     // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
     // an HBM miss under full write load, as in the uniform path.  Knob ragged_touch = 0 turns it off.
@@ -1046,14 +855,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
-        if (rec && wide)                                                                            \
-            k_mul_ragged_rec<unit16, CH><<<blocks, 256, 0, s>>>(                                    \
-                reinterpret_cast<const unit16 *>(L), reinterpret_cast<const unit16 *>(R),           \
-                reinterpret_cast<unit16 *>(out), offOut, rec, (u32)batch, u0, u0 + nu, U, dU);      \
-        else if (rec)                                                                               \
-            k_mul_ragged_rec<unit8, CH><<<blocks, 256, 0, s>>>(L, R, out, offOut, rec, (u32)batch,  \
-                                                               u0, u0 + nu, U, dU);                 \
-        else if (turn >= 4 && (CH) % 4 == 0)                                                        \
+        if (turn >= 4 && (CH) % 4 == 0)                                                             \
             CSGN_RAGGED_FLAT(CH, ((CH) % 4 == 0 ? 4 : 1));                                          \
         else if (turn >= 2 && (CH) % 2 == 0)                                                        \
             CSGN_RAGGED_FLAT(CH, ((CH) % 2 == 0 ? 2 : 1));                                          \
@@ -1070,11 +872,6 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
 #undef CSGN_RAGGED_FLAT
 #undef CSGN_RAGGED_LAUNCH
         result = hipGetLastError();
-    }
-    if (rec) {
-        const hipError_t fe = hipFreeAsync(rec, s);
-        if (result == hipSuccess)
-            result = fe;
     }
     return result;
 }

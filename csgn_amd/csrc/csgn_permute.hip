@@ -191,323 +191,12 @@ __device__ inline void wave_transpose64_n(u32 (&h)[2 * Q], const TrLane &c)
     tr_stage_n<3, 2 * Q>(h, c);
 }
 
-constexpr int kPermUnroll = 5;
-
-// Workgroup = ONE wave = 64 terms at a time, persistent over groups of 64 terms.  LDS: rows[64][SA]
-// (SA odd: conflict-free column reads), planes[dLp*64 + 1] (the last entry stays 0: "no source"),
-// psrc[dLp*64] (u16 source plane of every output bit).  The next group's terms are
-// loaded into registers (LQ words per lane, all in flight) while this group is transposed.
-template <int LQ, bool PIPE, int UW>
-__global__ void __launch_bounds__(64) k_permute_planes(u64 n_bits, u32 dL, FastDiv dUd, u64 out_terms,
-                                                       u64 in_stride_words,
-                                                       const u64 *__restrict__ terms,
-                                                       const u32 *__restrict__ perm,
-                                                       u64 *__restrict__ out)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const u32 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
-    const u32 SA = dLp | 1u;
-    const u32 none = dLp * 64u;                    // index of the all-zero plane
-    u64 *rows = reinterpret_cast<u64 *>(smem_raw);
-    u64 *planes = rows + 64u * SA;                 // none + 1 entries
-    unsigned short *psrc = reinterpret_cast<unsigned short *>(planes + none + 1);   // none entries
-    const u32 lane = threadIdx.x;
-    const TrLane trc = tr_lane(lane);
-    const u32 nb = (u32)n_bits;
-    const u32 Ud = dL / UW;                        // staging units (UW words = 8 or 16 bytes) per term
-    const u32 nu = 64u * Ud;                       // units in a full group
-    const u64 groups = (out_terms + 63) / 64;
-    typedef u64 StageUnit __attribute__((ext_vector_type(UW)));
-
-    // this lane's LQ staging slots: unit u = q*64 + lane of the group -> (term t, word k)
-    u32 rowoff[LQ];        // t*SA + k in rows[]
-    u32 tq[LQ];            // t
-#pragma unroll
-    for (int q = 0; q < LQ; ++q) {
-        const u32 u = min((u32)q * 64u + lane, nu - 1u);
-        const u32 t = csgn_fastdiv(u, dUd);
-        tq[q] = t;
-        rowoff[q] = t * SA + (u - t * Ud) * UW;
-    }
-    const u64 gskip = in_stride_words - SA;        // input offset = rowoff + t*(stride - SA)
-    StageUnit v[LQ];
-    auto fetch = [&](u64 g) {
-        const u64 t0 = g * 64;
-        const u32 nt = (u32)min((u64)64, out_terms - t0);
-        const u64 *base = terms + t0 * in_stride_words;
-#pragma unroll
-        for (int q = 0; q < LQ; ++q) {
-            // a term past the end re-reads the group's first term (discarded below)
-            const u64 off = tq[q] < nt ? rowoff[q] + tq[q] * gskip : 0ull;
-            v[q] = *reinterpret_cast<const StageUnit *>(base + off);
-        }
-    };
-    auto rows_put = [&](u32 off, StageUnit x, bool live) {
-#pragma unroll
-        for (int i = 0; i < UW; ++i)     // SA is odd: a row starts 8-byte, not 16-byte, aligned
-            rows[off + i] = live ? x[i] : 0ull;
-    };
-    auto rows_get = [&](u32 off) {
-        StageUnit x;
-#pragma unroll
-        for (int i = 0; i < UW; ++i)
-            x[i] = rows[off + i];
-        return x;
-    };
-
-    u64 g = blockIdx.x;
-    if (g < groups)
-        fetch(g);
-    // 0. source plane of every output bit (`none` for padding bits and out-of-range entries)
-    for (u32 j0 = 0; j0 < none; j0 += 64u * kPermUnroll) {
-        u32 p[kPermUnroll];
-#pragma unroll
-        for (int q = 0; q < kPermUnroll; ++q)
-            p[q] = perm[min(j0 + (u32)q * 64u + lane, nb - 1u)];
-#pragma unroll
-        for (int q = 0; q < kPermUnroll; ++q) {
-            const u32 j = j0 + (u32)q * 64u + lane;
-            psrc[j] = (unsigned short)(j < nb && p[q] < nb ? p[q] : none);
-        }
-    }
-    if (lane == 0)
-        planes[none] = 0;
-
-    // Order of the vector-memory operations inside one turn: wait for this group's terms, issue the
-    // PREVIOUS group's stores (results parked in o[] when PIPE), issue the next group's loads, then
-    // compute.  Everything issued has the whole compute phase to complete, so the vmcnt(0) at the
-    // top of the next turn finds it done (loads and stores share one in-order counter on gfx9).
-    StageUnit o[PIPE ? LQ : 1];
-    u64 gprev = ~0ull;
-    auto flush = [&](u64 gp) {
-        const u64 t0 = gp * 64;
-        const u32 nt = (u32)min((u64)64, out_terms - t0);
-        StageUnit *obase = reinterpret_cast<StageUnit *>(out + t0 * dL);
-#pragma unroll
-        for (int q = 0; q < LQ; ++q)
-            if ((u32)q * 64u + lane < nt * Ud)
-                obase[(u32)q * 64u + lane] = o[PIPE ? q : 0];
-    };
-
-    for (; g < groups; g += gridDim.x) {
-        const u64 t0 = g * 64;
-        const u32 nt = (u32)min((u64)64, out_terms - t0);
-        // 1. rows <- the 64 terms fetched earlier (slots past the end repeat the last unit)
-#pragma unroll
-        for (int q = 0; q < LQ; ++q)
-            rows_put(rowoff[q], v[q], tq[q] < nt);
-        __syncthreads();
-        if (PIPE && gprev != ~0ull)
-            flush(gprev);
-        if (g + gridDim.x < groups)
-            fetch(g + gridDim.x);
-        // 2. rows -> bit planes: lane b ends up with term-bit j = w*64 + 63 - b of all 64 terms.
-        //    kPermUnroll words in flight: the six exchange stages of one transpose are a serial
-        //    chain, independent words fill the gaps.  dLp is dL rounded up to kPermUnroll and every
-        //    LDS array is sized for it, so the loops need no guards (tail columns hold don't-cares).
-        for (u32 w0 = 0; w0 < dLp; w0 += kPermUnroll) {
-            u32 h[2 * kPermUnroll];
-#pragma unroll
-            for (int q = 0; q < kPermUnroll; ++q) {
-                const u64 x = rows[lane * SA + w0 + (u32)q];
-                h[2 * q] = (u32)x;
-                h[2 * q + 1] = (u32)(x >> 32);
-            }
-            wave_transpose64_n<kPermUnroll>(h, trc);
-#pragma unroll
-            for (int q = 0; q < kPermUnroll; ++q)
-                planes[(w0 + (u32)q) * 64u + 63u - lane] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
-        }
-        __syncthreads();
-        // 3. new bit j <- old bit perm[j]; planes -> rows
-        for (u32 w0 = 0; w0 < dLp; w0 += kPermUnroll) {
-            u32 h[2 * kPermUnroll];
-#pragma unroll
-            for (int q = 0; q < kPermUnroll; ++q) {
-                const u64 y = planes[psrc[(w0 + (u32)q) * 64u + 63u - lane]];
-                h[2 * q] = (u32)y;
-                h[2 * q + 1] = (u32)(y >> 32);
-            }
-            wave_transpose64_n<kPermUnroll>(h, trc);
-#pragma unroll
-            for (int q = 0; q < kPermUnroll; ++q)
-                rows[lane * SA + w0 + (u32)q] = ((u64)h[2 * q + 1] << 32) | h[2 * q];
-        }
-        __syncthreads();
-        // 4. rows -> out, coalesced: now, or parked in registers until the next turn's loads are in
-        if (PIPE) {
-#pragma unroll
-            for (int q = 0; q < LQ; ++q)
-                o[q] = rows_get(rowoff[q]);
-            gprev = g;
-        } else {
-            StageUnit *obase = reinterpret_cast<StageUnit *>(out + t0 * dL);
-#pragma unroll
-            for (int q = 0; q < LQ; ++q)
-                if ((u32)q * 64u + lane < nt * Ud)
-                    obase[(u32)q * 64u + lane] = rows_get(rowoff[q]);
-        }
-        __syncthreads();
-    }
-    if (PIPE && gprev != ~0ull)
-        flush(gprev);
-}
-
-
 // ---------------------------------------------------------------------------------------
-// Bit-plane permutation, second form (round 2).  The first form above is bound by latency, not by
-// instruction count: its LDS image (term rows + planes + source table = 23.6 KB at N=1247, 72 KB at
-// N=4096) leaves 6 resp. 2 waves per CU, so one or two waves per SIMD sit out every LDS round trip and
-// DPP hazard of a 1 500-instruction turn.  Here the only LDS is the plane array itself (8 bytes per
-// term bit, 10 KB at N=1247):
-//   - no row staging: lane t reads ITS term's words straight from global memory (16 bytes per load,
-//     one term per lane; the 64 lines a load touches are re-used by the next loads of the turn out
-//     of L1/L2) and writes its permuted words straight back -- HBM still sees every line once;
-//   - the source-plane table lives in registers (the wave is persistent over groups of 64 terms);
-//   - W waves share one 64-term group and one plane array, each transposing every W-th word, so a
-//     big plane array (32 KB at N=4096) still keeps 16 waves on the CU.
-// Per turn: wait for the prefetched terms; words -> planes (one wave_transpose64 per word);
-// barrier; prefetch the next group; planes -> words through the source table; store; barrier.
-// ---------------------------------------------------------------------------------------
-template <int MAXI, int CI, int UW, int MAXT>
-__global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes2(u32 n_bits, u32 dL, u64 out_terms, u64 in_stride_words,
-                                                          const u64 *__restrict__ terms,
-                                                          const u32 *__restrict__ perm, u64 *__restrict__ out)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    u64 *planes = reinterpret_cast<u64 *>(smem_raw);         // dL*64 planes + one all-zero plane
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, W = blockDim.x >> 6;
-    const u32 NI = dL / UW;                                  // items (UW words) per term
-    const u32 none = dL * 64u;
-    const TrLane trc = tr_lane(lane);
-    typedef u64 StageUnit __attribute__((ext_vector_type(UW)));
-    const u64 groups = (out_terms + 63) / 64;
-
-    // byte offset in planes[] of the source of every output bit this lane will assemble:
-    // output word w, lane b <-> term bit j = 64*w + 63 - b  <-  old bit perm[j]
-    // (plane numbers, two 16-bit entries per register: dL <= 256 keeps them below 2^16)
-    constexpr int NS = (MAXI * UW + 1) / 2;
-    u32 srcpk[NS];
-#pragma unroll
-    for (int e = 0; e < NS; ++e)
-        srcpk[e] = 0;
-#pragma unroll
-    for (int k = 0; k < MAXI; ++k)
-#pragma unroll
-        for (int u = 0; u < UW; ++u) {
-            const u32 i = wave + (u32)k * W;
-            const u32 j = (i * UW + (u32)u) * 64u + 63u - lane;
-            u32 p = none;
-            if (i < NI && j < n_bits) {
-                p = perm[j];
-                if (p >= n_bits)
-                    p = none;
-            }
-            const int e = k * UW + u;
-            srcpk[e / 2] |= p << (16 * (e & 1));
-        }
-    if (tid == 0)
-        planes[none] = 0;
-
-    StageUnit v[MAXI];
-    auto fetch = [&](u64 g) {
-        const u64 t0 = g * 64;
-        const u32 nt = (u32)min((u64)64, out_terms - t0);
-        const u64 *base = terms + (t0 + min(lane, nt - 1u)) * in_stride_words;   // lanes past the end re-read the last term
-#pragma unroll
-        for (int k = 0; k < MAXI; ++k) {
-            const u32 i = min(wave + (u32)k * W, NI - 1u);
-            v[k] = *reinterpret_cast<const StageUnit *>(base + i * UW);
-        }
-    };
-
-    u64 g = blockIdx.x;
-    if (g < groups)
-        fetch(g);
-    __syncthreads();
-    for (; g < groups; g += gridDim.x) {
-        const u64 t0 = g * 64;
-        const u32 nt = (u32)min((u64)64, out_terms - t0);
-        // 1. my words of the 64 terms -> bit planes (CI items = CI*UW words in flight per transpose
-        //    batch; a shorter batch takes the remainder, so no word is transposed for nothing)
-        auto to_planes = [&](auto cn_tag, int c0) {
-            constexpr int CN = decltype(cn_tag)::value;
-            u32 h[2 * CN * UW];
-#pragma unroll
-            for (int c = 0; c < CN; ++c)
-#pragma unroll
-                for (int u = 0; u < UW; ++u) {
-                    const u64 x = v[c0 + c][u];
-                    h[2 * (c * UW + u)] = (u32)x;
-                    h[2 * (c * UW + u) + 1] = (u32)(x >> 32);
-                }
-            wave_transpose64_n<CN * UW>(h, trc);
-#pragma unroll
-            for (int c = 0; c < CN; ++c) {
-                const u32 i = wave + (u32)(c0 + c) * W;
-                if (i < NI) {                                // wave-uniform
-#pragma unroll
-                    for (int u = 0; u < UW; ++u)
-                        planes[(i * UW + (u32)u) * 64u + 63u - lane] =
-                            ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
-                }
-            }
-        };
-#pragma unroll
-        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
-            if (wave + (u32)c0 * W < NI)                     // wave-uniform: skip batches past my last item
-                to_planes(std::integral_constant<int, CI>(), c0);
-        if constexpr (MAXI % CI != 0)
-            if (wave + (u32)(MAXI / CI * CI) * W < NI)
-                to_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
-        __syncthreads();
-        // the next group's terms travel while this one is finished
-        if (g + gridDim.x < groups)
-            fetch(g + gridDim.x);
-        // 2. new bit j <- old bit perm[j]: gather planes, turn them back into words, store
-        u64 *orow = out + (t0 + lane) * dL;
-        auto from_planes = [&](auto cn_tag, int c0) {
-            constexpr int CN = decltype(cn_tag)::value;
-            u32 h[2 * CN * UW];
-#pragma unroll
-            for (int c = 0; c < CN; ++c)
-#pragma unroll
-                for (int u = 0; u < UW; ++u) {
-                    const int e = (c0 + c) * UW + u;
-                    const u32 pl = (e & 1) ? srcpk[e / 2] >> 16 : srcpk[e / 2] & 0xFFFFu;
-                    const u64 y = planes[pl];
-                    h[2 * (c * UW + u)] = (u32)y;
-                    h[2 * (c * UW + u) + 1] = (u32)(y >> 32);
-                }
-            wave_transpose64_n<CN * UW>(h, trc);
-#pragma unroll
-            for (int c = 0; c < CN; ++c) {
-                const u32 i = wave + (u32)(c0 + c) * W;
-                if (i < NI && lane < nt) {
-                    StageUnit o;
-#pragma unroll
-                    for (int u = 0; u < UW; ++u)
-                        o[u] = ((u64)h[2 * (c * UW + u) + 1] << 32) | h[2 * (c * UW + u)];
-                    *reinterpret_cast<StageUnit *>(orow + i * UW) = o;
-                }
-            }
-        };
-#pragma unroll
-        for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
-            if (wave + (u32)c0 * W < NI)
-                from_planes(std::integral_constant<int, CI>(), c0);
-        if constexpr (MAXI % CI != 0)
-            if (wave + (u32)(MAXI / CI * CI) * W < NI)
-                from_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
-        __syncthreads();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Bit-plane permutation, third form: the second form's LDS economy (ONE array, W waves per 64-term
-// group, source table in registers) with the first form's coalesced HBM access.  The one LDS array is
-// used in turn as term rows (coalesced 16-byte units in, one word per lane out), as bit planes, and
+// Bit-plane permutation kernel.  ONE LDS array per 64-term group, W waves per group, the source table
+// in registers, coalesced HBM access.  (Two earlier forms -- rows, planes and table all in LDS with one
+// wave per group; and no row staging at all -- measured slower, 3.6 / 3.1-3.9 TB/s against 4.9-5.0, and
+// were removed in round 3; DESIGN 4.6 keeps the numbers, the history keeps the code.)  The one LDS array
+// is used in turn as term rows (coalesced 16-byte units in, one word per lane out), as bit planes, and
 // as term rows again for the way back; what has to survive a change of role waits in registers.
 //   A  prefetched units -> rows          B  rows -> my words (lane = term)
 //   C  words -> planes (transposes)          [next group's loads are issued here]
@@ -705,11 +394,10 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
     if (out_terms == 0)
         return hipSuccess;
     const u64 stride = per_term ? dL : terms_in * dL;
-    // bit-plane form, round 2 (k_permute_planes2): planes only in LDS, W waves per 64-term group
-    if (terms_in != 0 && out_terms >= 16 && dL <= 256 && !tune(TUNE_PERM_BALLOT) && tune(TUNE_PERM_V1) != 1) {
-        // knob perm_v1: 0 = third form (coalesced, one LDS array), 1 = first form, 2 = second form (direct access)
-        const bool v3 = tune(TUNE_PERM_V1) != 2;
-        const size_t lds = std::max<size_t>(((size_t)dL * 64 + 1) * 8, v3 ? (size_t)(64 * (dL | 1) * 8) : (size_t)0);
+    // bit-plane kernel: one LDS array per 64-term group, W waves per group (knob perm_ballot forces the
+    // ballot form below, which also takes batches under 16 terms and dL > 256)
+    if (terms_in != 0 && out_terms >= 16 && dL <= 256 && !tune(TUNE_PERM_BALLOT)) {
+        const size_t lds = std::max<size_t>(((size_t)dL * 64 + 1) * 8, (size_t)(64 * (dL | 1) * 8));
         int cus = 256;
         {
             int dev = 0;
@@ -723,7 +411,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         // LDS comes in 1 KiB granules; aim at ~16 waves per CU
         const u32 groups_per_cu = std::max<u32>(1u, (u32)((160u * 1024u) / ((lds + 1023) / 1024 * 1024)));
         // Waves per group.  At least enough to put ~16 waves on the CU and to keep a wave's items
-        // within its register budget (third form: 4 items = 112 VGPRs; second: 8); among the
+        // within its register budget (4 items = 112 VGPRs); among the
         // admissible counts the one that wastes the fewest transposes -- every wave runs whole
         // batches of CI items and the group waits for its slowest wave, so the cost of a choice is
         // W * roundup(ceil(NI/W), CI) transposed items for NI useful ones.  N=1247 (10 items): 5 waves
@@ -734,7 +422,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
             return mx;
         };
         u32 w_min = std::max<u32>(1u, (16u + groups_per_cu - 1) / groups_per_cu);
-        w_min = std::max<u32>(w_min, v3 ? (NI + 3u) / 4u : (NI + 7u) / 8u);
+        w_min = std::max<u32>(w_min, (NI + 3u) / 4u);
         w_min = std::min<u32>(w_min, std::min<u32>(16u, NI));
         u32 W = w_min;
         {
@@ -795,13 +483,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         KERNEL<MAXI, CI, UWV, MAXT><<<grid_for(asked_occ), 64u * W, lds, s>>>((u32)n_bits, (u32)dL, out_terms, \
                                                                               stride, terms, perm, out);  \
     } while (0)
-#define CSGN_PLANES2_T(MAXI, CI, UWV, MAXT)                              \
-    do {                                                                 \
-        if (v3)                                                          \
-            CSGN_PLANES_K(k_permute_planes3, MAXI, CI, UWV, MAXT);       \
-        else                                                             \
-            CSGN_PLANES_K(k_permute_planes2, MAXI, CI, UWV, MAXT);       \
-    } while (0)
+#define CSGN_PLANES2_T(MAXI, CI, UWV, MAXT) CSGN_PLANES_K(k_permute_planes3, MAXI, CI, UWV, MAXT)
 #define CSGN_PLANES2(MAXI, CI, UWV)                 \
     do {                                            \
         if (W == 1)                                 \
@@ -841,82 +523,6 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
 #undef CSGN_PLANES_K
         if (per_wave <= 10)
             return hipGetLastError();
-    }
-    // bit-plane form, round 1 (64 terms per wave, LDS row staging; knob perm_v1) unless the batch is too
-    // small to fill a wave or the LDS image (rows + planes) would not fit; knob perm_ballot forces the ballot form
-    {
-        const u64 dLp = (dL + kPermUnroll - 1) / kPermUnroll * kPermUnroll;
-        const size_t lds = ((size_t)64 * (dLp | 1) + dLp * 64 + 1) * 8 + dLp * 64 * 2;
-        if (terms_in != 0 && out_terms >= 16 && dL <= 64 && lds <= 160 * 1024 && !tune(TUNE_PERM_BALLOT)) {
-            const u64 groups = (out_terms + 63) / 64;
-            // persistent waves: as many as the chip holds at once, equal group counts per wave
-            int cus = 256;
-            {
-                int dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess)
-                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            }
-            // 16-byte staging accesses when every term starts 16-byte aligned
-            const bool wide = dL % 2 == 0 && stride % 2 == 0 && (((uintptr_t)terms | (uintptr_t)out) & 15) == 0 &&
-                              !tune(TUNE_PERM_NARROW);
-            const u32 Ud = (u32)(wide ? dL / 2 : dL);
-            const FastDiv dUd = csgn_fastdiv_make(Ud);
-#define CSGN_PLANES_LAUNCH(LQ, PIPE, UW)                                                            \
-    do {                                                                                            \
-        if (lds > 65536) {      /* beyond the default dynamic-LDS window (N > ~3500 bits) */        \
-            hipError_t e = hipFuncSetAttribute(                                                     \
-                reinterpret_cast<const void *>(&k_permute_planes<LQ, PIPE, UW>),                    \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            if (e != hipSuccess)                                                                    \
-                return e;                                                                           \
-        }                                                                                           \
-        /* how many of these waves a CU really holds: the runtime's answer, and LDS handed out in  \
-           granules (measured: 7 x 23.3 KB is reported to fit 160 KB but the seventh wave runs after \
-           the other six).  A wave beyond that number would start when the rest have finished. */   \
-        static thread_local size_t asked_lds = 0;     /* the query is remembered per kernel and LDS size */ \
-        static thread_local int asked_per_cu = 0;                                                   \
-        if (asked_lds != lds) {                                                                     \
-            int q = 0;                                                                              \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_permute_planes<LQ, PIPE, UW>, 64, \
-                                                             lds) != hipSuccess || q < 1)           \
-                q = 1;                                                                              \
-            asked_per_cu = q;                                                                       \
-            asked_lds = lds;                                                                        \
-        }                                                                                           \
-        int per_cu = asked_per_cu;                                                                  \
-        per_cu = std::max(1, std::min(per_cu, (int)(160 * 1024 / ((lds + 1023) / 1024 * 1024))));   \
-        if (const int cap = tune(TUNE_PERM_WAVES))                                          \
-            per_cu = std::min(per_cu, cap);                                                         \
-        const u64 resident = (u64)cus * (u64)per_cu;                                                \
-        const u64 rounds = (groups + resident - 1) / resident;                                      \
-        const u32 grid = (u32)((groups + rounds - 1) / rounds);                                     \
-        k_permute_planes<LQ, PIPE, UW><<<grid, 64, lds, s>>>(n_bits, (u32)dL, dUd, out_terms,       \
-                                                             stride, terms, perm, out);             \
-    } while (0)
-            if (wide) {
-                if (Ud <= 4)
-                    CSGN_PLANES_LAUNCH(4, true, 2);
-                else if (Ud <= 10)
-                    CSGN_PLANES_LAUNCH(10, true, 2);
-                else if (Ud <= 16)
-                    CSGN_PLANES_LAUNCH(16, true, 2);
-                else
-                    CSGN_PLANES_LAUNCH(32, false, 2);
-            } else {
-                if (Ud <= 4)
-                    CSGN_PLANES_LAUNCH(4, true, 1);
-                else if (Ud <= 8)
-                    CSGN_PLANES_LAUNCH(8, true, 1);
-                else if (Ud <= 20)
-                    CSGN_PLANES_LAUNCH(20, true, 1);
-                else if (Ud <= 32)
-                    CSGN_PLANES_LAUNCH(32, true, 1);
-                else
-                    CSGN_PLANES_LAUNCH(64, false, 1);
-            }
-#undef CSGN_PLANES_LAUNCH
-            return hipGetLastError();
-        }
     }
     // terms per workgroup: a multiple of the 4 waves, LDS image <= 32 KB
     u32 tb = 64;

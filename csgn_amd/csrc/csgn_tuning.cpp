@@ -1,7 +1,6 @@
 // csgn_tuning.cpp -- storage of the tuning knobs (csgn_tuning.h).  Host code only.
 #include "csgn_tuning.h"
 
-#include <atomic>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -21,14 +20,29 @@ const Knob kKnobs[TUNE_COUNT] = {
     {"mul_m", 0},        {"mul_ti", 4},        {"mul_nt", 1},        {"mul_flat", 0},
     {"mul_bs", 0},       {"mul_xcd", 1},       {"mul_touch", -1},    {"mul_pf_kb", -1},
     {"stream_xcd", -1},  {"ragged_c", 0},      {"ragged_flat", 0},   {"ragged_pf", 32},
-    {"ragged_touch", 1}, {"ragged_table", 0},  {"ragged_m", 4},      {"ragged_rec", 0},    {"perm_ballot", 0},   {"perm_narrow", 0},
-    {"perm_waves", 0},   {"perm_v1", 0},       {"perm_persist", 1},  {"dec_loop", 0},
+    {"ragged_touch", 1}, {"ragged_m", 4},      {"perm_ballot", 0},   {"perm_narrow", 0},
+    {"perm_waves", 0},   {"perm_persist", 1},  {"dec_loop", 0},
     {"enc_lds", 0},      {"enc_wave", 1},      {"enc_compact", -1},
 };
 
-std::atomic<int> g_value[TUNE_COUNT];
+// Knob values are PER HOST THREAD: a thread that sets a knob changes the dispatch of its own later
+// calls only, so the one-host-thread-per-GPU callers of the C ABI (include/csgn_hip.h, "thread
+// safety") cannot alter one another's kernels in mid-stream (round 2 kept them in
+// process-wide atomics).  A thread's first use copies the defaults + the environment snapshot.
+struct ThreadKnobs {
+    bool ready = false;
+    int v[TUNE_COUNT];
+};
+thread_local ThreadKnobs t_knobs;
 int g_env_value[TUNE_COUNT];
 bool g_env_set[TUNE_COUNT];
+
+int *values()
+{
+    if (!t_knobs.ready)
+        tune_reset();                    // first use on this thread: defaults + the environment snapshot
+    return t_knobs.v;
+}
 
 // The one place the environment is read: when the library is loaded, before any entry point can
 // be called.
@@ -43,7 +57,6 @@ struct EnvSnapshot {
             g_env_set[k] = v && *v;
             g_env_value[k] = g_env_set[k] ? atoi(v) : 0;
         }
-        tune_reset();
     }
 };
 EnvSnapshot g_snapshot;
@@ -60,7 +73,7 @@ int find(const char *name)
 
 } // namespace
 
-int tune(TuneKey k) { return g_value[k].load(std::memory_order_relaxed); }
+int tune(TuneKey k) { return values()[k]; }
 
 const char *tune_name(int k) { return (k >= 0 && k < TUNE_COUNT) ? kKnobs[k].name : nullptr; }
 
@@ -69,7 +82,7 @@ bool tune_set(const char *name, int value)
     const int k = find(name);
     if (k < 0)
         return false;
-    g_value[k].store(value, std::memory_order_relaxed);
+    values()[k] = value;
     return true;
 }
 
@@ -78,14 +91,15 @@ bool tune_get(const char *name, int *value)
     const int k = find(name);
     if (k < 0)
         return false;
-    *value = g_value[k].load(std::memory_order_relaxed);
+    *value = values()[k];
     return true;
 }
 
 void tune_reset()
 {
+    t_knobs.ready = true;
     for (int k = 0; k < TUNE_COUNT; ++k)
-        g_value[k].store(g_env_set[k] ? g_env_value[k] : kKnobs[k].dflt, std::memory_order_relaxed);
+        t_knobs.v[k] = g_env_set[k] ? g_env_value[k] : kKnobs[k].dflt;
 }
 
 } // namespace csgn

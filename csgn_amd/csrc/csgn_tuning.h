@@ -1,6 +1,7 @@
 // csgn_tuning.h -- the library's tuning knobs (kernel choice and sweep parameters).
 //
-// Every knob is one process-wide atomic int.  Its start value is the built-in default, or the
+// Every knob is one int PER HOST THREAD (thread_local): setting it changes the calling thread's later
+// dispatches and nobody else's.  Its start value in every thread is the built-in default, or the
 // value of the environment variable CSGN_<KEY IN CAPITALS> sampled ONCE when libcsgn_hip.so is
 // loaded; after that only csgn_set_tuning()/csgn_reset_tuning() (include/csgn_hip.h) change it.
 // No compute entry point reaches getenv.  Knobs select among kernels that compute the same
@@ -23,14 +24,11 @@ enum TuneKey {
     TUNE_RAGGED_FLAT,    // 1 = never use the tiled kernel for ragged batches
     TUNE_RAGGED_PF,      // ragged multiply: operand prefetch distance in pairs, 0 = off
     TUNE_RAGGED_TOUCH,   // ragged multiply: 1 = touch pass per 1 GiB output slice
-    TUNE_RAGGED_TABLE,   // ragged multiply, indexed form (pair-of-every-32nd-term table; measured SLOWER than the searching kernel, kept as an experiment): 0 = off (default), 1 = on for outputs >= 32 MB, 2/4/8 = units per lane, negative = no size threshold
     TUNE_RAGGED_M,       // flat ragged multiply: 4 KiB chunks per turn that share one speculative pair lookup and whose operand loads travel together: 1, 2 or 4
-    TUNE_RAGGED_REC,     // ragged multiply, record form (32-byte record per pair: offsets + division constants; measured no faster than the searching kernel, kept as an experiment): 0 = never (default), 1 = outputs >= 8 MB, -1 = always
     TUNE_PERM_BALLOT,    // 1 = ballot bit-gather permutation kernel instead of the bit-plane kernel
     TUNE_PERM_NARROW,    // 1 = 8-byte staging accesses in the bit-plane kernel
-    TUNE_PERM_WAVES,     // first form: cap on waves per CU; second/third form: waves per 64-term group; 0 = auto
-    TUNE_PERM_V1,        // bit-plane kernel: 0 = third form (default), 1 = first form (round 1), 2 = second form (direct access)
-    TUNE_PERM_PERSIST,   // second/third form: 1 = persistent workgroups striding over the groups, 0 = one group per workgroup, k > 1 = k groups per CU resident
+    TUNE_PERM_WAVES,     // bit-plane kernel: waves per 64-term group; 0 = auto
+    TUNE_PERM_PERSIST,   // bit-plane kernel: 1 = persistent workgroups striding over the groups, 0 = one group per workgroup, k > 1 = k groups per CU resident
     TUNE_DEC_LOOP,       // 1 = looping 256-term decrypt pass 1 instead of the segment form
     TUNE_ENC_LDS,        // 1 = LDS-staged encrypt kernel instead of the segment form
     TUNE_ENC_WAVE,       // device-RNG encrypt: 1 = wave-local kernel (default), 0 = segment kernel
@@ -38,7 +36,7 @@ enum TuneKey {
     TUNE_COUNT
 };
 
-int tune(TuneKey k);                      // relaxed atomic load
+int tune(TuneKey k);                      // the calling thread's value
 const char *tune_name(int k);             // "mul_m", ... (nullptr past the end)
 bool tune_set(const char *name, int value);
 bool tune_get(const char *name, int *value);

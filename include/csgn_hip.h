@@ -229,7 +229,9 @@ int csgn_encrypt_explicit(uint64_t n_bits, uint64_t d, uint64_t batch,
  * position is drawn; plaintext 1 ORs the key mask in; for plaintext 0, if all D secret positions
  * came out 1, position s[draw % D] is cleared (equivalent to src/SecretKey.cpp:51-76: draw the
  * position first, force it to 0 when all the others are 1) -- unless the key has a single distinct
- * position, which the reference never clears either.
+ * position, which the reference never clears either.  `draw` comes from a second stream of the same
+ * (key, nonce) whose ChaCha constants are "csgn draw pos v1" instead of "expand 32-byte k": no nonce
+ * makes it coincide with a keystream.
  *   h_rng              key/nonce/rounds (host struct; fill with csgn_rng_from_os for real use)
  *   first_ciphertext   GLOBAL index of d_plain[0] / d_out[0] in the (key, nonce) stream: ciphertext
  *                      c always draws the same words whatever batch or shard it is encrypted in
@@ -354,13 +356,19 @@ int csgn_circuit_permute(csgn_circuit *circuit, uint32_t a, const uint32_t *d_pe
  * end to end) replays as ONE graph launch.  d_plain (batch bytes), d_key (D indices) and d_mask stay
  * the caller's and must remain valid; rewrite d_plain between runs to encrypt other bits.  Element i
  * of run r (r = 1, 2, ...; csgn_circuit_epoch after csgn_circuit_run) draws stream position
- * first_ciphertext + i of the generator (h_rng->key, h_rng->nonce + r): the graph's first node
- * increments the run counter on the device, so no replay re-uses a keystream.  Give every encrypt
- * node of a circuit its own first_ciphertext range (or its own nonce). */
+ * first_ciphertext + i of the generator (node key, nonce = r), where the NODE KEY is derived here,
+ * on the host, from (h_rng->key, h_rng->nonce) -- csgn_circuit_node_key -- and the nonce words carry
+ * nothing but the run number: the graph's first node increments the run counter on the device, so no
+ * replay re-uses a keystream, and no choice of nonce by the caller can make one node's run r the run
+ * r' of another.  Give every encrypt node of a circuit its own first_ciphertext range (or its own
+ * h_rng->nonce). */
 int csgn_circuit_encrypt(csgn_circuit *circuit, uint64_t d, const uint8_t *d_plain, const uint64_t *d_key,
                          const uint64_t *d_mask, const csgn_rng *h_rng, uint64_t first_ciphertext,
                          uint32_t *value);
 uint64_t csgn_circuit_epoch(const csgn_circuit *circuit);      /* runs launched so far */
+/* The key a circuit encrypt node built from *h_rng encrypts under: words 0..7 of the ChaCha20 block
+ * (constants "csgn node key v1", key = h_rng->key, nonce = h_rng->nonce, counter 0).  Host only. */
+int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8]);
 int csgn_circuit_build(csgn_circuit *circuit);
 uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
 uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);      /* per element; 0 for a ragged value */
@@ -382,8 +390,10 @@ const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1
  * each).  A knob's start value is its built-in default or the environment variable
  * CSGN_<KEY IN CAPITALS>, sampled ONCE when the library is loaded: no compute entry point reads
  * the environment.  Knobs choose among kernels that produce the same words; results never depend
- * on them.  They are process-wide atomics: set them before launching work from other threads.
- * A circuit (csgn_circuit_build) bakes in the values current at build time. */
+ * on them.  They are PER HOST THREAD: csgn_set_tuning changes the dispatch of the calling thread's own
+ * later calls and of no other thread's (every thread starts from the defaults + the environment
+ * snapshot), so concurrent one-thread-per-GPU callers cannot switch one another's kernels.
+ * A circuit (csgn_circuit_build) bakes in the building thread's values at build time. */
 int csgn_set_tuning(const char *key, int value);
 int csgn_get_tuning(const char *key, int *h_value);
 void csgn_reset_tuning(void);            /* defaults + the environment snapshot taken at load */

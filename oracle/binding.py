@@ -107,6 +107,8 @@ class Oracle:
         L.csgn_oracle_add.argtypes = [u64p, u64, u64p, u64p, u64, u64p, u64p, u64p]
         L.csgn_oracle_keygen.restype = i64
         L.csgn_oracle_keygen.argtypes = [u64, u64, i32p, u64, u64p]
+        L.csgn_oracle_node_key.restype = None
+        L.csgn_oracle_node_key.argtypes = [C.c_void_p, u64, C.c_void_p]
         L.csgn_oracle_key_mask.restype = None
         L.csgn_oracle_key_mask.argtypes = [u64, u64p, u64, u64p]
         L.csgn_oracle_encrypt.restype = i64
@@ -233,6 +235,13 @@ class Oracle:
         nonce = u64(0)
         self.lib.csgn_oracle_rng_from_seed(seed & (2**64 - 1), k.ctypes.data, C.byref(nonce))
         return k, int(nonce.value)
+
+    def node_key(self, rng_key, nonce: int) -> np.ndarray:
+        """Key of a circuit encrypt node built from (rng_key, nonce): csgn_circuit_node_key."""
+        k = np.ascontiguousarray(np.asarray(rng_key, dtype=np.uint32))
+        out = np.zeros(8, dtype=np.uint32)
+        self.lib.csgn_oracle_node_key(k.ctypes.data, nonce & (2**64 - 1), out.ctypes.data)
+        return out
 
     def keyed_layout(self, n_bits: int):
         a, b, c = u64(0), u64(0), u64(0)

@@ -311,11 +311,16 @@ int64_t csgn_oracle_encrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
     a += b; d ^= a; d = ROTL32(d, 8);     \
     c += d; b ^= c; b = ROTL32(b, 7)
 
-void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t counter,
-                              unsigned rounds, uint32_t out[16])
+/* ChaCha block with the 16 constant bytes given as text: "expand 32-byte k" is Bernstein's own (the
+ * keystream); "csgn draw pos v1" gives the stream the plaintext-0 rule draws its position from,
+ * "csgn node key v1" (20 rounds) the key of a circuit's encrypt node (include/csgn_hip.h). */
+static void chacha_block_sigma(const char sigma[16], const uint32_t key[8], uint64_t nonce, uint64_t counter,
+                               unsigned rounds, uint32_t out[16])
 {
     uint32_t in[16], x[16];
-    in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+    for (int i = 0; i < 4; ++i)
+        in[i] = (uint32_t)(unsigned char)sigma[4 * i] | (uint32_t)(unsigned char)sigma[4 * i + 1] << 8 |
+                (uint32_t)(unsigned char)sigma[4 * i + 2] << 16 | (uint32_t)(unsigned char)sigma[4 * i + 3] << 24;
     for (int i = 0; i < 8; ++i)
         in[4 + i] = key[i];
     in[12] = (uint32_t)counter;
@@ -338,6 +343,20 @@ void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t co
 }
 #undef QR
 #undef ROTL32
+
+void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t counter,
+                              unsigned rounds, uint32_t out[16])
+{
+    chacha_block_sigma("expand 32-byte k", key, nonce, counter, rounds, out);
+}
+
+/* key of a circuit encrypt node built from (key, nonce): csgn_circuit_node_key */
+void csgn_oracle_node_key(const uint32_t key[8], uint64_t nonce, uint32_t node_key[8])
+{
+    uint32_t block[16];
+    chacha_block_sigma("csgn node key v1", key, nonce, 0, 20, block);
+    memcpy(node_key, block, 8 * sizeof(uint32_t));
+}
 
 void csgn_oracle_rng_from_seed(uint64_t seed, uint32_t key[8], uint64_t *nonce)
 {
@@ -405,10 +424,10 @@ void csgn_oracle_encrypt_keyed(uint64_t n_bits, uint64_t d, const uint64_t *key_
             o[k] = (plain[i] & 1u) ? (v | mask[k]) : v;
         }
         if (!(plain[i] & 1u) && all && secret_bits >= 2) {
-            /* all D secret positions came out 1: clear s[draw % D], draw = first word of the
-             * block (counter = c) of the stream whose nonce has its top bit flipped */
+            /* all D secret positions came out 1: clear s[draw % D], draw = first word of block c of
+             * the draw stream (same key and nonce, constants "csgn draw pos v1") */
             uint32_t x[16];
-            csgn_oracle_chacha_block(rng_key, nonce ^ 0x8000000000000000ull, c, rounds, x);
+            chacha_block_sigma("csgn draw pos v1", rng_key, nonce, c, rounds, x);
             uint64_t pos = key_idx[((uint64_t)x[0] * d) >> 32];
             o[pos / WORD_BITS] &= ~(1ull << (WORD_BITS - 1u - (unsigned)(pos % WORD_BITS)));
         }

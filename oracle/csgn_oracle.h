@@ -79,6 +79,9 @@ int64_t csgn_oracle_encrypt(uint64_t n_bits, uint64_t d, const uint64_t *key,
  * (include/csgn_hip.h), restated independently of the kernels. */
 void csgn_oracle_chacha_block(const uint32_t key[8], uint64_t nonce, uint64_t counter,
                               unsigned rounds, uint32_t out[16]);
+/* key of a circuit encrypt node (csgn_circuit_node_key of include/csgn_hip.h): words 0..7 of the
+ * ChaCha20 block with constants "csgn node key v1", counter 0 */
+void csgn_oracle_node_key(const uint32_t key[8], uint64_t nonce, uint32_t node_key[8]);
 void csgn_oracle_rng_from_seed(uint64_t seed, uint32_t key[8], uint64_t *nonce);
 void csgn_oracle_keyed_layout(uint64_t n_bits, uint64_t *units, uint64_t *passes, uint64_t *group);
 void csgn_oracle_encrypt_keyed(uint64_t n_bits, uint64_t d, const uint64_t *key_idx, uint64_t batch,

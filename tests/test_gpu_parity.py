@@ -899,16 +899,17 @@ def test_permute_all_word_counts(hip, oracle, n):
 
 
 @pytest.mark.parametrize("n", [1, 31, 63, 64, 65, 130, 1247, 1280, 1300, 4096, 4100, 8192, 10000, 16384])
-@pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot", "planes-v1", "planes-v2", "planes-v2-narrow", "planes-w1", "planes-w3", "planes-w16"])
+@pytest.mark.parametrize("form", ["planes", "planes-narrow", "ballot", "planes-w1", "planes-w3", "planes-w16", "planes-p0"])
 def test_permute_kernel_forms(hip, oracle, knobs, n, form):
     """Bit-plane form (64 terms per wave, 64x64 bit transposes; 16- and 8-byte staging) against
     the ballot form and the oracle, on batches that leave ragged last waves; strided first-term
     input and per-term mode."""
     knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
     knobs.set("CSGN_PERM_NARROW", "1" if form.endswith("narrow") else "0")
-    knobs.set("perm_v1", 1 if form.startswith("planes-v1") else 2 if form.startswith("planes-v2") else 0)
     if form.startswith("planes-w"):
         knobs.set("perm_waves", int(form[len("planes-w"):]))
+    if form == "planes-p0":
+        knobs.set("perm_persist", 0)                        # one 64-term group per workgroup
     dl = oracle.default_len(n)
     rng = np.random.default_rng(1000 + n)
     perm = rng.permutation(n).astype(np.uint64)
@@ -949,11 +950,10 @@ def test_permute_forms_fuzz(hip, oracle, knobs):
         per_term = bool(rng.integers(0, 2)) if terms_in > 1 else False
         W = hip.synth_fill(it, n, 0, batch * terms_in * dl)
         outs = []
-        for form in ("planes", "narrow", "ballot", "v1", "waves", "v2"):
+        for form in ("planes", "narrow", "ballot", "waves", "waves-narrow"):
             knobs.set("CSGN_PERM_BALLOT", "1" if form == "ballot" else "0")
-            knobs.set("CSGN_PERM_NARROW", "1" if form == "narrow" else "0")
-            knobs.set("perm_v1", 1 if form == "v1" else 2 if form == "v2" else 0)
-            knobs.set("perm_waves", int(rng.integers(1, 17)) if form == "waves" else 0)
+            knobs.set("CSGN_PERM_NARROW", "1" if form.endswith("narrow") else "0")
+            knobs.set("perm_waves", int(rng.integers(1, 17)) if form.startswith("waves") else 0)
             outs.append(hip.permute_uniform(n, batch, terms_in, W, dperm, per_term=per_term).clone())
         for o in outs[:2] + outs[3:]:
             assert torch.equal(o, outs[2]), (n, batch, terms_in, per_term)
@@ -1295,6 +1295,68 @@ def test_config3_depth10_chain_then_1024x1024(hip, oracle):
     assert hip.digest(prod[:1024 * 1024 * dl]) == oracle.digest(want)
 
 
+@pytest.mark.parametrize("dispatch", ["default", "tiled"])
+def test_config3_as_written_batch_4096_through_an_arena(hip, oracle, knobs, dispatch):
+    """BASELINE config 3 as it is written: batch = 4096 pairs of 1024-term x 1024-term operands, the
+    operands being depth-10 multiply chains (x <- x * (Enc(b) + Enc(b')), ten times, on fresh
+    ciphertexts), streamed through a small output arena (6 slots, so launches wrap and the last one is
+    partial).  Pair p's operands are the two chains of circuit p % 2 with their 1024 terms in a
+    per-pair order, so no two pairs multiply the same buffers.  EVERY product still in the arena at
+    the end is digested against the oracle (src/Ciphertext.cpp:146-163), once with the library's own
+    dispatch for this shape (operand touch pass + flat kernel) and once with the LDS-tiled kernel the
+    config names (knob mul_flat = -1)."""
+    import torch
+    n, d, dl, B, T, slots, B0 = 1247, 16, 20, 4096, 1024, 6, 2
+    if dispatch == "tiled":
+        knobs.set("mul_flat", -1)
+    want_kernel = "k_mul_tiled" if dispatch == "tiled" else "k_touch+k_mul_flat"
+    assert hip.lib.csgn_mul_uniform_kernel(n, B, T, T).decode() == want_kernel
+    key = make_key(n, d, 71)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    rng = np.random.default_rng(72)
+
+    def chain(seed):
+        per = 1 + 20
+        plain = rng.integers(0, 2, size=(per, B0)).astype(np.uint8)
+        fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), dkey, dmask, seed=seed)
+        inp = lambda i: fresh[i * B0 * dl:(i + 1) * B0 * dl]
+        x, xt = inp(0), 1
+        for level in range(10):
+            rhs = hip.add_uniform(n, B0, 1, 1, inp(1 + 2 * level), inp(2 + 2 * level))
+            x = hip.mul_uniform(n, B0, xt, 2, x, rhs)
+            xt *= 2
+        assert xt == T
+        return x.view(B0, T, dl)
+
+    ca, cb = chain(303), chain(404)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(73)
+    orders = torch.stack([torch.randperm(T, generator=gen) for _ in range(2 * B)]).to(hip.device)   # per pair and side
+    L = hip.empty_words(B * T * dl).view(B, T, dl)
+    R = hip.empty_words(B * T * dl).view(B, T, dl)
+    for c in range(B0):
+        sel = torch.arange(c, B, B0, device=hip.device)
+        L[sel] = ca[c][orders[sel]]
+        R[sel] = cb[c][orders[B + sel]]
+    per = T * T * dl
+    arena = hip.empty_words(slots * per)
+    arena.fill_(-1)
+    hip.mul_uniform(n, B, T, T, L.view(-1), R.view(-1), out=arena, out_slots=slots)
+    torch.cuda.synchronize()
+    # pair q lands in slot q % slots; launches of 6 pairs, the last one holds 4096 - 682*6 = 4 pairs
+    last_full = (B // slots) * slots
+    survivors = {q % slots: q for q in range(last_full - slots, B)}       # later pairs overwrite earlier ones
+    assert sorted(survivors) == list(range(slots)) and survivors[0] == last_full and survivors[slots - 1] == last_full - 1
+    for slot, q in survivors.items():
+        want, _ = oracle.mul(n, hip.download(L[q].reshape(-1)), hip.download(R[q].reshape(-1)))
+        assert hip.digest(arena[slot * per:(slot + 1) * per]) == oracle.digest(want), (dispatch, slot, q)
+    # the plaintext of every surviving product, from the materialised words and from the fused form
+    bits = hip.download(hip.decrypt_uniform(n, slots, T * T, arena, dmask))
+    qs = torch.tensor([survivors[s] for s in range(slots)], device=hip.device)
+    fused = hip.download(hip.decrypt_combined_uniform(n, slots, T, T, L[qs].reshape(-1), R[qs].reshape(-1), dmask, True))
+    assert np.array_equal(bits, fused)
+
+
 @pytest.mark.parametrize("n,d,seed", [(1247, 16, 1), (4096, 32, 2), (65, 4, 3), (63, 4, 4)])
 def test_fuzz_random_operation_sequences(hip, oracle, n, d, seed):
     """Seeded random walk over the whole C ABI: a pool of device-resident ciphertexts and its
@@ -1463,8 +1525,9 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
 def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, batch):
     """BASELINE configs 2 / 4 end to end as ONE hipGraph: two encrypt nodes (keyed generator writing
     straight into the circuit's block), c1*c0 and c1+c0, two decrypts.  Every replay must use a new
-    keystream (nonce + run number, bumped on the device); ciphertext words equal the restated
-    definition, bits equal the clear circuit."""
+    keystream: a node encrypts under its own derived key (csgn_circuit_node_key, restated in the oracle)
+    with nonce = run number, bumped on the device; ciphertext words equal the restated definition, bits
+    equal the clear circuit."""
     import ctypes as C
     import torch
     from csgn_amd.capi import check
@@ -1474,6 +1537,10 @@ def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, bat
     dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
     rng = hip.rng_from_seed(99, 8)
     rk, nonce = oracle.rng_from_seed(99)
+    nk = oracle.node_key(rk, nonce)
+    got_nk = (C.c_uint32 * 8)()
+    check(lib.csgn_circuit_node_key(C.byref(rng), got_nk))
+    assert list(got_nk) == [int(x) for x in nk] and list(got_nk) != [int(x) for x in rk]
     pa = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
     pb = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
     c = C.c_void_p()
@@ -1506,9 +1573,9 @@ def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, bat
         ca, cb = grab(va, 1), grab(vb, 1)
         sample = slice(0, min(batch, 3000) * dl)
         assert np.array_equal(hip.download(ca)[sample],
-                              oracle.encrypt_keyed(n, key, ha[:min(batch, 3000)], rk, nonce + run, 8))
+                              oracle.encrypt_keyed(n, key, ha[:min(batch, 3000)], nk, run, 8))
         assert np.array_equal(hip.download(cb)[sample],
-                              oracle.encrypt_keyed(n, key, hb[:min(batch, 3000)], rk, nonce + run, 8, first_ciphertext=first_b))
+                              oracle.encrypt_keyed(n, key, hb[:min(batch, 3000)], nk, run, 8, first_ciphertext=first_b))
         assert torch.equal(grab(vm, 1), ca & cb)                # src/Ciphertext.cpp:124-131
         both = grab(vs, 2).view(batch, 2 * dl)
         assert torch.equal(both[:, :dl].reshape(-1), ca) and torch.equal(both[:, dl:].reshape(-1), cb)
@@ -1680,25 +1747,16 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     dOL, dOR = hip.upload(offL), hip.upload(offR)
     knobs.set("CSGN_RAGGED_FLAT", "1")
     knobs.set("CSGN_RAGGED_TOUCH", "0")
-    knobs.set("ragged_table", 0)                                # the searching kernel, unsliced
-    knobs.set("ragged_rec", 0)
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
     ref = ref.clone()
     knobs.set("CSGN_RAGGED_TOUCH", "1")                         # ... sliced with the touch pass
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
-    knobs.set("ragged_rec", 0)
-    for tab, touch in ((1, 1), (1, 0), (8, 1)):                 # the indexed kernel (opt-in)
-        knobs.set("ragged_table", tab)
-        knobs.set("CSGN_RAGGED_TOUCH", touch)
+    for m, c in ((1, 8), (2, 2), (4, 4)):                       # chunks per turn / per workgroup
+        knobs.set("ragged_m", m)
+        knobs.set("ragged_c", c)
         out, off = hip.mul_ragged(n, L, dOL, R, dOR)
-        assert torch.equal(out, ref) and torch.equal(off, ref_off), (tab, touch)
-    knobs.set("ragged_table", 0)
-    for rec, touch in ((1, 1), (1, 0)):                         # the record kernel (default for this size)
-        knobs.set("ragged_rec", rec)
-        knobs.set("CSGN_RAGGED_TOUCH", touch)
-        out, off = hip.mul_ragged(n, L, dOL, R, dOR)
-        assert torch.equal(out, ref) and torch.equal(off, ref_off), ("rec", touch)
+        assert torch.equal(out, ref) and torch.equal(off, ref_off), (m, c)
     mo = hip.download(off)
     assert np.array_equal(mo, csr((t1s * t2s).tolist()))
     cut_term = (1 << 26) // 10                                  # first term of the second slice
@@ -1711,23 +1769,33 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
 
 
 def test_ragged_forms_fuzz(hip, oracle, knobs):
-    """30 random CSR batches (empty operands, runs of empty pairs, one large pair among small
-    ones) through the flat ragged multiply and add with 1 / 8 / 16 chunks per workgroup and operand
-    prefetch off / 32 / 5000 pairs ahead, through the indexed multiply (side table, 2 / 4 / 8 units
-    per lane) and through the default dispatch: identical words; every fifth batch is compared pair
-    by pair with the oracle."""
+    """36 random CSR batches (empty operands, runs of empty pairs -- some longer than the 256-pair
+    offset window of the flat kernels -- one large pair among small ones, all-singles and all-equal
+    batches that the default dispatch hands to the uniform kernels) through the flat ragged multiply
+    and add with 1 / 2 / 8 / 16 chunks per workgroup, 1 / 2 / 4 chunks per turn and operand prefetch
+    off / 32 / 5000 pairs ahead, and through the default dispatch: identical words; every fifth batch
+    is compared pair by pair with the oracle."""
     import torch
     rng = np.random.default_rng(4242 + FUZZ_SEED)
-    for it in range(30):
+    for it in range(36):
         n = int(rng.choice([65, 1247, 1300, 4096]))
         dl = oracle.default_len(n)
-        batch = int(rng.choice([1, 7, 300, 2500]))
+        batch = int(rng.choice([1, 7, 300, 2500, 9000]))
         t1s = rng.integers(0, 9, size=batch)
         t2s = rng.integers(0, 9, size=batch)
         if it % 3 == 0:
             t1s[rng.integers(0, batch)], t2s[rng.integers(0, batch)] = 200, 150
         if it % 4 == 0 and batch > 600:
-            t1s[100:600] = 0                                   # a run of empty pairs longer than a workgroup
+            t1s[100:600] = 0                                   # a run of empty pairs longer than a workgroup's offset window
+        if it % 6 == 1:
+            t1s[:] = 1                                         # all singles: 1x1 products, 1+1 sums
+            t2s[:] = 1
+        if it % 6 == 4:
+            t1s[:] = int(rng.integers(1, 6))                   # all pairs of one shape: a uniform batch in CSR clothes
+            t2s[:] = int(rng.integers(1, 6))
+        if it % 9 == 5 and batch > 2000:
+            t1s[:] = (rng.integers(0, 40, size=batch) == 0)    # singles thinly spread among empty pairs
+            t2s[:] = 1
         if not int(np.sum(t1s * t2s)):
             t1s[0] = t2s[0] = 2
         offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
@@ -1739,17 +1807,11 @@ def test_ragged_forms_fuzz(hip, oracle, knobs):
         for env in ({}, {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "1", "CSGN_RAGGED_PF": "0"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "8", "CSGN_RAGGED_PF": "32"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_C": "16", "CSGN_RAGGED_PF": "5000"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-4"},          # indexed form, whatever the size
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-2"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "-8"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_TABLE": "0"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1"},            # record form, whatever the size
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "-1", "CSGN_RAGGED_C": "1"},
-                    {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_REC": "0"},
+                    {"CSGN_RAGGED_FLAT": "1"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "1", "CSGN_RAGGED_C": "8"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "2", "CSGN_RAGGED_C": "2"},
                     {"CSGN_RAGGED_FLAT": "1", "CSGN_RAGGED_M": "4", "CSGN_RAGGED_C": "16"}):
-            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_TABLE", "CSGN_RAGGED_REC", "CSGN_RAGGED_M"):
+            for k in ("CSGN_RAGGED_FLAT", "CSGN_RAGGED_C", "CSGN_RAGGED_PF", "CSGN_RAGGED_M"):
                 knobs.unset(k)
             for k, v in env.items():
                 knobs.set(k, v)
@@ -1801,10 +1863,13 @@ def test_decrypt_ragged_skewed(hip, oracle):
     n, d = 1247, 16
     key = make_key(n, d, 77)
     dmask = hip.upload(hip.key_mask(n, key))
-    counts = [3, 0, 100000, 1, 4096, 4097, 0, 0, 7, 70000, 2]
-    parts = [planted(oracle, n, key, t, (t * 7 + i) % (t + 1), 300 + i) if t else np.zeros(0, np.uint64)
-             for i, t in enumerate(counts)]
-    bits = hip.download(hip.decrypt_ragged(n, hip.upload(np.concatenate(parts)), hip.upload(csr(counts)), dmask))
-    for i, t in enumerate(counts):
-        want = oracle.decrypt_canonical(n, key, parts[i]) if t else 0
-        assert bits[i] == want == (((t * 7 + i) % (t + 1)) % 2 if t else 0), i
+    # long ciphertexts are folded in 65 536-term chunks from a device-side work list: lengths around the
+    # long/short threshold (4096) and around one and several chunks, at bit offsets that are not word-aligned
+    for counts in ([3, 0, 100000, 1, 4096, 4097, 0, 0, 7, 70000, 2],
+                   [5, 65536, 1, 65537, 0, 131072, 9, 131073, 65535, 3, 200001, 1]):
+        parts = [planted(oracle, n, key, t, (t * 7 + i) % (t + 1), 300 + i) if t else np.zeros(0, np.uint64)
+                 for i, t in enumerate(counts)]
+        bits = hip.download(hip.decrypt_ragged(n, hip.upload(np.concatenate(parts)), hip.upload(csr(counts)), dmask))
+        for i, t in enumerate(counts):
+            want = oracle.decrypt_canonical(n, key, parts[i]) if t else 0
+            assert bits[i] == want == (((t * 7 + i) % (t + 1)) % 2 if t else 0), (counts, i)

@@ -23,11 +23,10 @@ for n, batch in [(1247, 1 << 20), (1247, 1 << 22), (1247, 1 << 16), (4096, 1 << 
     W = hip.synth_fill(3, n, 0, batch * dl)
     perm = hip.upload(np.random.default_rng(3).permutation(n).astype(np.uint32))
     row = []
-    for form in ("planes3", "planes3/p4", "planes3/p6", "planes3/p8", "planes3/narrow", "planes2", "planes-v1", "ballot") * 2:
+    for form in ("planes3", "planes3/p4", "planes3/p6", "planes3/p8", "planes3/narrow", "ballot") * 2:
         capi.reset_tuning()
         capi.set_tuning("perm_ballot", form == "ballot")
         capi.set_tuning("perm_narrow", form.endswith("narrow"))
-        capi.set_tuning("perm_v1", 1 if form == "planes-v1" else 2 if form.startswith("planes2") else 0)
         for part in form.split("/")[1:]:
             if part[0] == "w":
                 capi.set_tuning("perm_waves", int(part[1:]))

@@ -76,6 +76,21 @@ for n, d in [(1247, 16), (4096, 32)]:
         report(f"mul {t1}x{t2} N={n} batch={batch}", batch, "mult", batch * 8 * dl * (t1 + t2 + t1 * t2),
                lambda: hip.mul_uniform(n, batch, t1, t2, L, R, out=out))
         del L, R, out
+    if n == 1247:
+        # BASELINE config 3's kernel by name: the LDS-tiled all-pairs kernel at 1024x1024 (the default dispatch
+        # for this shape is touch + flat, timed by bench.py; knob mul_flat = -1 selects the tiled one)
+        from csgn_amd import capi
+        t1 = t2 = 1024
+        batch = 64
+        L = hip.synth_fill(1, n, 0, batch * t1 * dl)
+        R = hip.synth_fill(2, n, 0, batch * t2 * dl)
+        out = hip.empty_words(batch * t1 * t2 * dl)
+        capi.set_tuning("mul_flat", -1)
+        assert hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode() == "k_mul_tiled"
+        report(f"mul {t1}x{t2} N={n} batch={batch} [k_mul_tiled, LDS]", batch, "mult", batch * 8 * dl * (t1 + t2 + t1 * t2),
+               lambda: hip.mul_uniform(n, batch, t1, t2, L, R, out=out))
+        capi.reset_tuning()
+        del L, R, out
     # add (concatenation)
     for (t1, t2, batch) in [(1, 1, 1 << 20), (1024, 1024, 1024)]:
         L = hip.synth_fill(1, n, 0, batch * t1 * dl)

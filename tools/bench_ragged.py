@@ -10,7 +10,7 @@ NSETS=[3]
 VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_RAGGED_TOUCH':'0'}),
           ('cold C=1',{'CSGN_RAGGED_C':'1'}),('cold C=2',{'CSGN_RAGGED_C':'2'}),('cold C=4',{'CSGN_RAGGED_C':'4'}),('cold C=4 M=2',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'2'}),('cold C=4 M=1',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'1'}),
           ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
-          ('record form: cold',{'CSGN_RAGGED_REC':'1'}),('indexed M=8: cold',{'CSGN_RAGGED_TABLE':'8'})]
+          ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     fn(); torch.cuda.synchronize(); ts=[]
@@ -74,7 +74,13 @@ for name,t1s,t2s in [
         t=timed(lambda: hip.add_ragged(n,L,dL_,R,dR_, total_terms_out=tot))
         row.append(f"C={ch}: {alg/t/1e9:6.0f}")
     print(f"add_ragged {name:<32} GB/s (alloc + kernel)   " + "  ".join(row), flush=True)
-    del L,R
+    # the add kernels alone (output and offsets preallocated; k_off_sum + the CSR kernel), default knobs
+    capi.reset_tuning()
+    aout, aoff = hip.empty_words(tot*dl), hip.empty_words(len(t1s)+1)
+    t=timed(lambda: check(hip.lib.csgn_add_ragged(n,len(t1s),L.data_ptr(),dL_.data_ptr(),R.data_ptr(),dR_.data_ptr(),
+                                                  aout.data_ptr(),aoff.data_ptr(),tot,hip.stream)), rounds=9)
+    print(f"add_ragged {name:<32} kernels only: {alg/t/1e9:6.0f} GB/s ({100*alg/t/8e12:4.1f}% of peak, {t*1e6:7.1f} us)", flush=True)
+    del L,R,aout,aoff
 
 # ragged decrypt: term lists of skewed lengths (the products of the batches above have this shape)
 key = np.random.default_rng(1).permutation(n)[:16].astype(np.uint64)
@@ -91,4 +97,10 @@ for name, ts in [
     doff = hip.upload(off)
     t = timed(lambda: hip.decrypt_ragged(n, W, doff, dmask, total_terms=tot))
     print(f"decrypt_ragged {name:<34} {t*1e3:8.3f} ms  {tot*dl*8/t/1e9:8.1f} GB/s ({100*tot*dl*8/t/8e12:4.1f}% of peak), {tot*dl*8/1e6:.0f} MB", flush=True)
+    # kernels only (bits and scratch preallocated)
+    bits = torch.empty(len(ts), dtype=torch.uint8, device=hip.device)
+    scratch = torch.empty(int(hip.lib.csgn_decrypt_scratch_bytes(len(ts), tot)), dtype=torch.uint8, device=hip.device)
+    t = timed(lambda: check(hip.lib.csgn_decrypt_ragged(n, len(ts), tot, W.data_ptr(), doff.data_ptr(), dmask.data_ptr(),
+                                                        bits.data_ptr(), scratch.data_ptr(), hip.stream)), rounds=9)
+    print(f"decrypt_ragged {name:<34} kernels only: {tot*dl*8/t/1e9:8.1f} GB/s ({100*tot*dl*8/t/8e12:4.1f}% of peak, {t*1e6:7.1f} us)", flush=True)
     del W

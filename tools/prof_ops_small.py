@@ -18,6 +18,10 @@ for n, d, batch in [(1247, 16, 1 << 22), (4096, 32, 1 << 20)]:
         rng = hip.rng_from_seed(3, rounds)
         for _ in range(3):
             hip.encrypt_keyed(n, d, plain, dkey, dmask, rng, out=out)
+    plain_b = hip.upload(np.random.default_rng(4).integers(0, 2, batch).astype(np.uint8))
+    ra, rb = hip.rng_from_seed(3, 8), hip.rng_from_seed(4, 8)
+    for _ in range(3):
+        hip.encrypt_mul_keyed(n, d, plain, plain_b, dkey, dmask, ra, rb)      # the fused fresh chain
     for _ in range(3):
         hip.permute_uniform(n, batch, 1, out, perm)
     torch.cuda.synchronize()
