@@ -40,12 +40,15 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
     for (int c0 = 0; c0 < C; c0 += M) {
         if (g_begin + (u32)c0 * 256u >= total_units)
             break;
-        const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_r0 = offR[pw], s_r1 = offR[pw + 1];
-        const u64 s_o1 = s_l1 + s_r1;                           // offOut[pw + 1]
+        const u32 pw2 = min(pw + 2u, batch);
+        const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_l2 = offL[pw2];
+        const u64 s_r0 = offR[pw], s_r1 = offR[pw + 1], s_r2 = offR[pw2];
+        const u64 s_o1 = s_l1 + s_r1, s_o2 = s_l2 + s_r2;       // offOut[pw + 1], offOut[pw + 2]
         const u64 turn_end = min(g_begin + (u64)(c0 + M) * 256u, total_units);
         const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
         const bool whole = last_term < s_o1;                    // workgroup-uniform
-        if (!whole) {
+        const bool two = !whole && last_term < s_o2;            // the turn crosses ONE pair boundary: no window
+        if (!whole && !two) {
             const u32 i = threadIdx.x;
             const u32 pi = min(pw + i, batch);
             w_l[i] = offL[pi];
@@ -77,7 +80,12 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
             from_l[m] = true;
             {
                 u64 l0 = s_l0, rr0 = s_r0, t1 = s_l1 - s_l0;
-                if (!whole && term >= s_o1) {
+                if (two && term >= s_o1) {                      // the second pair of the bet
+                    p[m] = pw + 1u;
+                    l0 = s_l1;
+                    rr0 = s_r1;
+                    t1 = s_l2 - s_l1;
+                } else if (!whole && term >= s_o1) {
                     // largest j in [0, kAddWin] with w_l[j] + w_r[j] <= term
                     u32 lo = 0, hi = kAddWin + 1u;
 #pragma unroll
@@ -112,7 +120,9 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
         for (int m = 0; m < M; ++m)
             if (live[m])
                 unit_store<Unit, true>(out + g_begin + (u32)(c0 + m) * 256u + threadIdx.x, v[m]);
-        if (!whole) {
+        if (two) {
+            pw += 1u;                                           // the turn ended in the second pair
+        } else if (!whole) {
             if (threadIdx.x == 255u)
                 s_next = p[M - 1];
             __syncthreads();

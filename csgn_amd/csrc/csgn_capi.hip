@@ -385,10 +385,18 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
     }
     hipError_t e = csgn::mul_ragged_plan(batch, (const u64 *)d_off_left, (const u64 *)d_off_right,
                                          (u64 *)d_off_out, sc.p, S(stream));
+    // the four plan numbers and, in the same copy, the plan's notes on huge pairs (csgn_mul_ragged
+    // gives each of those a uniform launch of its own)
+    std::vector<u64> head(csgn::mul_ragged_plan_head_words(), 0);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(h_plan, sc.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, S(stream));
+        e = hipMemcpyAsync(head.data(), sc.p, head.size() * sizeof(u64), hipMemcpyDeviceToHost, S(stream));
     if (e == hipSuccess)
         e = hipStreamSynchronize(S(stream));
+    if (e == hipSuccess) {
+        memcpy(h_plan, head.data(), 4 * sizeof(u64));
+        csgn::mul_ragged_remember_plan((const u64 *)d_off_left, (const u64 *)d_off_right, (const u64 *)d_off_out, batch,
+                                       head.data());
+    }
     if (&sc == &local && local.p)
         (void)hipFree(local.p);
     if (e != hipSuccess)

@@ -16,9 +16,12 @@ namespace {
 template <typename Unit>
 __global__ void __launch_bounds__(256) k_term_hits(const Unit *__restrict__ terms,
                                                    const Unit *__restrict__ mask, u64 total_terms,
-                                                   u32 U, FastDiv dU, u64 *__restrict__ hits)
+                                                   u32 U, FastDiv dU, u64 *__restrict__ hits,
+                                                   u32 *__restrict__ zero4)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4)
+        zero4[threadIdx.x] = 0;                     // the ragged pass 2's counters (see LongWork)
     Unit *lmask = reinterpret_cast<Unit *>(smem_raw);                  // U units
     u32 *fail = reinterpret_cast<u32 *>(smem_raw + (size_t)U * sizeof(Unit));   // 256 flags
 
@@ -60,9 +63,12 @@ __global__ void __launch_bounds__(256) k_term_hits_seg(const Unit *__restrict__ 
                                                        const Unit *__restrict__ mask,
                                                        u64 total_units, u32 U, FastDiv dU, u32 TB,
                                                        unsigned char *__restrict__ hits,
-                                                       uint8_t *__restrict__ direct_bits)
+                                                       uint8_t *__restrict__ direct_bits,
+                                                       u32 *__restrict__ zero4)
 {
     __shared__ u64 ok_bits[K * 4 + 1];
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4)
+        zero4[threadIdx.x] = 0;                     // the ragged pass 2's counters (see LongWork)
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     // XCD-contiguous block order: +4.5 % on a pure read stream (tools/rbench.hip)
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -136,11 +142,13 @@ constexpr u64 kLongTerms = 4096;
 constexpr u64 kChunkTerms = 65536;
 
 // work area of the ragged pass 2 (after the hit bitmap): [n_long, n_entries, pad, pad][slot -> ciphertext:
-// max_long u32][slot parity: max_long u32][entries: (slot << 32) | chunk, max_entries u64]
+// max_long u32][slot parity: max_long u32][slot chunks left: max_long u32][entries: (slot << 32) | chunk,
+// max_entries u64].  The counters are zeroed by pass 1 (one launch less than a memset).
 struct LongWork {
     u32 *counters;
     u32 *slot_ct;
     u32 *slot_par;
+    u32 *slot_left;
     u64 *entries;
 };
 
@@ -161,6 +169,7 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
         work.slot_ct[slot] = (u32)b;
         work.slot_par[slot] = 0;
         const u32 nch = (u32)((e - s + kChunkTerms - 1) / kChunkTerms);
+        work.slot_left[slot] = nch;
         const u32 base = atomicAdd(work.counters + 1, nch);
         for (u32 c = 0; c < nch; ++c)
             work.entries[base + c] = ((u64)slot << 32) | c;
@@ -188,10 +197,11 @@ __global__ void __launch_bounds__(256) k_hits_parity(const u64 *__restrict__ hit
 }
 
 // The long ciphertexts of a ragged batch, chunk by chunk: workgroups stride over the work list (its
-// length is on the device), fold 1024 bitmap words each (four independent loads per lane) and XOR one
-// bit into the ciphertext's slot.
+// length is on the device), fold 1024 bitmap words each (five independent loads per lane) and XOR one
+// bit into the ciphertext's slot; the workgroup that folds a ciphertext's LAST chunk writes its bit.
 __global__ void __launch_bounds__(256) k_hits_parity_chunks(const u64 *__restrict__ hits,
-                                                            const u64 *__restrict__ off, LongWork work)
+                                                            const u64 *__restrict__ off, LongWork work,
+                                                            uint8_t *__restrict__ bits)
 {
     __shared__ u32 wave_par[4];
     const u32 n = work.counters[1];
@@ -219,17 +229,15 @@ __global__ void __launch_bounds__(256) k_hits_parity_chunks(const u64 *__restric
         if ((threadIdx.x & (kWave - 1)) == 0)
             wave_par[threadIdx.x >> 6] = (u32)__popcll(odd) & 1u;
         __syncthreads();
-        if (threadIdx.x == 0 && (wave_par[0] ^ wave_par[1] ^ wave_par[2] ^ wave_par[3]))
-            atomicXor(work.slot_par + slot, 1u);
+        if (threadIdx.x == 0) {
+            if (wave_par[0] ^ wave_par[1] ^ wave_par[2] ^ wave_par[3])
+                atomicXor(work.slot_par + slot, 1u);
+            __threadfence();                                    // my parity is in before I count myself out
+            if (atomicSub(work.slot_left + slot, 1u) == 1u)     // the last chunk of this ciphertext
+                bits[b] = (uint8_t)(atomicOr(work.slot_par + slot, 0u) & 1u);
+        }
         __syncthreads();
     }
-}
-
-__global__ void __launch_bounds__(256) k_long_to_bits(LongWork work, uint8_t *__restrict__ bits)
-{
-    const u32 n = work.counters[0];
-    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-        bits[work.slot_ct[i]] = (uint8_t)(work.slot_par[i] & 1u);
 }
 
 // decrypt, pass 2 for LONG uniform ciphertexts: a ciphertext's bit range is cut into chunks of
@@ -302,7 +310,7 @@ size_t decrypt_scratch_bytes(u64 batch, u64 total_terms)
     //   uniform long ciphertexts: one u32 partial parity per ciphertext
     //   ragged batches: LongWork (4 counters, 2 u32 per long slot, one u64 per chunk entry)
     const size_t uniform = (size_t)batch * 4u + 16u;
-    const size_t ragged = 16u + (size_t)decrypt_max_long(batch, total_terms) * 8u + 8u +
+    const size_t ragged = 16u + (size_t)decrypt_max_long(batch, total_terms) * 12u + 8u +
                           (size_t)decrypt_max_entries(batch, total_terms) * 8u;
     return decrypt_bitmap_bytes(total_terms) + (uniform > ragged ? uniform : ragged);
 }
@@ -314,6 +322,17 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
     if (batch == 0)
         return hipSuccess;
     u64 *hits = reinterpret_cast<u64 *>(scratch);
+    LongWork work = {};
+    if (off) {
+        unsigned char *wbase = reinterpret_cast<unsigned char *>(scratch) + decrypt_bitmap_bytes(total_terms);
+        const u64 max_long = decrypt_max_long(batch, total_terms);
+        work.counters = reinterpret_cast<u32 *>(wbase);
+        work.slot_ct = work.counters + 4;
+        work.slot_par = work.slot_ct + max_long;
+        work.slot_left = work.slot_par + max_long;
+        work.entries = reinterpret_cast<u64 *>(wbase + ((16u + max_long * 12u + 7u) & ~(size_t)7u));
+    }
+    u32 *zero4 = work.counters;                     // pass 1 zeroes them; nullptr for uniform batches
     if (total_terms) {
         const bool wide = (dL % 2 == 0) && aligned16(terms) && aligned16(mask);
         const u32 U = (u32)(wide ? dL / 2 : dL);
@@ -346,9 +365,9 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         if (wide)                                                                                     \
             k_term_hits_seg<unit16, K><<<(u32)nblk, 256, 0, s>>>(                                     \
                 reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask), tu, U, \
-                dU, tb, hb, direct);                                                                  \
+                dU, tb, hb, direct, zero4);                                                           \
         else                                                                                          \
-            k_term_hits_seg<unit8, K><<<(u32)nblk, 256, 0, s>>>(terms, mask, tu, U, dU, tb, hb, direct); \
+            k_term_hits_seg<unit8, K><<<(u32)nblk, 256, 0, s>>>(terms, mask, tu, U, dU, tb, hb, direct, zero4); \
     } while (0)
             switch (k_seg) {
             case 1: CSGN_HITS_SEG(1); break;
@@ -366,10 +385,10 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         } else if (wide)
             k_term_hits<unit16><<<blocks, 256, (size_t)U * 16 + 1024, s>>>(
                 reinterpret_cast<const unit16 *>(terms), reinterpret_cast<const unit16 *>(mask),
-                total_terms, U, dU, hits);
+                total_terms, U, dU, hits, zero4);
         else
             k_term_hits<unit8><<<blocks, 256, (size_t)U * 8 + 1024, s>>>(terms, mask, total_terms, U,
-                                                                        dU, hits);
+                                                                        dU, hits, zero4);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
@@ -378,21 +397,11 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         // ragged: short ciphertexts one lane each; the long ones are queued chunk by chunk
         if (batch >= (1ull << 32))
             return hipErrorInvalidValue;
-        unsigned char *wbase = reinterpret_cast<unsigned char *>(scratch) + decrypt_bitmap_bytes(total_terms);
-        LongWork work;
-        work.counters = reinterpret_cast<u32 *>(wbase);
-        work.slot_ct = work.counters + 4;
-        const u64 max_long = decrypt_max_long(batch, total_terms);
-        work.slot_par = work.slot_ct + max_long;
-        work.entries = reinterpret_cast<u64 *>(wbase + ((16u + max_long * 8u + 7u) & ~(size_t)7u));
-        hipError_t e = hipMemsetAsync(work.counters, 0, 16, s);
-        if (e != hipSuccess)
-            return e;
+        // (the work area's counters were zeroed by pass 1; with no terms at all nothing is queued)
         k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits, work);
         if (total_terms > kLongTerms) {
             const u64 max_entries = decrypt_max_entries(batch, total_terms);
-            k_hits_parity_chunks<<<(u32)std::min<u64>(8192, max_entries), 256, 0, s>>>(hits, off, work);
-            k_long_to_bits<<<(u32)std::min<u64>(64, (max_long + 255) / 256), 256, 0, s>>>(work, bits);
+            k_hits_parity_chunks<<<(u32)std::min<u64>(8192, max_entries), 256, 0, s>>>(hits, off, work, bits);
         }
     } else if (terms_uniform <= kLongTerms) {
         k_hits_parity<1, 0><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, nullptr, terms_uniform, batch, bits, LongWork{});

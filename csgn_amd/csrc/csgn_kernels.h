@@ -26,6 +26,9 @@ const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2);
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s);
 u64 mul_ragged_plan_scratch_words(u64 batch);
+u64 mul_ragged_plan_head_words();       // [plan4][huge-pair count][records]: what the host copies back
+// remembers (per host thread) what a plan learned, for the csgn_mul_ragged that follows it
+void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch, const u64 *h_head);
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,

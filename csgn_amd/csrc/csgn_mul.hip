@@ -251,13 +251,16 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
     for (int c0 = 0; c0 < C; c0 += M) {
         if (g_begin + (u32)c0 * 256u >= total_units)
             break;
-        const u64 s_o0 = offOut[pw], s_o1 = offOut[pw + 1];
-        const u64 s_l0 = offL[pw], s_r0 = offR[pw], s_r1 = offR[pw + 1];
-        // last term of the turn (workgroup-uniform): does the bet pair own all of it?
+        // the bet: pair pw and the one after it (uniform addresses: scalar loads, one round trip)
+        const u32 pw2 = min(pw + 2u, batch);
+        const u64 s_o0 = offOut[pw], s_o1 = offOut[pw + 1], s_o2 = offOut[pw2];
+        const u64 s_l0 = offL[pw], s_l1 = offL[pw + 1], s_r0 = offR[pw], s_r1 = offR[pw + 1], s_r2 = offR[pw2];
+        // last term of the turn (workgroup-uniform): does the bet pair own all of it, or the two together?
         const u64 turn_end = min(g_begin + (u64)(c0 + M) * 256u, total_units);          // one past the last unit
         const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
         const bool whole = last_term < s_o1;
-        if (!whole) {
+        const bool two = !whole && last_term < s_o2;            // a turn that crosses ONE pair boundary: no window
+        if (!whole && !two) {
             const u32 i = threadIdx.x;
             const u32 pi = min(pw + i, batch);                   // the offset arrays have batch + 1 entries
             w_out[i] = offOut[pi];
@@ -290,7 +293,13 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             if (live[m]) {
                 u64 o0 = s_o0, l0 = s_l0, rr0 = s_r0;
                 u32 t2 = (u32)(s_r1 - s_r0);
-                if (!whole && term >= s_o1) {                   // past the end of pair pw: look in the window
+                if (two && term >= s_o1) {                      // the second pair of the bet
+                    p[m] = pw + 1u;
+                    o0 = s_o1;
+                    l0 = s_l1;
+                    rr0 = s_r1;
+                    t2 = (u32)(s_r2 - s_r1);
+                } else if (!whole && term >= s_o1) {            // past the end of pair pw: look in the window
                     // largest j in [0, kWin] with w_out[j] <= term (w_out[0] = s_o0 <= term)
                     u32 lo = 0, hi = kWin + 1u;
 #pragma unroll
@@ -330,7 +339,9 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         for (int m = 0; m < M; ++m)
             if (live[m])
                 unit_store<Unit, true>(out + g_begin + (u32)(c0 + m) * 256u + threadIdx.x, lv[m] & rv[m]);
-        if (!whole) {                                           // the next turn starts from the last lane's pair
+        if (two) {
+            pw += 1u;                                           // last_term >= s_o1: the turn ended in the second pair
+        } else if (!whole) {                                    // the next turn starts from the last lane's pair
             if (threadIdx.x == 255u)
                 s_next = p[M - 1];
             __syncthreads();
@@ -338,6 +349,10 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         }
     }
 }
+
+constexpr u64 kHugeTerms = 65536;        // a product of this many terms is recorded by the plan (10 MB at N=1247)
+constexpr u64 kHugeRecords = 32;
+constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6;      // [plan4][huge count][records]
 
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
 // launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
@@ -426,12 +441,27 @@ __global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 ba
     }
 }
 
+// ... and, while every pair's final offset passes through a lane anyway, the HUGE pairs (products of
+// kHugeTerms terms and more) are written down for the host: {pair, offL, offR, t1, t2, offOut}, up to
+// kHugeRecords of them.  csgn_mul_ragged gives such a pair its own uniform launch (no lookups at
+// all inside 99 % of a skewed batch's output) and runs the CSR kernel on the stretches between them.
 __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
-                                                  u64 *__restrict__ offOut)
+                                                  const u64 *__restrict__ offL, const u64 *__restrict__ offR,
+                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge)
 {
     const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (b < batch)
-        offOut[b] += partial[b >> 10];
+    if (b < batch) {
+        const u64 o = offOut[b] + partial[b >> 10];
+        offOut[b] = o;
+        const u64 l0 = offL[b], r0 = offR[b], t1 = offL[b + 1] - l0, t2 = offR[b + 1] - r0;
+        if (t1 * t2 >= kHugeTerms) {
+            const u64 slot = atomicAdd(reinterpret_cast<unsigned long long *>(huge), 1ull);
+            if (slot < kHugeRecords) {
+                u64 *r = huge + 1 + slot * 6;
+                r[0] = b; r[1] = l0; r[2] = r0; r[3] = t1; r[4] = t2; r[5] = o;
+            }
+        }
+    }
 }
 
 // Block size for the tiled kernel: a multiple of 64 that U divides (so every column a lane
@@ -564,7 +594,13 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
     // kernel that produced them, and two extra launches triple the cost of a small product
     // (class API, 64x64: 10.9 us per multiply with the touch, 3.0-3.8 without)
     const bool streaming = pairs * (t1 + t2) * U * unit_bytes >= (4ull << 20);
-    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && (streaming || touch_env > 0)) {
+    // Knob shared_gpu = 1: the caller is NOT alone on the GPU.  The touch + flat pair counts on its
+    // operands staying in the 256 MiB memory-side cache between the touch and the rows that read
+    // them; a co-tenant that streams through HBM (a second stream of 1 GiB copies, profiles/r03/
+    // cotenant_ab.json) evicts them and the pair falls to 3.5 TB/s, where the LDS-tiled kernel, which
+    // fetches each left term once per 4 rows x 4 KiB whatever the cache holds, keeps 4.8.
+    const bool shared = csgn::tune(TUNE_SHARED_GPU) != 0;
+    if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && ((streaming && !shared) || touch_env > 0)) {
         p.flat = 1;
         p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
     } else if (t2 * U < (unit_bytes == 16 ? 256u : 64u)) {
@@ -767,13 +803,14 @@ hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     return hipSuccess;
 }
 
-u64 mul_ragged_plan_scratch_words(u64 batch) { return 4 + (batch + 1023) / 1024 + 1; }
+u64 mul_ragged_plan_scratch_words(u64 batch) { return kPlanHeadWords + (batch + 1023) / 1024 + 1; }
+u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
 
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s)
 {
-    // d_work: [plan4 (total, max t1, max t2, max t1*t2)][one partial per 1024-pair chunk]
-    u64 *plan4 = d_work, *partial = d_work + 4;
+    // d_work: [plan4 (total, max t1, max t2, max t1*t2)][huge count][huge records][one partial per 1024-pair chunk]
+    u64 *plan4 = d_work, *huge = d_work + 4, *partial = d_work + kPlanHeadWords;
     const u64 nchunks = (batch + 1023) / 1024;
     hipError_t e = hipMemsetAsync(d_work, 0, mul_ragged_plan_scratch_words(batch) * 8, s);
     if (e != hipSuccess)
@@ -784,8 +821,43 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
         k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
     k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
     if (batch)
-        k_plan_fix<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, partial, offOut);
+        k_plan_fix<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge);
     return hipGetLastError();
+}
+
+// What the last csgn_mul_ragged_plan of this host thread learned about the huge pairs of a batch.
+// csgn_mul_ragged consults it when it is called with the SAME offset arrays, batch and plan numbers
+// (the documented sequence: plan, then multiply); with anything else it knows nothing and every pair
+// goes through the CSR kernel.  The offsets must not change between the two calls -- they are the
+// plan's own output.
+struct RememberedPlan {
+    const u64 *offL = nullptr, *offR = nullptr, *offOut = nullptr;
+    u64 batch = 0, total = 0, max_t1 = 0, max_t2 = 0;
+    u32 n = 0;                                   // records kept (sorted by pair)
+    u64 rec[kHugeRecords][6];
+};
+static thread_local RememberedPlan t_plan;
+
+void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch, const u64 *h_head)
+{
+    RememberedPlan &r = t_plan;
+    r.offL = offL;
+    r.offR = offR;
+    r.offOut = offOut;
+    r.batch = batch;
+    r.total = h_head[0];
+    r.max_t1 = h_head[1];
+    r.max_t2 = h_head[2];
+    const u64 count = h_head[4];
+    r.n = (u32)std::min<u64>(count, kHugeRecords);
+    for (u32 i = 0; i < r.n; ++i)
+        for (int k = 0; k < 6; ++k)
+            r.rec[i][k] = h_head[5 + i * 6 + k];
+    // the slots were handed out by an atomic counter: order the records by pair (insertion sort, <= 32)
+    for (u32 i = 1; i < r.n; ++i)
+        for (u32 j = i; j > 0 && r.rec[j][0] < r.rec[j - 1][0]; --j)
+            for (int k = 0; k < 6; ++k)
+                std::swap(r.rec[j][k], r.rec[j - 1][k]);
 }
 
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
@@ -832,16 +904,18 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
     // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
     // an HBM miss under full write load, as in the uniform path.  Knob ragged_touch = 0 turns it off.
-    const bool touch = wide && total_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
-    const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
-    hipError_t result = hipSuccess;
-    for (u64 u0 = 0; u0 < total_units && result == hipSuccess; u0 += per_launch) {
-        const u64 nu = (total_units - u0 < per_launch) ? total_units - u0 : per_launch;
-        const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
-        if (touch)
-            k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
-                                               reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
-                                               u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
+    auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
+        const u64 range_units = range_end - range_begin;
+        const bool touch = wide && range_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
+        hipError_t result = hipSuccess;
+        for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
+            const u64 nu = (range_end - u0 < per_launch) ? range_end - u0 : per_launch;
+            const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+            if (touch)
+                k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
+                                                   reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
+                                                   u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
 #define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
     do {                                                                                            \
         if (wide)                                                                                   \
@@ -862,17 +936,49 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         else                                                                                        \
             CSGN_RAGGED_FLAT(CH, 1);                                                                \
     } while (0)
-        switch (chunks) {
-        case 1: CSGN_RAGGED_LAUNCH(1); break;
-        case 2: CSGN_RAGGED_LAUNCH(2); break;
-        case 4: CSGN_RAGGED_LAUNCH(4); break;
-        case 16: CSGN_RAGGED_LAUNCH(16); break;
-        default: CSGN_RAGGED_LAUNCH(8); break;
-        }
+            switch (chunks) {
+            case 1: CSGN_RAGGED_LAUNCH(1); break;
+            case 2: CSGN_RAGGED_LAUNCH(2); break;
+            case 4: CSGN_RAGGED_LAUNCH(4); break;
+            case 16: CSGN_RAGGED_LAUNCH(16); break;
+            default: CSGN_RAGGED_LAUNCH(8); break;
+            }
 #undef CSGN_RAGGED_FLAT
 #undef CSGN_RAGGED_LAUNCH
-        result = hipGetLastError();
+            result = hipGetLastError();
+        }
+        return result;
+    };
+    // Huge pairs the plan wrote down (same offset arrays, same batch, same plan numbers as the last
+    // csgn_mul_ragged_plan of this thread): each gets the UNIFORM kernels on its own sub-buffers -- no
+    // lookup of any kind inside what is usually nearly all of a skewed batch's output -- provided it
+    // is worth a launch of its own (24 MB of output: ~3.5 us of HBM time against ~3 launches); the CSR
+    // kernel runs on the stretches between them.  Knob ragged_flat = 1 keeps everything in the CSR kernel.
+    const RememberedPlan &rp = t_plan;
+    const bool planned = csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0 && rp.offL == offL && rp.offR == offR &&
+                         rp.offOut == offOut && rp.batch == batch && rp.total == total_out_terms &&
+                         rp.max_t1 == max_t1 && rp.max_t2 == max_t2;
+    u64 cursor = 0;
+    if (planned) {
+        for (u32 i = 0; i < rp.n; ++i) {
+            const u64 pb = rp.rec[i][0], l0 = rp.rec[i][1], r0 = rp.rec[i][2], t1 = rp.rec[i][3], t2 = rp.rec[i][4],
+                      o0 = rp.rec[i][5];
+            if (pb >= batch || t1 * t2 * dL * 8u < (24ull << 20) || o0 + t1 * t2 > total_out_terms || o0 * U < cursor)
+                continue;
+            if (o0 * U > cursor) {
+                const hipError_t e = flat_range(cursor, o0 * U);
+                if (e != hipSuccess)
+                    return e;
+            }
+            const hipError_t e = mul_uniform(n_bits, 1, t1, t2, L + l0 * dL, R + r0 * dL, out + o0 * dL, 0, s);
+            if (e != hipSuccess)
+                return e;
+            cursor = (o0 + t1 * t2) * U;
+        }
     }
+    hipError_t result = hipSuccess;
+    if (cursor < total_units)
+        result = flat_range(cursor, total_units);
     return result;
 }
 

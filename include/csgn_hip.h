@@ -133,9 +133,13 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
                          uint64_t *d_off_out, uint64_t h_plan[4], void *stream);
 /* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets; pass the plan's
  * max_t1 = h_plan[1], max_t2 = h_plan[2], total_out_terms = h_plan[0].  Nearly uniform batches
- * of large products run the LDS-tiled kernel; skewed or small ones a flat kernel whose grid is
- * the real output (a workgroup finds its first pair by binary search over d_off_out, its waves
- * walk forward from there). */
+ * of large products run the LDS-tiled kernel; a batch whose pairs ALL have the largest shape runs
+ * the uniform kernels; skewed or small ones a flat kernel whose grid is the real output (a workgroup
+ * finds its first pair by a 64-ary search over d_off_out and stages the offsets it needs in LDS).
+ * Called right after csgn_mul_ragged_plan on the same host thread with the same offset arrays -- the
+ * documented sequence -- it also knows the batch's HUGE pairs (24 MB of output and more, up to 32 of
+ * them) from the plan and gives each a uniform launch of its own; the offsets must therefore not
+ * change between the two calls. */
 int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
@@ -394,6 +398,13 @@ const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1
  * later calls and of no other thread's (every thread starts from the defaults + the environment
  * snapshot), so concurrent one-thread-per-GPU callers cannot switch one another's kernels.
  * A circuit (csgn_circuit_build) bakes in the building thread's values at build time. */
+/* Sharing the GPU.  The default dispatch of a large all-pairs multiply (operand touch pass + flat
+ * kernel) is tuned for a caller that has the chip to itself: measured 7.3 TB/s alone, but 3.5 TB/s
+ * beside a second stream of back-to-back 1 GiB device copies, where the LDS-tiled kernel holds 4.8
+ * (6.9 alone; profiles/r03/cotenant_ab.json).  A host thread whose GPU also serves other streams or
+ * processes should call csgn_set_tuning("shared_gpu", 1) (or start with CSGN_SHARED_GPU=1 in the
+ * environment): its multiplies then take the kernel that does not depend on what the memory-side
+ * cache holds.  Results are identical either way. */
 int csgn_set_tuning(const char *key, int value);
 int csgn_get_tuning(const char *key, int *h_value);
 void csgn_reset_tuning(void);            /* defaults + the environment snapshot taken at load */

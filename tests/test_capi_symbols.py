@@ -200,6 +200,10 @@ def test_tuning_knobs_are_per_host_thread(lib, knobs):
     assert lib.csgn_mul_uniform_kernel(1247, 128, 1024, 1024).decode() == "k_mul_tiled"
     capi.reset_tuning()
     assert lib.csgn_mul_uniform_kernel(1247, 128, 1024, 1024).decode() == "k_touch+k_mul_flat"
+    # a caller that shares its GPU asks for the kernel that does not lean on the memory-side cache
+    capi.set_tuning("shared_gpu", 1)
+    assert lib.csgn_mul_uniform_kernel(1247, 128, 1024, 1024).decode() == "k_mul_tiled"
+    capi.reset_tuning()
 
 
 def test_environment_is_read_in_one_place_only():

@@ -1768,6 +1768,46 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
         assert np.array_equal(got, want), b
 
 
+def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
+    """csgn_mul_ragged right after csgn_mul_ragged_plan: pairs of 24 MB of output and more (written down by
+    the plan) get uniform launches of their own, the CSR kernel runs on the stretches between them.  Two
+    huge pairs (400x400 and 512x330 terms, N=1247), one at the very start, among 3000 small and empty
+    ones, and a third at the very end; identical to the CSR kernel alone (knob ragged_flat = 1), huge and
+    neighbouring pairs equal the oracle.  A multiply whose offsets were NOT planned on this thread (a
+    copy of the offset arrays) must give the same words through the CSR kernel."""
+    import torch
+    n, dl = 1247, 20
+    rng = np.random.default_rng(77)
+    batch = 3003
+    t1s, t2s = rng.integers(0, 6, size=batch), rng.integers(0, 6, size=batch)
+    huge = {0: (400, 400), 1500: (512, 330), batch - 1: (300, 600)}
+    for b, (a, c) in huge.items():
+        t1s[b], t2s[b] = a, c
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    L = hip.synth_fill(61, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(62, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)                 # plan + multiply: the huge pairs go uniform
+    out = out.clone()
+    knobs.set("ragged_flat", 1)
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)             # everything through the CSR kernel
+    assert torch.equal(out, ref) and torch.equal(off, ref_off)
+    knobs.unset("ragged_flat")
+    # unplanned offsets (copies): nothing is remembered for them, same words
+    from csgn_amd.capi import check
+    mo = hip.download(off)
+    dOL2, dOR2, off2 = dOL.clone(), dOR.clone(), off.clone()
+    out2 = hip.empty_words(out.numel())
+    check(hip.lib.csgn_mul_ragged(n, batch, L.data_ptr(), dOL2.data_ptr(), R.data_ptr(), dOR2.data_ptr(), out2.data_ptr(),
+                                  off2.data_ptr(), int(t1s.max()), int(t2s.max()), int(mo[-1]), hip.stream))
+    assert torch.equal(out2, ref)
+    hl, hr = hip.download(L), hip.download(R)
+    for b in sorted(set(huge) | {1, 2, 1499, 1501, batch - 2}):
+        if t1s[b] and t2s[b]:
+            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+            assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
 def test_ragged_forms_fuzz(hip, oracle, knobs):
     """36 random CSR batches (empty operands, runs of empty pairs -- some longer than the 256-pair
     offset window of the flat kernels -- one large pair among small ones, all-singles and all-equal

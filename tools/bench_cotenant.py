@@ -7,7 +7,7 @@ streams through the same HBM and the same 256 MiB memory-side cache the operand 
 (csgn_mul.hip: k_touch leaves <= 64 MB of operands there until their pairs run).  Both dispatches,
 interleaved in ONE process (rule 24 of the guide):
     auto   = k_touch + k_mul_flat  (library default for this shape)
-    tiled  = k_mul_tiled           (knob mul_flat = -1: LDS-staged left tile, no cache dependence)
+    tiled  = k_mul_tiled           (knob shared_gpu = 1: LDS-staged left tile, no cache dependence)
 with and without the co-tenant.  Prints mult/s and algorithmic TB/s per arm and round, the
 co-tenant's own copy rate, and the medians.
 
@@ -43,7 +43,7 @@ torch.cuda.synchronize()
 def run(arm, cotenant):
     capi.reset_tuning()
     if arm == "tiled":
-        capi.set_tuning("mul_flat", -1)
+        capi.set_tuning("shared_gpu", 1)                 # the documented knob for callers that share the GPU
     name = hip.lib.csgn_mul_uniform_kernel(n, B, T, T).decode()
     ncopies = 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -16,7 +16,9 @@ import csv, json, statistics, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 by = {}
 for r in rows:
-    e = by.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"].split("(")[0].split("::")[-1], "grid": int(r["Grid_Size"]),
+    import re as _re
+    _m = _re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", r["Kernel_Name"])
+    e = by.setdefault(int(r["Dispatch_Id"]), {"name": (_m.group(1) + (_m.group(2) or "")) if _m else r["Kernel_Name"], "grid": int(r["Grid_Size"]),
                                               "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                               "vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"])})
     e[r["Counter_Name"]] = float(r["Counter_Value"])
