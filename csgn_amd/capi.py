@@ -85,6 +85,7 @@ SIGNATURES = {
     "csgn_circuit_decrypt": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
     "csgn_circuit_permute": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
     "csgn_circuit_encrypt": (C.c_int, [vp, u64, vp, vp, vp, vp, u64, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_encrypt_mul": (C.c_int, [vp, u64, vp, vp, vp, vp, vp, vp, u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "csgn_circuit_epoch": (u64, [vp]),
     "csgn_circuit_node_key": (C.c_int, [vp, vp]),
     "csgn_circuit_build": (C.c_int, [vp]),

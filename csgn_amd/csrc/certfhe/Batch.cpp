@@ -271,6 +271,58 @@ unsigned BatchCircuit::encryptInput(const SecretKey &key)
     return id;
 }
 
+unsigned BatchCircuit::encryptProduct(const SecretKey &key, unsigned *bits_id)
+{
+    if (!key.certFHEContext || key.certFHEContext->getN() != ctx.getN())
+        throw std::invalid_argument("certFHE::BatchCircuit::encryptProduct: key and circuit differ in N");
+    key.ensureMask();
+    masks.push_back(key.device_mask);
+    const uint64_t d = (uint64_t)key.length, pw = (count_ + 7) / 8;
+    // one block: [key indices (d words)][plaintext bytes of a][plaintext bytes of b], zero until setPlainPair()
+    std::vector<uint64_t> stage(d + 2 * pw, 0);
+    for (uint64_t i = 0; i < d; ++i)
+        stage[i] = key.s[i];
+    std::shared_ptr<DevicePayload> blk = detail::uploadWords(stage.data(), stage.size());
+    volatile uint64_t *wipe = stage.data();
+    for (uint64_t i = 0; i < d; ++i)
+        wipe[i] = 0;
+    masks.push_back(blk);
+    csgn_rng ra, rb;                                  // two independent generator keys from the OS
+    detail::check(csgn_rng_from_os(&ra, 8), "csgn_rng_from_os");
+    detail::check(csgn_rng_from_os(&rb, 8), "csgn_rng_from_os");
+    uint32_t id = 0, bid = 0;
+    const uint8_t *pa = reinterpret_cast<const uint8_t *>(blk->data() + d);
+    detail::check(csgn_circuit_encrypt_mul(handle, d, pa, pa + pw * 8, blk->data(), key.device_mask->data(), &ra, &rb,
+                                           next_first, &id, bits_id ? &bid : nullptr),
+                  "csgn_circuit_encrypt_mul");
+    volatile uint32_t *wa = ra.key, *wb = rb.key;
+    for (int i = 0; i < 8; ++i)
+        wa[i] = wb[i] = 0;
+    next_first += (uint64_t)1 << 40;
+    pair_plains.push_back(std::make_pair((unsigned)id, blk));
+    if (bits_id)
+        *bits_id = bid;
+    return id;
+}
+
+void BatchCircuit::setPlainPair(unsigned product, const std::vector<unsigned char> &a, const std::vector<unsigned char> &b)
+{
+    if (a.size() != count_ || b.size() != count_)
+        throw std::invalid_argument("certFHE::BatchCircuit::setPlainPair: one bit of each operand per element expected");
+    const uint64_t pw = (count_ + 7) / 8;
+    for (size_t i = 0; i < pair_plains.size(); ++i)
+        if (pair_plains[i].first == product) {
+            const uint64_t d_words = pair_plains[i].second->words - 2 * pw;
+            detail::check(csgn_memcpy_h2d(pair_plains[i].second->data() + d_words, a.data(), (size_t)count_, detail::stream()),
+                          "csgn_memcpy_h2d");
+            detail::check(csgn_memcpy_h2d(pair_plains[i].second->data() + d_words + pw, b.data(), (size_t)count_, detail::stream()),
+                          "csgn_memcpy_h2d");
+            detail::check(csgn_stream_sync(detail::stream()), "csgn_stream_sync");
+            return;
+        }
+    throw std::invalid_argument("certFHE::BatchCircuit::setPlainPair: not a fused product of this circuit");
+}
+
 void BatchCircuit::setPlain(unsigned encrypted_input, const std::vector<unsigned char> &bits)
 {
     if (bits.size() != count_)

@@ -421,7 +421,7 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     (unsigned long long)max_t1, (unsigned long long)max_t2);
     hipError_t e = csgn::mul_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
                                     (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
-                                    (const u64 *)d_off_out, max_t1, max_t2, total_out_terms, S(stream));
+                                    (const u64 *)d_off_out, max_t1, max_t2, total_out_terms, S(stream), true);
     if (e == hipErrorInvalidValue)
         return fail(CSGN_ERR_UNSUPPORTED, "ragged batch too large for one call (2^32 pairs / one pair's tile grid)");
     HIP_TRY(e);
@@ -777,7 +777,7 @@ struct csgn_circuit {
         uint64_t max_terms;
     };
     struct Op {
-        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator)
+        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator), 5 fused Enc*Enc (+Dec)
         uint32_t a, b, out;
         const void *mask;     // decrypt / encrypt: key mask (u64 words); permute: permutation (u32 entries)
         size_t scratch, bits; // byte offsets (decrypt)
@@ -786,6 +786,10 @@ struct csgn_circuit {
         const uint64_t *key;
         uint64_t d, first;
         csgn_rng rng;
+        // fused Enc*Enc only
+        const uint8_t *plain_b;
+        csgn_rng rng_b;
+        bool want_bits;
     };
     uint64_t n_bits = 0, batch = 0;
     std::vector<Value> values;
@@ -1044,6 +1048,55 @@ int csgn_circuit_encrypt(csgn_circuit *c, uint64_t d, const uint8_t *d_plain, co
     return CSGN_OK;
 }
 
+int csgn_circuit_encrypt_mul(csgn_circuit *c, uint64_t d, const uint8_t *d_plain_a, const uint8_t *d_plain_b,
+                             const uint64_t *d_key, const uint64_t *d_mask, const csgn_rng *h_rng_a,
+                             const csgn_rng *h_rng_b, uint64_t first_ciphertext, uint32_t *value, uint32_t *bits_id)
+{
+    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
+    REQUIRE(d_plain_a && d_plain_b && d_key && d_mask && h_rng_a && h_rng_b, "null argument");
+    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
+    REQUIRE(h_rng_a->rounds == 8 || h_rng_a->rounds == 12 || h_rng_a->rounds == 20, "rng rounds must be 8, 12 or 20");
+    REQUIRE(h_rng_a->rounds == h_rng_b->rounds, "both generators must use the same number of rounds");
+    REQUIRE(memcmp(h_rng_a->key, h_rng_b->key, sizeof(h_rng_a->key)) != 0 || h_rng_a->nonce != h_rng_b->nonce,
+            "the two operands must draw from different streams (same key AND nonce given)");
+    REQUIRE(first_ciphertext + c->batch >= first_ciphertext && first_ciphertext + c->batch < (1ull << 56),
+            "ciphertext index range too large");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    if (!product_below(c->batch, 1, dl, 1ull << 57))
+        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)c->batch);
+    if (!c->has_encrypt) {
+        c->has_encrypt = true;
+        c->epoch_offset = circuit_reserve(c, 8);
+    }
+    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
+    const uint32_t out = (uint32_t)(c->values.size() - 1);
+    csgn_circuit::Op op = {};
+    op.kind = 5;
+    op.out = out;
+    op.mask = d_mask;
+    op.plain = d_plain_a;
+    op.plain_b = d_plain_b;
+    op.key = d_key;
+    op.d = d;
+    op.first = first_ciphertext;
+    // as csgn_circuit_encrypt: each operand under its own derived node key, nonce = run number
+    op.rng = *h_rng_a;
+    node_key_from(*h_rng_a, op.rng.key);
+    op.rng.nonce = 0;
+    op.rng_b = *h_rng_b;
+    node_key_from(*h_rng_b, op.rng_b.key);
+    op.rng_b.nonce = 0;
+    op.want_bits = bits_id != nullptr;
+    if (bits_id) {
+        op.bits = circuit_reserve(c, (size_t)c->batch);
+        c->bits_offsets.push_back(op.bits);
+        *bits_id = (uint32_t)(c->bits_offsets.size() - 1);
+    }
+    c->ops.push_back(op);
+    *value = out;
+    return CSGN_OK;
+}
+
 uint64_t csgn_circuit_epoch(const csgn_circuit *c) { return c ? c->runs : 0; }
 
 int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8])
@@ -1109,6 +1162,14 @@ int csgn_circuit_build(csgn_circuit *c)
             e = csgn::encrypt_keyed(c->n_bits, op.d, c->batch, op.first, op.plain, (const u64 *)op.key,
                                     (const u64 *)op.mask, op.rng.key, op.rng.nonce, op.rng.rounds,
                                     (const u64 *)epoch, (u64 *)O, s);
+            continue;
+        }
+        if (op.kind == 5) {
+            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
+            e = csgn::encrypt_mul_keyed(c->n_bits, op.d, c->batch, op.first, op.plain, op.plain_b, (const u64 *)op.key,
+                                        (const u64 *)op.mask, op.rng.key, op.rng.nonce, op.rng_b.key, op.rng_b.nonce,
+                                        op.rng.rounds, (const u64 *)epoch, (u64 *)O,
+                                        op.want_bits ? base + op.bits : nullptr, s);
             continue;
         }
         const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);

@@ -31,9 +31,11 @@ u64 mul_ragged_plan_head_words();       // [plan4][huge-pair count][records]: wh
 void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch, const u64 *h_head);
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);
+// use_remembered_plan: consult what the calling thread's last mul_ragged_plan wrote down about huge
+// pairs (only the C entry point does: a circuit's offsets never came from that plan)
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s);
+                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan = false);
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        hipStream_t s);
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,

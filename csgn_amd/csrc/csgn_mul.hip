@@ -862,7 +862,7 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
 
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s)
+                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
@@ -955,7 +955,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // is worth a launch of its own (24 MB of output: ~3.5 us of HBM time against ~3 launches); the CSR
     // kernel runs on the stretches between them.  Knob ragged_flat = 1 keeps everything in the CSR kernel.
     const RememberedPlan &rp = t_plan;
-    const bool planned = csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0 && rp.offL == offL && rp.offR == offR &&
+    const bool planned = use_remembered_plan && csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0 && rp.offL == offL && rp.offR == offR &&
                          rp.offOut == offOut && rp.batch == batch && rp.total == total_out_terms &&
                          rp.max_t1 == max_t1 && rp.max_t2 == max_t2;
     u64 cursor = 0;

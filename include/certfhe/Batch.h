@@ -85,6 +85,7 @@ class BatchCircuit {
     uint64_t count_;
     std::vector<std::shared_ptr<detail::DevicePayload> > masks;   // key masks / permutations / plaintext bytes the graph refers to
     std::vector<std::pair<unsigned, std::shared_ptr<detail::DevicePayload> > > plains;   // encrypt inputs: value id -> plaintext bytes
+    std::vector<std::pair<unsigned, std::shared_ptr<detail::DevicePayload> > > pair_plains;   // fused products: value id -> both operands' plaintext bytes
     uint64_t next_first;                                           // stream range handed to the next encrypt input
     BatchCircuit(const BatchCircuit &);
     BatchCircuit &operator=(const BatchCircuit &);
@@ -98,6 +99,12 @@ class BatchCircuit {
     // every run() draws a new keystream.  No staging copy: Enc,Enc -> * -> Dec is one graph launch.
     unsigned encryptInput(const SecretKey &key);
     void setPlain(unsigned encrypted_input, const std::vector<unsigned char> &bits);
+    // The fused fresh chain as ONE node (csgn_circuit_encrypt_mul): value = Enc(a[i]) * Enc(b[i]) for the bits
+    // last given to setPlainPair(), both operands generated in registers, only the product written; when
+    // bits_id is given it receives the id for bits(): the product's decryption, computed by the same
+    // kernel.  The reference's canonical flow (tests/basic_operations.cpp:26-40) is then one kernel.
+    unsigned encryptProduct(const SecretKey &key, unsigned *bits_id = nullptr);
+    void setPlainPair(unsigned product, const std::vector<unsigned char> &a, const std::vector<unsigned char> &b);
     unsigned add(unsigned a, unsigned b);
     unsigned mul(unsigned a, unsigned b);
     unsigned permute(unsigned a, const Permutation &p);   // applyPermutation: ONE term, the permuted first term

@@ -369,6 +369,16 @@ int csgn_circuit_permute(csgn_circuit *circuit, uint32_t a, const uint32_t *d_pe
 int csgn_circuit_encrypt(csgn_circuit *circuit, uint64_t d, const uint8_t *d_plain, const uint64_t *d_key,
                          const uint64_t *d_mask, const csgn_rng *h_rng, uint64_t first_ciphertext,
                          uint32_t *value);
+/* The fused fresh chain as ONE node (csgn_encrypt_mul_keyed inside the graph): value = Enc_A(d_plain_a) *
+ * Enc_B(d_plain_b), one term per element, and -- when bits_id is not NULL -- its decryption under the same
+ * key as a result buffer.  BASELINE configs 2 / 4 end to end (encrypt, encrypt, multiply, decrypt) are
+ * then two graph nodes (run counter + this kernel) and one pass over 8*dL bytes per pair.  The operands
+ * themselves are never materialised; a circuit that needs them as values uses csgn_circuit_encrypt and
+ * csgn_circuit_mul instead (the circuit never rewrites what the caller described: every value it was asked
+ * for stays addressable through csgn_circuit_value).  Keys, nonces and runs as for csgn_circuit_encrypt. */
+int csgn_circuit_encrypt_mul(csgn_circuit *circuit, uint64_t d, const uint8_t *d_plain_a, const uint8_t *d_plain_b,
+                             const uint64_t *d_key, const uint64_t *d_mask, const csgn_rng *h_rng_a,
+                             const csgn_rng *h_rng_b, uint64_t first_ciphertext, uint32_t *value, uint32_t *bits_id);
 uint64_t csgn_circuit_epoch(const csgn_circuit *circuit);      /* runs launched so far */
 /* The key a circuit encrypt node built from *h_rng encrypts under: words 0..7 of the ChaCha20 block
  * (constants "csgn node key v1", key = h_rng->key, nonce = h_rng->nonce, counter 0).  Host only. */

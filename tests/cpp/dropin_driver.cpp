@@ -643,6 +643,33 @@ static int cmd_graph(int count)
         }
         EXPECT(first_words[0] != first_words[1] || first_words[1] != first_words[2]);
     }
+    {
+        // the same chain as ONE fused node (BatchCircuit::encryptProduct): the product and its decryption
+        // come out of a single kernel; the product must decrypt, word by word through the per-object API
+        // too, to a[i] & b[i]
+        BatchCircuit f(ctx, count);
+        unsigned bits_id = 0;
+        const unsigned prod = f.encryptProduct(sk, &bits_id);
+        f.build();
+        std::vector<uint64_t> first_words;
+        for (int round = 0; round < 3; ++round) {
+            std::vector<unsigned char> ba(count), bb(count), wm(count);
+            for (int i = 0; i < count; ++i) {
+                ba[i] = (unsigned char)((i * 5 + round) & 1);
+                bb[i] = (unsigned char)(((i >> 2) + round) & 1);
+                wm[i] = ba[i] & bb[i];
+            }
+            f.setPlainPair(prod, ba, bb);
+            f.run();
+            EXPECT(f.bits(bits_id) == wm);
+            CiphertextBatch p = f.value(prod);
+            EXPECT(p.terms() == 1 && p.decrypt(sk) == wm);
+            Ciphertext one = p.at(count - 1);
+            EXPECT(sk.decrypt(one).getValue() == wm[count - 1]);
+            first_words.push_back(p.at(0).getValues()[0]);
+        }
+        EXPECT(first_words[0] != first_words[1] || first_words[1] != first_words[2]);
+    }
     printf("graph ok count=%d\n", count);
     return 0;
 }

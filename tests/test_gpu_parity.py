@@ -1588,6 +1588,57 @@ def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, bat
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("n,d,batch", [(1247, 16, 65536), (4096, 32, 77), (65, 3, 5000)])
+def test_circuit_graph_fused_fresh_chain_node(hip, oracle, n, d, batch):
+    """csgn_circuit_encrypt_mul: Enc*Enc (+Dec) as ONE graph node.  Words equal the restated definition under
+    the two derived node keys with nonce = run number, bits equal b1 & b0 (computed by the kernel from the
+    generated words: checked against csgn_decrypt_uniform of the product), every replay differs."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 41)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    ra, rb = hip.rng_from_seed(199, 8), hip.rng_from_seed(299, 8)
+    (ka, na), (kb, nb) = oracle.rng_from_seed(199), oracle.rng_from_seed(299)
+    nka, nkb = oracle.node_key(ka, na), oracle.node_key(kb, nb)
+    pa = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    pb = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    vf, bf = C.c_uint32(), C.c_uint32()
+    first = 12345
+    check(lib.csgn_circuit_encrypt_mul(c, d, pa.data_ptr(), pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(ra),
+                                       C.byref(rb), first, C.byref(vf), C.byref(bf)))
+    assert lib.csgn_circuit_encrypt_mul(c, d, pa.data_ptr(), pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(ra),
+                                        C.byref(ra), first, C.byref(vf), None) == -1          # the same stream twice
+    check(lib.csgn_circuit_build(c))
+    prev = None
+    for run in (1, 2, 3):
+        ha = np.random.default_rng(run).integers(0, 2, batch).astype(np.uint8)
+        hb = np.random.default_rng(200 + run).integers(0, 2, batch).astype(np.uint8)
+        pa.copy_(torch.from_numpy(ha))
+        pb.copy_(torch.from_numpy(hb))
+        check(lib.csgn_circuit_run(c, hip.stream))
+        prod = hip.empty_words(batch * dl)
+        check(lib.csgn_memcpy_d2d(prod.data_ptr(), lib.csgn_circuit_value(c, vf.value), batch * dl * 8, hip.stream))
+        k = min(batch, 3000)
+        want = (oracle.encrypt_keyed(n, key, ha[:k], nka, run, 8, first_ciphertext=first)
+                & oracle.encrypt_keyed(n, key, hb[:k], nkb, run, 8, first_ciphertext=first))
+        assert np.array_equal(hip.download(prod)[:k * dl], want), run
+        gb = torch.empty(batch, dtype=torch.uint8, device=hip.device)
+        check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bf.value), batch, hip.stream))
+        bits = hip.download(gb)
+        assert np.array_equal(bits, hip.download(hip.decrypt_uniform(n, batch, 1, prod, dmask)))
+        if len(set(int(x) for x in key)) > 1:
+            assert np.array_equal(bits, ha & hb)
+        if prev is not None:
+            assert not torch.equal(prod, prev)
+        prev = prod
+    lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 40), (65, 4, 1000)])
 def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
     """Ragged values in a captured circuit (static per-element shapes): x = (a*b + c) * (a + u) with

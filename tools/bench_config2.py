@@ -4,7 +4,8 @@ form, with the launch cost separated from the kernel time (dev tool):
   a. csgn_mul_uniform 1x1, one call bracketed by HIP events (what a caller sees for one batch);
   b. the same call 200 times back to back (per-call time once launches overlap the previous kernel);
   c. Enc, Enc -> * -> Dec as ONE hipGraph (csgn_circuit_encrypt): per replay;
-  d. the same four operations issued one by one.
+  d. the same four operations issued one by one;
+  e. the chain as ONE fused node (csgn_circuit_encrypt_mul) in a graph, and as one csgn_encrypt_mul_keyed call.
 Run it under `rocprofv3 --kernel-trace --stats` for the pure kernel durations (k_and_stream,
 k_encrypt_wave, k_term_hits_seg); profiles/r02/config2.* keeps both."""
 import ctypes as C
@@ -72,6 +73,29 @@ for batch in (65536, 1 << 20):
         graph.append(a.elapsed_time(b) * 1e3)
     lib.csgn_circuit_destroy(c)
 
+    # the same chain as ONE fused node (csgn_circuit_encrypt_mul: both operands in registers, product + bits out)
+    rng_b = hip.rng_from_seed(8, 8)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    vf, bf = C.c_uint32(), C.c_uint32()
+    check(lib.csgn_circuit_encrypt_mul(c, d, pa.data_ptr(), pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(rng),
+                                       C.byref(rng_b), 0, C.byref(vf), C.byref(bf)))
+    check(lib.csgn_circuit_build(c))
+    for _ in range(5):
+        check(lib.csgn_circuit_run(c, hip.stream))
+    torch.cuda.synchronize()
+    fused_graph = []
+    for _ in range(50):
+        a, b = ev(), ev()
+        a.record(); check(lib.csgn_circuit_run(c, hip.stream)); b.record(); b.synchronize()
+        fused_graph.append(a.elapsed_time(b) * 1e3)
+    lib.csgn_circuit_destroy(c)
+    fused_call = []
+    for _ in range(50):
+        a, b = ev(), ev()
+        a.record(); hip.encrypt_mul_keyed(n, d, pa, pb, dkey, dmask, rng, rng_b); b.record(); b.synchronize()
+        fused_call.append(a.elapsed_time(b) * 1e3)
+
     ca, cb = hip.empty_words(batch * dl), hip.empty_words(batch * dl)
     def by_hand():
         hip.encrypt_keyed(n, d, pa, dkey, dmask, rng, 0, out=ca)
@@ -94,6 +118,9 @@ for batch in (65536, 1 << 20):
         "mul_1x1_GBps_back_to_back": bytes_mul / back_to_back / 1e3,
         "enc_enc_mul_dec_graph_us": statistics.median(graph),
         "enc_enc_mul_dec_one_by_one_us": statistics.median(hand),
+        "fused_node_graph_us": statistics.median(fused_graph),
+        "fused_csgn_encrypt_mul_keyed_call_us": statistics.median(fused_call),
+        "mult_per_s_fused_graph": batch / statistics.median(fused_graph) * 1e6,
         "end_to_end_GBps_graph": bytes_e2e / statistics.median(graph) / 1e3,
         "mult_per_s_graph": batch / statistics.median(graph) * 1e6,
     }

@@ -160,14 +160,28 @@ __global__ void __launch_bounds__(1024) k_chacha(unsigned *out, Stamp *stamps, u
 #define P_AAR(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\nv_add_u32 %" #i ", %" #i ", %8\nv_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
 #define P_ROT2(i) "v_lshrrev_b32 %9, 25, %" #i "\nv_lshl_or_b32 %" #i ", %" #i ", 7, %9\n"
 #define P_AX_PERM(i) "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %8\nv_perm_b32 %" #i ", %" #i ", %" #i ", %8\n"
+// runs of the same class: k adds, then k xors, then k rotates (k independent chains), to see whether the
+// price of mixing the full-rate and the half-rate class depends on how often the stream switches
+#define A_(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define X_(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define R_(i) "v_alignbit_b32 %" #i ", %" #i ", %" #i ", 25\n"
+#define RUN2 A_(0) A_(1) X_(0) X_(1) R_(0) R_(1) A_(2) A_(3) X_(2) X_(3) R_(2) R_(3) A_(4) A_(5) X_(4) X_(5) R_(4) R_(5) A_(6) A_(7) X_(6) X_(7) R_(6) R_(7)
+#define RUN4 A_(0) A_(1) A_(2) A_(3) X_(0) X_(1) X_(2) X_(3) R_(0) R_(1) R_(2) R_(3) A_(4) A_(5) A_(6) A_(7) X_(4) X_(5) X_(6) X_(7) R_(4) R_(5) R_(6) R_(7)
+#define RUN8 A_(0) A_(1) A_(2) A_(3) A_(4) A_(5) A_(6) A_(7) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) R_(0) R_(1) R_(2) R_(3) R_(4) R_(5) R_(6) R_(7)
+// 16 of each: two passes over the 8 chains per class (adds of pass 2 depend on adds of pass 1: chain length 2)
+#define RUN16 A_(0) A_(1) A_(2) A_(3) A_(4) A_(5) A_(6) A_(7) A_(0) A_(1) A_(2) A_(3) A_(4) A_(5) A_(6) A_(7) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) R_(0) R_(1) R_(2) R_(3) R_(4) R_(5) R_(6) R_(7) R_(0) R_(1) R_(2) R_(3) R_(4) R_(5) R_(6) R_(7)
 #define P_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %8 bitop3:0x96\n"
 
 enum Pat { PT_ADD_E64, PT_ADD_LIT, PT_PERM, PT_ALIGNBYTE, PT_LSHL_OR, PT_XAD, PT_ADD3, PT_BFI, PT_LSHL, PT_XOR_SDWA,
            PT_MOV_DPP, PT_PK_ADD16, PT_MUL24, PT_MAD24, PT_MULLO, PT_AXR, PT_AX, PT_AR, PT_AAR, PT_ROT2, PT_AX_PERM,
-           PT_BITOP3 };
+           PT_BITOP3, PT_RUN2, PT_RUN4, PT_RUN8, PT_RUN16 };
 
 #define PBODY(PAT, N)                                                                                        \
     asm volatile(N(PAT)                                                                                      \
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
+                 : "v"(k), "v"(tmp))
+#define PRUN(STR)                                                                                            \
+    asm volatile(STR                                                                                         \
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
                  : "v"(k), "v"(tmp))
 #define X8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT) REP8(PAT)
@@ -206,6 +220,10 @@ __global__ void __launch_bounds__(1024) k_pattern(unsigned *out, Stamp *stamps, 
         else if (PT == PT_ROT2) PBODY(P_ROT2, X4);
         else if (PT == PT_AAR) PBODY(P_AAR, X2);
         else if (PT == PT_BITOP3) PBODY(P_BITOP3, X8);
+        else if (PT == PT_RUN2) { PRUN(RUN2); PRUN(RUN2); }                     // 48 instructions per trip
+        else if (PT == PT_RUN4) { PRUN(RUN4); PRUN(RUN4); }
+        else if (PT == PT_RUN8) { PRUN(RUN8); PRUN(RUN8); }
+        else if (PT == PT_RUN16) { PRUN(RUN16); }
         else if (PT == PT_AXR) { PBODY(P_AXR, X2); PBODY(P_AX, REP8); }          // 48 + 16
         else if (PT == PT_AX_PERM) { PBODY(P_AX_PERM, X2); PBODY(P_AX, REP8); }
     }
@@ -350,6 +368,18 @@ int main(int argc, char **argv)
     RUN_PAT(PT_AXR, "mix add,xor,alignbit")
     RUN_PAT(PT_AX_PERM, "mix add,xor,perm")
     RUN_PAT(PT_ROT2, "rot = lshr + lshl_or")
+#define RUN_PAT48(PT, NAME)                                                                                  \
+    for (int w : {1, 4, 8}) {                                                                                 \
+        Result r = run((const void *)k_pattern<PT>, [&](int g, int t, size_t l, int tr) {                     \
+            hipLaunchKernelGGL((k_pattern<PT>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);         \
+        }, w, 48.0, trips / 2, cus, d_out, d_stamps);                                                         \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_PAT48(PT_RUN2, "runs of 2: a,a,x,x,r,r")
+    RUN_PAT48(PT_RUN4, "runs of 4")
+    RUN_PAT48(PT_RUN8, "runs of 8")
+    RUN_PAT48(PT_RUN16, "runs of 16")
     CHECK(hipFree(d_out));
     CHECK(hipFree(d_stamps));
     return 0;
