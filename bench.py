@@ -313,6 +313,7 @@ def main():
     collective = "none"
     comm = None
     shard_lib = None
+    nccl_group = None                                          # only for the agreed fallback
 
     def all_ok(flag: bool) -> bool:
         t = torch.tensor([1 if flag else 0], device=(torch.device("cpu") if host_group else dev))
@@ -351,14 +352,30 @@ def main():
                   f"{shard_lib.csgn_shard_last_error().decode(errors='replace')}", file=sys.stderr)
         else:
             comm = h
-        if not all_ok(comm is not None):                          # phase 4
+        if not all_ok(comm is not None):                          # phase 4: every rank knows the outcome
+            # Some rank could not join.  Every rank agrees on that (the MIN above), so they leave the native
+            # path TOGETHER -- no rank is left inside a collective -- and try torch.distributed's own RCCL
+            # group for the same gather; if that cannot be formed either the job ends non-zero.
             if comm is not None:
                 shard_lib.csgn_comm_abort(comm)
                 shard_lib.csgn_comm_destroy(comm)
-            sys.exit(1)
-        collective = ("csgn_comm_gather_counts -> ncclAllGather(result term counts) [RCCL %s from %s, native C ABI "
-                      "built against %s; rendezvous over gloo, no torch NCCL group]" % (
-                          capi.rccl_version_text(rt_code), rccl_path, capi.rccl_version_text(hd_code)))
+                comm = None
+            if rank == 0:
+                print("bench.py: native RCCL communicator could not be formed on every rank; all ranks switch to "
+                      "torch.distributed's RCCL group", file=sys.stderr)
+            try:
+                nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:
+                print(f"# rank {rank}: torch RCCL group failed too: {e!r}", file=sys.stderr)
+                sys.exit(1)
+            native = False
+        if comm is not None:
+            collective = ("csgn_comm_gather_counts -> ncclAllGather(result term counts) [RCCL %s from %s, native C ABI "
+                          "built against %s; rendezvous over gloo, no torch NCCL group]" % (
+                              capi.rccl_version_text(rt_code), rccl_path, capi.rccl_version_text(hd_code)))
+        else:
+            collective = ("torch.distributed.all_gather_into_tensor(result term counts) [RCCL, torch process group; "
+                          "FALLBACK: the native communicator failed on some rank, all ranks agreed to switch]")
     torch.cuda.synchronize()
 
     def gather():
@@ -369,7 +386,7 @@ def main():
         elif args.dev_ranks_share_gpu:
             gathered.copy_(gather_term_counts(counts.cpu(), total_pairs, force=True))
         else:
-            gather_term_counts(counts, total_pairs, out=gathered, force=True)
+            gather_term_counts(counts, total_pairs, group=nccl_group, out=gathered, force=True)
 
     def product_counts():
         # per-pair result term counts of this step's products (newlen/dL, src/Ciphertext.cpp:146)

@@ -288,6 +288,70 @@ __device__ inline void chacha_block(const EncKeyed &k, u32 nonce_lo, u32 nonce_h
         x[4 + i] += k.key[i];
     x[12] += ctr_lo; x[13] += ctr_hi; x[14] += nonce_lo; x[15] += nonce_hi;
 }
+
+// TWO blocks at once with the instruction order forced: each of a quarter round's twelve steps is done
+// for all eight quarter rounds in flight (four per block) before the next step starts.  Measured
+// (tools/valu_bench.hip, profiles/r03/valu_issue.txt): the VALU issues a stream that alternates between
+// its full-rate class (add, xor: 2.25 cycles per wave64 instruction) and its half-rate class (rotate:
+// 4.25) at 3.7-3.9 cycles per instruction when the classes change every 1-4 instructions -- which is
+// what hipcc's own schedule of one block does -- but at 3.2 in runs of eight: the price of mixing is
+// paid per switch.  __builtin_amdgcn_sched_barrier(0) keeps hipcc from interleaving the steps again.
+// The two blocks may differ in key, nonce and counter (encrypt: two counters of one stream; fused
+// chain: one counter of two streams).  Words identical to chacha_block (same tests).
+#define CSGN_ST1(a, b, c, d) a += b;
+#define CSGN_ST2(a, b, c, d) d ^= a;
+#define CSGN_ST3(a, b, c, d) d = rotl32(d, 16);
+#define CSGN_ST4(a, b, c, d) c += d;
+#define CSGN_ST5(a, b, c, d) b ^= c;
+#define CSGN_ST6(a, b, c, d) b = rotl32(b, 12);
+#define CSGN_ST7(a, b, c, d) a += b;
+#define CSGN_ST8(a, b, c, d) d ^= a;
+#define CSGN_ST9(a, b, c, d) d = rotl32(d, 8);
+#define CSGN_ST10(a, b, c, d) c += d;
+#define CSGN_ST11(a, b, c, d) b ^= c;
+#define CSGN_ST12(a, b, c, d) b = rotl32(b, 7);
+#define CSGN_COLQ(ST, X) ST(X[0], X[4], X[8], X[12]) ST(X[1], X[5], X[9], X[13]) ST(X[2], X[6], X[10], X[14]) ST(X[3], X[7], X[11], X[15])
+#define CSGN_DIAQ(ST, X) ST(X[0], X[5], X[10], X[15]) ST(X[1], X[6], X[11], X[12]) ST(X[2], X[7], X[8], X[13]) ST(X[3], X[4], X[9], X[14])
+#define CSGN_BOTH(Q, ST) Q(ST, xa) Q(ST, xb) __builtin_amdgcn_sched_barrier(0);
+#define CSGN_HALF(Q)                                                                                      \
+    CSGN_BOTH(Q, CSGN_ST1) CSGN_BOTH(Q, CSGN_ST2) CSGN_BOTH(Q, CSGN_ST3) CSGN_BOTH(Q, CSGN_ST4)            \
+    CSGN_BOTH(Q, CSGN_ST5) CSGN_BOTH(Q, CSGN_ST6) CSGN_BOTH(Q, CSGN_ST7) CSGN_BOTH(Q, CSGN_ST8)            \
+    CSGN_BOTH(Q, CSGN_ST9) CSGN_BOTH(Q, CSGN_ST10) CSGN_BOTH(Q, CSGN_ST11) CSGN_BOTH(Q, CSGN_ST12)
+
+template <int ROUNDS>
+__device__ inline void chacha_block2(const EncKeyed &ka, u32 na_lo, u32 na_hi, u32 ca_lo, u32 ca_hi, const EncKeyed &kb,
+                                     u32 nb_lo, u32 nb_hi, u32 cb_lo, u32 cb_hi, u32 (&xa)[16], u32 (&xb)[16])
+{
+    const u32 c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;   // "expand 32-byte k"
+    xa[0] = c0; xa[1] = c1; xa[2] = c2; xa[3] = c3;
+    xb[0] = c0; xb[1] = c1; xb[2] = c2; xb[3] = c3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xa[4 + i] = ka.key[i];
+        xb[4 + i] = kb.key[i];
+    }
+    xa[12] = ca_lo; xa[13] = ca_hi; xa[14] = na_lo; xa[15] = na_hi;
+    xb[12] = cb_lo; xb[13] = cb_hi; xb[14] = nb_lo; xb[15] = nb_hi;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r += 2) {
+        CSGN_HALF(CSGN_COLQ)
+        CSGN_HALF(CSGN_DIAQ)
+    }
+    xa[0] += c0; xa[1] += c1; xa[2] += c2; xa[3] += c3;
+    xb[0] += c0; xb[1] += c1; xb[2] += c2; xb[3] += c3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xa[4 + i] += ka.key[i];
+        xb[4 + i] += kb.key[i];
+    }
+    xa[12] += ca_lo; xa[13] += ca_hi; xa[14] += na_lo; xa[15] += na_hi;
+    xb[12] += cb_lo; xb[13] += cb_hi; xb[14] += nb_lo; xb[15] += nb_hi;
+}
+#undef CSGN_HALF
+#undef CSGN_BOTH
+#undef CSGN_DIAQ
+#undef CSGN_COLQ
 #undef CSGN_QR
 
 // The draw of src/SecretKey.cpp:51 for ciphertext c in keyed mode: a separate stream of the same key and
@@ -638,8 +702,8 @@ __device__ __forceinline__ void encmul_pass(const EncMulPassCtx &c, u32 &aa_lo, 
 {
     const u64 ctr = c.blk0 + (u64)PI * 64u;
     u32 xa[16], xb[16];
-    chacha_block<ROUNDS>(c.a.rng_a, c.na_lo, c.na_hi, (u32)ctr, (u32)(ctr >> 32), xa);
-    chacha_block<ROUNDS>(c.a.rng_b, c.nb_lo, c.nb_hi, (u32)ctr, (u32)(ctr >> 32), xb);
+    chacha_block2<ROUNDS>(c.a.rng_a, c.na_lo, c.na_hi, (u32)ctr, (u32)(ctr >> 32), c.a.rng_b, c.nb_lo, c.nb_hi, (u32)ctr,
+                          (u32)(ctr >> 32), xa, xb);
     encmul_unit<0, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
     encmul_unit<1, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);
     encmul_unit<2, PI>(c, xa, xb, aa_lo, aa_hi, ab_lo, ab_hi);

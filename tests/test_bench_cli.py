@@ -78,3 +78,21 @@ def test_bench_spawned_rank_with_the_rccl_gather():
     assert len(lines) == 1, p.stdout[:500]                     # RCCL's banner must not reach stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "ncclAllGather" in d["config"]["collective"] and d["config"]["verified_vs_oracle"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_world_size_logic_rehearsed_on_one_gpu(world):
+    """The N > 1 bench path -- ranks started by bench.py, shard ranges from the GLOBAL pair index, host
+    barrier, max-over-ranks time, gathered counts verified on rank 0 -- with every rank on GPU 0 and the
+    exchange on gloo (RCCL refuses two ranks on one device; --dev-ranks-share-gpu is a development
+    rehearsal and says so in config.collective).  value must be the whole job's."""
+    p = run(["--gpus", str(world), "--dev-ranks-share-gpu", "--batch", "256", "--slots", "32", "--steps", "2",
+             "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["verified_vs_oracle"] is True
+    assert "gloo" in d["config"]["collective"] and "DEVELOPMENT" in d["config"]["collective"]
+    assert abs(d["value"] - world * 256 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6

@@ -241,6 +241,130 @@ __global__ void __launch_bounds__(1024) k_pattern(unsigned *out, Stamp *stamps, 
     }
 }
 
+// The ChaCha double round with the instruction ORDER forced: B blocks per lane (4*B independent quarter
+// rounds at a time), each of a quarter round's 12 steps done for all 4*B quarter rounds before the next
+// step starts (__builtin_amdgcn_sched_barrier(0) between steps), so the stream is runs of 4*B adds,
+// 4*B xors, 4*B rotates ...  -- does the cost of mixing the full-rate and the half-rate class fall
+// when the stream switches class less often?
+#define ST1(a, b, c, d) a += b;
+#define ST2(a, b, c, d) d ^= a;
+#define ST3(a, b, c, d) d = rotl32(d, 16);
+#define ST4(a, b, c, d) c += d;
+#define ST5(a, b, c, d) b ^= c;
+#define ST6(a, b, c, d) b = rotl32(b, 12);
+#define ST7(a, b, c, d) a += b;
+#define ST8(a, b, c, d) d ^= a;
+#define ST9(a, b, c, d) d = rotl32(d, 8);
+#define ST10(a, b, c, d) c += d;
+#define ST11(a, b, c, d) b ^= c;
+#define ST12(a, b, c, d) b = rotl32(b, 7);
+#define COLQ(ST, X) ST(X[0], X[4], X[8], X[12]) ST(X[1], X[5], X[9], X[13]) ST(X[2], X[6], X[10], X[14]) ST(X[3], X[7], X[11], X[15])
+#define DIAQ(ST, X) ST(X[0], X[5], X[10], X[15]) ST(X[1], X[6], X[11], X[12]) ST(X[2], X[7], X[8], X[13]) ST(X[3], X[4], X[9], X[14])
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define ALLB(Q, ST)                          \
+    _Pragma("unroll") for (int b = 0; b < BLOCKS; ++b) { Q(ST, x[b]) } \
+    SB
+#define HALF(Q) ALLB(Q, ST1) ALLB(Q, ST2) ALLB(Q, ST3) ALLB(Q, ST4) ALLB(Q, ST5) ALLB(Q, ST6) ALLB(Q, ST7) ALLB(Q, ST8) ALLB(Q, ST9) ALLB(Q, ST10) ALLB(Q, ST11) ALLB(Q, ST12)
+
+template <int BLOCKS>
+__global__ void __launch_bounds__(1024) k_chacha_grouped(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];
+    unsigned x[BLOCKS][16];
+#pragma unroll
+    for (int b = 0; b < BLOCKS; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            x[b][i] = seed * (threadIdx.x + 1u) + (unsigned)(b * 16 + i) * 0x9E3779B9u;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; ++t) {
+        HALF(COLQ)
+        HALF(DIAQ)
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = 0;
+#pragma unroll
+    for (int b = 0; b < BLOCKS; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc ^= x[b][i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
+// Do two VGPR source operands from the same register bank (index mod 4) cost an extra cycle?  64
+// v_add_u32 / v_xor_b32 with EXPLICIT physical registers: dst = src0 = v[32+i], src1 = v[48+i+SKEW]
+// (i = 0..7): SKEW 0 -> src0 and src1 in the same bank, SKEW 1 -> neighbouring banks.
+template <int SKEW, int XOR>
+__global__ void __launch_bounds__(1024) k_bank(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("v_mov_b32 v32, %0\nv_mov_b32 v33, %0\nv_mov_b32 v34, %0\nv_mov_b32 v35, %0\nv_mov_b32 v36, %0\nv_mov_b32 v37, %0\nv_mov_b32 v38, %0\nv_mov_b32 v39, %0\n"
+                 "v_mov_b32 v48, %0\nv_mov_b32 v49, %0\nv_mov_b32 v50, %0\nv_mov_b32 v51, %0\nv_mov_b32 v52, %0\nv_mov_b32 v53, %0\nv_mov_b32 v54, %0\nv_mov_b32 v55, %0\nv_mov_b32 v56, %0\n"
+                 :: "v"(seed * (threadIdx.x + 1u))
+                 : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+#define BK_OP(OPC, d, s) OPC " v" #d ", v" #d ", v" #s "\n"
+#define BK8(OPC, a0, a1, a2, a3, a4, a5, a6, a7) BK_OP(OPC, 32, a0) BK_OP(OPC, 33, a1) BK_OP(OPC, 34, a2) BK_OP(OPC, 35, a3) BK_OP(OPC, 36, a4) BK_OP(OPC, 37, a5) BK_OP(OPC, 38, a6) BK_OP(OPC, 39, a7)
+#define BK64(OPC, ...) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__) BK8(OPC, __VA_ARGS__)
+#define BK_CLOB "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56"
+    for (int t = 0; t < trips; ++t) {
+        if (SKEW == 0 && !XOR) asm volatile(BK64("v_add_u32", 48, 49, 50, 51, 52, 53, 54, 55) ::: BK_CLOB);
+        if (SKEW == 1 && !XOR) asm volatile(BK64("v_add_u32", 49, 50, 51, 52, 53, 54, 55, 56) ::: BK_CLOB);
+        if (SKEW == 0 && XOR) asm volatile(BK64("v_xor_b32", 48, 49, 50, 51, 52, 53, 54, 55) ::: BK_CLOB);
+        if (SKEW == 1 && XOR) asm volatile(BK64("v_xor_b32", 49, 50, 51, 52, 53, 54, 55, 56) ::: BK_CLOB);
+    }
+    unsigned acc;
+    asm volatile("v_xor_b32 %0, v32, v39" : "=v"(acc) :: BK_CLOB);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
+#include "valu_bench_chacha_asm.inc"
+// The ChaCha double round on two blocks as ONE asm statement with explicit registers: runs of 8 per
+// step, and (FRIENDLY) the four words of every quarter round in four different VGPR banks (register
+// index mod 4) -- hipcc's own allocation puts x[i] and x[i+4] in the same bank, so every add and xor of a
+// column round reads two registers of one bank.
+template <int FRIENDLY>
+__global__ void __launch_bounds__(1024) k_chacha_asm(unsigned *out, Stamp *stamps, unsigned seed, int trips)
+{
+    extern __shared__ unsigned char lds_pad[];
+    const unsigned s0 = seed * (threadIdx.x + 1u);
+    asm volatile("v_mov_b32 v64, %0\nv_add_u32 v65, 1, %0\nv_add_u32 v66, 2, %0\nv_add_u32 v67, 3, %0\nv_add_u32 v68, 4, %0\nv_add_u32 v69, 5, %0\nv_add_u32 v70, 6, %0\nv_add_u32 v71, 7, %0\n"
+                 "v_add_u32 v72, 8, %0\nv_add_u32 v73, 9, %0\nv_add_u32 v74, 10, %0\nv_add_u32 v75, 11, %0\nv_add_u32 v76, 12, %0\nv_add_u32 v77, 13, %0\nv_add_u32 v78, 14, %0\nv_add_u32 v79, 15, %0\n"
+                 "v_add_u32 v80, 16, %0\nv_add_u32 v81, 17, %0\nv_add_u32 v82, 18, %0\nv_add_u32 v83, 19, %0\nv_add_u32 v84, 20, %0\nv_add_u32 v85, 21, %0\nv_add_u32 v86, 22, %0\nv_add_u32 v87, 23, %0\n"
+                 "v_add_u32 v88, 24, %0\nv_add_u32 v89, 25, %0\nv_add_u32 v90, 26, %0\nv_add_u32 v91, 27, %0\nv_add_u32 v92, 28, %0\nv_add_u32 v93, 29, %0\nv_add_u32 v94, 30, %0\nv_add_u32 v95, 31, %0\n"
+                 :: "v"(s0) : CHACHA_ASM_CLOBBERS);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < trips; ++t) {
+        if (FRIENDLY)
+            asm volatile(CHACHA_ASM_FRIENDLY ::: CHACHA_ASM_CLOBBERS);
+        else
+            asm volatile(CHACHA_ASM_NATURAL ::: CHACHA_ASM_CLOBBERS);
+    }
+    unsigned acc;
+    asm volatile("v_xor_b32 %0, v64, v95\nv_xor_b32 %0, %0, v70\nv_xor_b32 %0, %0, v81" : "=v"(acc) :: CHACHA_ASM_CLOBBERS);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63u) == 0) {
+        Stamp s;
+        s.cyc = c1 - c0;
+        s.rt = t1 - t0;
+        stamps[((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    }
+}
+
 struct Result {
     double ginstr_s, cyc_per_instr_simd, clock_ghz, ms;
 };
@@ -338,6 +462,39 @@ int main(int argc, char **argv)
     }
     RUN_CHACHA(1, "chacha dround 1 blk")
     RUN_CHACHA(2, "chacha dround 2 blk")
+#define RUN_CHACHA_G(B, NAME)                                                                                 \
+    for (int w : {1, 2, 4}) {                                                                                 \
+        Result r = run((const void *)k_chacha_grouped<B>, [&](int g, int t, size_t l, int tr) {               \
+            hipLaunchKernelGGL((k_chacha_grouped<B>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);   \
+        }, w, 96.0 * B, trips / (2 * B) + 1, cus, d_out, d_stamps);                                           \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+#define RUN_BANK(SK, X, NAME)                                                                                 \
+    for (int w : {2, 8}) {                                                                                    \
+        Result r = run((const void *)k_bank<SK, X>, [&](int g, int t, size_t l, int tr) {                     \
+            hipLaunchKernelGGL((k_bank<SK, X>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);         \
+        }, w, 64.0, trips / 2, cus, d_out, d_stamps);                                                         \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_BANK(0, 0, "add v,v,v same bank")
+    RUN_BANK(1, 0, "add v,v,v other bank")
+    RUN_BANK(0, 1, "xor v,v,v same bank")
+    RUN_BANK(1, 1, "xor v,v,v other bank")
+#define RUN_CHACHA_ASM(F, NAME)                                                                               \
+    for (int w : {1, 2, 4, 8}) {                                                                              \
+        Result r = run((const void *)k_chacha_asm<F>, [&](int g, int t, size_t l, int tr) {                   \
+            hipLaunchKernelGGL((k_chacha_asm<F>), dim3(g), dim3(t), l, 0, d_out, d_stamps, 12345u, tr);       \
+        }, w, 192.0, trips / 4 + 1, cus, d_out, d_stamps);                                                    \
+        printf("  %-22s %5d %8.3f %12.1f %10.3f %12.2f\n", NAME, w, r.ms, r.ginstr_s, r.clock_ghz,            \
+               r.cyc_per_instr_simd);                                                                         \
+    }
+    RUN_CHACHA_ASM(0, "chacha asm x8 natural")
+    RUN_CHACHA_ASM(1, "chacha asm x8 banks")
+    RUN_CHACHA_G(1, "chacha grouped by 4")
+    RUN_CHACHA_G(2, "chacha grouped by 8")
+    RUN_CHACHA_G(4, "chacha grouped by 16")
 #define RUN_PAT(PT, NAME)                                                                                    \
     for (int w : {1, 4, 8}) {                                                                                 \
         Result r = run((const void *)k_pattern<PT>, [&](int g, int t, size_t l, int tr) {                     \
