@@ -210,9 +210,9 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u32 U = (u32)(wide ? dL / 2 : dL);
     const u64 total_units = total_terms_out * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    // at most 4 chunks per workgroup unless the knob says otherwise (as the ragged multiply: with the
-    // 64-ary start-up search more chunks only coarsen the write front); M = min(4, C) chunks per turn
-    const int chunks = csgn::tune(TUNE_RAGGED_C) ? ragged_chunks(total_units) : std::min(4, ragged_chunks(total_units));
+    // chunks per workgroup as the ragged multiply (ragged_chunks: up to 8 while the grid keeps >= 8192
+    // workgroups); M = min(4, C) chunks per turn
+    const int chunks = ragged_chunks(total_units);
     const int turn = csgn::tune(TUNE_RAGGED_M);
     const u64 per_launch = kMaxBlocks256 * 256u;         // units: a multiple of every 256*C
     for (u64 u0 = 0; u0 < total_units; u0 += per_launch) {

@@ -896,9 +896,13 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
-    // 4 KiB chunks per workgroup: at most 4 here since the per-chunk lookup became one scalar round trip
-    // (measured cold, log-normal batch: C=4 5.65 TB/s, C=8 5.24, C=16 4.94, C=2 4.18, C=1 2.48)
-    const int chunks = csgn::tune(TUNE_RAGGED_C) ? ragged_chunks(total_units) : std::min(4, ragged_chunks(total_units));
+    // 4 KiB chunks per workgroup: as many as 8 while the grid keeps >= 8192 workgroups (ragged_chunks).  Round 3,
+    // cold, profiles/r03/bench_ragged.log: on the 2.8 GB log-normal batch C=4 and C=8 are within run-to-run noise
+    // (5.1-5.5 TB/s each over three runs), C=16 4.85, C=2 5.2, C=1 3.9; the 178 MB skewed batch C=1 4.74, C=2 4.66,
+    // C=4 4.47, C=8 4.28 -- small outputs want many short workgroups, which the rule gives them.  A per-workgroup
+    // start table from a pre-kernel (instead of each workgroup's 64-ary search) was tried and measured 0-8 % SLOWER
+    // on all four batches, so it is not here.
+    const int chunks = ragged_chunks(total_units);
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
     // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
@@ -959,11 +963,22 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                          rp.offOut == offOut && rp.batch == batch && rp.total == total_out_terms &&
                          rp.max_t1 == max_t1 && rp.max_t2 == max_t2;
     u64 cursor = 0;
+    // ... and only when those pairs are most of the batch: every split costs launches (a uniform one and the
+    // CSR kernel's on either side, each with its own ramp and tail), which a few 30 MB pairs inside a 2.8 GB
+    // log-normal batch do not repay (measured: 5.03 TB/s split, 5.35 unsplit)
+    bool split = false;
+    if (planned) {
+        u64 huge_terms = 0;
+        for (u32 i = 0; i < rp.n; ++i)
+            if (rp.rec[i][3] * rp.rec[i][4] * dL * 8u >= (24ull << 20))
+                huge_terms += rp.rec[i][3] * rp.rec[i][4];
+        split = huge_terms * 2 >= total_out_terms;
+    }
     if (planned) {
         for (u32 i = 0; i < rp.n; ++i) {
             const u64 pb = rp.rec[i][0], l0 = rp.rec[i][1], r0 = rp.rec[i][2], t1 = rp.rec[i][3], t2 = rp.rec[i][4],
                       o0 = rp.rec[i][5];
-            if (pb >= batch || t1 * t2 * dL * 8u < (24ull << 20) || o0 + t1 * t2 > total_out_terms || o0 * U < cursor)
+            if (!split || pb >= batch || t1 * t2 * dL * 8u < (24ull << 20) || o0 + t1 * t2 > total_out_terms || o0 * U < cursor)
                 continue;
             if (o0 * U > cursor) {
                 const hipError_t e = flat_range(cursor, o0 * U);

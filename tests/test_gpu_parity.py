@@ -1803,7 +1803,7 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     knobs.set("CSGN_RAGGED_TOUCH", "1")                         # ... sliced with the touch pass
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
-    for m, c in ((1, 8), (2, 2), (4, 4)):                       # chunks per turn / per workgroup
+    for m, c in ((1, 8), (2, 2), (4, 4), (4, 8), (4, 16)):      # chunks per turn / per workgroup
         knobs.set("ragged_m", m)
         knobs.set("ragged_c", c)
         out, off = hip.mul_ragged(n, L, dOL, R, dOR)

@@ -9,7 +9,7 @@ CHUNKS=[int(x) for x in os.environ.get('CHUNKS','0').split(',')]
 NSETS=[3]
 VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_RAGGED_TOUCH':'0'}),
           ('cold C=1',{'CSGN_RAGGED_C':'1'}),('cold C=2',{'CSGN_RAGGED_C':'2'}),('cold C=4',{'CSGN_RAGGED_C':'4'}),('cold C=4 M=2',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'2'}),('cold C=4 M=1',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'1'}),
-          ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
+          ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('cold C=16',{'CSGN_RAGGED_C':'16'}),('cold C=8 M=2',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_M':'2'}),('cold C=8 no pf',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_PF':'0'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
           ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
