@@ -78,15 +78,14 @@ __global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, FastDiv ddL
 template <int K>
 __device__ inline u32 lane_xor(u32 v)
 {
-    // all on the VALU (DPP): an LDS-crossbar swizzle costs a round trip the two waves a SIMD
-    // holds here cannot hide
+    // on the VALU (DPP) where one DPP move does it
     if (K == 8)
         return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xF, 0xF, true);
-    if (K == 4) {
-        // lanes with bit 2 clear read lane+4 (row_shl:4, banks 0 and 2), the others lane-4
-        int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
-        return (u32)__builtin_amdgcn_update_dpp(t, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
-    }
+    if (K == 4)   // no DPP pattern gives lane^4 in one go (two masked row shifts + a zeroed destination = 3 VALU
+                  // slots): the LDS crossbar does it in one ds_swizzle, and with 5 waves per SIMD its round trip is
+                  // covered (round 3, profiles/r03/ab_permute_swizzle.log: +5-7 % at N=1247; for the stages that
+                  // cost one DPP the swizzle is no gain, for all four a loss)
+        return (u32)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1F);
     if (K == 2)
         return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true);
     return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
