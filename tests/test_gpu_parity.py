@@ -1803,6 +1803,15 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     knobs.set("CSGN_RAGGED_TOUCH", "1")                         # ... sliced with the touch pass
     out, off = hip.mul_ragged(n, L, dOL, R, dOR)
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
+    # stream order: operands written on the caller's stream right before the call are what the product sees,
+    # and overwriting them right after it does not reach back into it
+    L2, R2 = torch.zeros_like(L), torch.zeros_like(R)
+    for _ in range(3):
+        L2.copy_(L); R2.copy_(R)
+        out, off = hip.mul_ragged(n, L2, dOL, R2, dOR)
+        L2.zero_(); R2.zero_()
+        assert torch.equal(out, ref)
+    del L2, R2
     for m, c in ((1, 8), (2, 2), (4, 4), (4, 8), (4, 16)):      # chunks per turn / per workgroup
         knobs.set("ragged_m", m)
         knobs.set("ragged_c", c)

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""A few launches of the ragged multiply (searching kernel and record form) on the log-normal batch with
-cold operands, and of the uniform flat kernel at the batch's mean shape, for rocprofv3 --pmc (dev tool;
-tools/prof_r02_ragged.sh)."""
+"""A few launches of the ragged multiply on the log-normal batch with cold operands, and of the uniform
+flat kernel at the batch's mean shape, for rocprofv3 --pmc (dev tool; tools/prof_r03_ragged.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,15 +20,11 @@ dL_, dR_ = hip.upload(offL), hip.upload(offR)
 out, off_out = hip.mul_ragged(n, sets[0][0], dL_, sets[0][1], dR_)
 mt1, mt2, tot = int(t1s.max()), int(t2s.max()), int(np.sum(t1s.astype(np.int64) * t2s))
 print("ragged output terms", tot, "bytes", tot * dl * 8)
-for rec in (0, -1):
-    capi.reset_tuning()
-    capi.set_tuning("ragged_rec", rec)
-    for k in range(6):
-        Lk, Rk = sets[k % 3]
-        check(hip.lib.csgn_mul_ragged(n, len(t1s), Lk.data_ptr(), dL_.data_ptr(), Rk.data_ptr(), dR_.data_ptr(),
-                                      out.data_ptr(), off_out.data_ptr(), mt1, mt2, tot, hip.stream))
-    torch.cuda.synchronize()
-capi.reset_tuning()
+for k in range(6):
+    Lk, Rk = sets[k % 3]
+    check(hip.lib.csgn_mul_ragged(n, len(t1s), Lk.data_ptr(), dL_.data_ptr(), Rk.data_ptr(), dR_.data_ptr(),
+                                  out.data_ptr(), off_out.data_ptr(), mt1, mt2, tot, hip.stream))
+torch.cuda.synchronize()
 del out
 # uniform 32x32 x 16384 (16.8 GB would be too much: 2048 pairs per launch through a small arena)
 pairs = 16384
