@@ -630,8 +630,18 @@ __global__ void __launch_bounds__(256) k_touch_ragged(const u32 *__restrict__ L,
                                                       const u64 *__restrict__ offOut, u32 batch, u64 term_lo,
                                                       u64 term_hi, u64 term_bytes)
 {
-    const u32 p_lo = csr_find(offOut, 0u, batch, term_lo);          // uniform searches: loads broadcast
-    const u32 p_hi = csr_find(offOut, 0u, batch, term_hi - 1);
+    // the first and the last pair of the slice: two 64-ary wave searches side by side (waves 0 and 1), three or
+    // four round trips in all -- the two binary searches that stood here were ~28 dependent loads, most of the
+    // kernel's 20 us (PMC round 3: 60 VALU instructions per wave, parked 94 % of the time)
+    __shared__ u32 s_p[2];
+    const u32 wave = threadIdx.x >> 6;
+    if (wave < 2u) {
+        const u32 f = wave_find(offOut, 0u, batch, wave == 0u ? term_lo : term_hi - 1);
+        if ((threadIdx.x & (kWave - 1)) == 0u)
+            s_p[wave] = f;
+    }
+    __syncthreads();
+    const u32 p_lo = s_p[0], p_hi = s_p[1];
     const u64 lb = offL[p_lo] * term_bytes, le = offL[p_hi + 1] * term_bytes;
     const u64 rb = offR[p_lo] * term_bytes, re = offR[p_hi + 1] * term_bytes;
     const u64 op = (le - lb) + (re - rb);
@@ -639,14 +649,20 @@ __global__ void __launch_bounds__(256) k_touch_ragged(const u32 *__restrict__ L,
         return;
     const u64 stride = (u64)gridDim.x * 256u * 128u;
     const u64 first = ((u64)blockIdx.x * 256u + threadIdx.x) * 128u;
-    for (u64 a = lb + first; a < le; a += stride) {
-        const u32 v = L[a >> 2];
-        asm volatile("" ::"v"(v));
-    }
-    for (u64 a = rb + first; a < re; a += stride) {
-        const u32 v = R[a >> 2];
-        asm volatile("" ::"v"(v));
-    }
+    // four lines per thread in flight at a time (the values are not used; the asm only keeps the loads)
+    auto touch = [&](const u32 *__restrict__ base, u64 b, u64 e) {
+        for (u64 a = b + first; a < e; a += 4u * stride) {
+            u32 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[i] = base[min(a + (u64)i * stride, e - 4u) >> 2];
+            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        }
+    };
+    if (le - lb >= 4u)
+        touch(L, lb, le);
+    if (re - rb >= 4u)
+        touch(R, rb, re);
 }
 
 // One uniform chunk (pairs are contiguous in L, R and out).
@@ -917,7 +933,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             const u64 nu = (range_end - u0 < per_launch) ? range_end - u0 : per_launch;
             const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
             if (touch)
-                k_touch_ragged<<<512, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
+                k_touch_ragged<<<2048, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
                                                    reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
                                                    u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
 #define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
