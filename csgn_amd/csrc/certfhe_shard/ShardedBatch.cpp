@@ -44,7 +44,7 @@ struct ShardWorker {
     std::condition_variable cv;
     std::deque<std::function<void()> > queue;
     bool quit = false;
-    bool fail_next = false;                                   // test hook
+    std::atomic<bool> fail_next{false};                       // test hook (set by the caller's thread)
     std::vector<std::pair<size_t, void *> > pool;             // (bytes, ptr) free blocks of this GPU
     size_t pooled = 0;
 
@@ -171,8 +171,7 @@ struct ShardGroupImpl {
             ShardWorker *me = x.get();
             auto task = [this, me, &f, &done_mu, &done_cv, &left] {
                 try {
-                    if (me->fail_next) {
-                        me->fail_next = false;
+                    if (me->fail_next.exchange(false)) {
                         throw std::runtime_error("injected failure (ShardGroup::injectFailure)");
                     }
                     if (dead.load())
@@ -316,7 +315,7 @@ void ShardGroup::setTimeoutMs(uint64_t ms)
         ck(csgn_comm_set_timeout_ms(x->comm, ms), "csgn_comm_set_timeout_ms");
 }
 
-void ShardGroup::injectFailure(int rank) { impl->w.at(rank)->fail_next = true; }
+void ShardGroup::injectFailure(int rank) { impl->w.at(rank)->fail_next.store(true); }
 
 void ShardGroup::forceGroupedBroadcast(bool on)
 {

@@ -72,6 +72,24 @@ inline uint64_t ceil_mul_div(uint64_t a, uint64_t b, uint64_t d)
     return (uint64_t)((p + d - 1) / d);
 }
 
+// Puts the calling thread's current device back when it goes out of scope: the calls that walk over
+// several GPUs (csgn_comm_init_all*, csgn_comm_destroy) must not leave their caller on another device.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard()
+    {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            saved = -1;
+            (void)hipGetLastError();
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (saved >= 0)
+            (void)hipSetDevice(saved);
+    }
+};
+
 int finish_comm(csgn_comm *c)
 {
     HIP_TRY(hipSetDevice(c->device));
@@ -248,18 +266,20 @@ int csgn_comm_init_all_ex(int ndev, const int *devices, unsigned flags, csgn_com
         REQUIRE(devs[i] >= 0 && devs[i] < have, "device %d not visible (have %d)", devs[i], have);
         comms[i] = nullptr;
     }
+    DeviceGuard guard;
     std::vector<ncclComm_t> nc(ndev, nullptr);
     NCCL_TRY(ncclCommInitAll(nc.data(), ndev, devs.data()));
-    for (int i = 0; i < ndev; ++i) {
-        csgn_comm *c = new csgn_comm();
+    for (int i = 0; i < ndev; ++i) {                 // every RCCL communicator gets its owner first, so that a
+        csgn_comm *c = new csgn_comm();              // failure below leaves nothing the caller cannot destroy
         c->nccl = nc[i];
         c->rank = i;
         c->world = ndev;
         c->device = devs[i];
         comms[i] = c;
-        if (int rc = finish_comm(c))
-            return rc;
     }
+    for (int i = 0; i < ndev; ++i)
+        if (int rc = finish_comm(comms[i]))
+            return rc;                               // the caller destroys comms[0..ndev)
     return CSGN_OK;
 }
 
@@ -311,6 +331,7 @@ int csgn_comm_destroy(csgn_comm *c)
 {
     if (!c)
         return CSGN_OK;
+    DeviceGuard guard;
     (void)hipSetDevice(c->device);
     const bool aborted = c->aborted.load();
     if (c->stream && !aborted)

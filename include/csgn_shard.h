@@ -78,15 +78,19 @@ int csgn_comm_rccl_info(int *h_runtime, int *h_header, char *h_path, size_t cap)
 int csgn_comm_device_count(int *h_count);
 /* One process driving `ndev` GPUs with one host thread each: fills comms[0..ndev) (rank i on
  * device devices[i], or device i when devices == NULL).  Each comm owns a non-blocking stream on
- * its device (csgn_comm_stream; pass it, or CSGN_STREAM_OF_COMM, to use it). */
+ * its device (csgn_comm_stream; pass it, or CSGN_STREAM_OF_COMM, to use it).  The calling thread's
+ * current device is the same after the call as before.  On failure comms[] holds what was made
+ * (NULL or a communicator each): pass every non-NULL one to csgn_comm_destroy. */
 int csgn_comm_init_all(int ndev, const int *devices, csgn_comm **comms);               /* flags = CSGN_COMM_STRICT */
 int csgn_comm_init_all_ex(int ndev, const int *devices, unsigned flags, csgn_comm **comms);
-/* One process per GPU: rank 0 makes the id, every rank (0 included) joins with it. */
+/* One process per GPU: rank 0 makes the id, every rank (0 included) joins with it.  csgn_comm_init_rank*
+ * leaves the calling thread ON `device` (the thread that owns the rank). */
 int csgn_comm_unique_id(unsigned char h_id[CSGN_COMM_ID_BYTES]);
 int csgn_comm_init_rank(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
                         csgn_comm **comm);                                             /* flags = CSGN_COMM_STRICT */
 int csgn_comm_init_rank_ex(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
                            unsigned flags, csgn_comm **comm);
+/* Waits for the communicator's stream (unless aborted), frees it; the caller's current device is unchanged. */
 int csgn_comm_destroy(csgn_comm *comm);
 /* ncclCommAbort: releases every peer blocked in a collective with this communicator's rank missing.
  * Callable from any host thread, any number of times; afterwards only csgn_comm_destroy is valid. */

@@ -251,6 +251,29 @@ def test_native_comm_from_python_world_1(shard_lib):
 
 
 @pytest.mark.gpu
+def test_init_all_and_destroy_leave_the_callers_device_alone(shard_lib):
+    """csgn_comm_init_all_ex walks over the devices and csgn_comm_destroy switches to the communicator's:
+    both put the calling thread's current device back (a host thread that owns GPU 0 must not find itself on
+    GPU 7 after tearing a group down).  With one GPU on the box the device number cannot differ, so the check
+    is on the contract's other half as well: every communicator comes back usable and is destroyed cleanly."""
+    import torch
+    from csgn_amd import capi
+    before = torch.cuda.current_device()
+    comms = (C.c_void_p * 1)()
+    devs = (C.c_int * 1)(0)
+    capi.check_shard(shard_lib.csgn_comm_init_all_ex(1, devs, capi.CSGN_COMM_ALLOW_MINOR_SKEW, comms))
+    try:
+        assert comms[0] and shard_lib.csgn_comm_device(C.c_void_p(comms[0])) == 0
+        assert torch.cuda.current_device() == before
+        capi.check_shard(shard_lib.csgn_comm_barrier(C.c_void_p(comms[0]), capi.CSGN_STREAM_OF_COMM))
+    finally:
+        shard_lib.csgn_comm_destroy(C.c_void_p(comms[0]))
+    assert torch.cuda.current_device() == before
+    x = torch.arange(10, device="cuda")                        # the thread's context still works
+    assert int(x.sum()) == 45
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which", ["explicit", "null", "comm"])
 def test_gather_is_ordered_behind_its_producer_on_the_launch_stream(shard_lib, which):
     """the gather must run on the stream it is GIVEN.  NULL is the legacy default
