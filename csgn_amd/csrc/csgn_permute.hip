@@ -314,13 +314,13 @@ __global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes3(u32 n_bit
                 }
             }
         };
+        // every wave runs every batch, also one whose items are all past the end for it (the group waits at
+        // the barrier for the wave that does have them; unconditional code lets the registers of w die here)
 #pragma unroll
         for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
-            if (wave + (u32)c0 * W < NI)
-                to_planes(std::integral_constant<int, CI>(), c0);
+            to_planes(std::integral_constant<int, CI>(), c0);
         if constexpr (MAXI % CI != 0)
-            if (wave + (u32)(MAXI / CI * CI) * W < NI)
-                to_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+            to_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
         __syncthreads();
         if (g + gridDim.x < groups)
             fetch(g + gridDim.x);                            // travels during D..F
@@ -347,11 +347,9 @@ __global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes3(u32 n_bit
         };
 #pragma unroll
         for (int c0 = 0; c0 + CI <= MAXI; c0 += CI)
-            if (wave + (u32)c0 * W < NI)
-                from_planes(std::integral_constant<int, CI>(), c0);
+            from_planes(std::integral_constant<int, CI>(), c0);
         if constexpr (MAXI % CI != 0)
-            if (wave + (u32)(MAXI / CI * CI) * W < NI)
-                from_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
+            from_planes(std::integral_constant<int, MAXI % CI>(), MAXI / CI * CI);
         __syncthreads();
         // E. new words -> rows
 #pragma unroll
