@@ -1165,6 +1165,65 @@ def test_concurrent_host_threads_on_separate_streams(hip, oracle):
     assert not errors, errors
 
 
+def test_concurrent_host_threads_ragged_plans_encrypt_and_permute(hip, oracle):
+    """Per-host-thread state of the library under concurrency: every thread plans its OWN skewed CSR batch (one
+    pair of >= 24 MB of output, so csgn_mul_ragged consults the plan its thread remembered), draws keyed
+    ciphertexts and permutes them, each on its own stream, four threads at once.  A plan remembered by one
+    thread must never steer another thread's multiply; all results equal the oracle's."""
+    import threading
+    import torch
+    n, d, dl = 1247, 16, 20
+    key = make_key(n, d, 43)
+    dmask_host = hip.key_mask(n, key)
+    errors = []
+
+    def worker(idx):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                dmask, dkey = hip.upload(dmask_host), hip.upload(key)
+                rng_np = np.random.default_rng(900 + idx)
+                for it in range(3):
+                    batch = 40 + 7 * idx + it
+                    t1s, t2s = rng_np.integers(0, 5, size=batch), rng_np.integers(0, 5, size=batch)
+                    big = int(rng_np.integers(0, batch))
+                    t1s[big], t2s[big] = 400 + idx, 400 + 3 * it          # >= 160 000 product terms: 25.6 MB
+                    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+                    hl = oracle.synth(3000 + 10 * idx + it, n, 0, int(offL[-1]) * dl)
+                    hr = oracle.synth(4000 + 10 * idx + it, n, 0, int(offR[-1]) * dl)
+                    out, off = hip.mul_ragged(n, hip.upload(hl), hip.upload(offL), hip.upload(hr), hip.upload(offR))
+                    mo = hip.download(off)
+                    assert np.array_equal(mo, csr((t1s * t2s).tolist()))
+                    for b in {big, 0, batch - 1, max(0, big - 1), min(batch - 1, big + 1)}:
+                        if t1s[b] and t2s[b]:
+                            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl],
+                                                 hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+                            assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), (idx, it, b)
+                    # keyed encrypt at a thread-specific stream position, then a permutation of the fresh batch
+                    rng = hip.rng_from_seed(500 + idx, 8)
+                    rk, nonce = oracle.rng_from_seed(500 + idx)
+                    plain = rng_np.integers(0, 2, 300 + idx).astype(np.uint8)
+                    first = 1000 * idx + 17 * it
+                    ct = hip.encrypt_keyed(n, d, hip.upload(plain), dkey, dmask, rng, first_ciphertext=first)
+                    got = hip.download(ct)
+                    assert np.array_equal(got, oracle.encrypt_keyed(n, key, plain, rk, nonce, 8, first_ciphertext=first))
+                    perm = np.random.default_rng(idx * 31 + it).permutation(n).astype(np.uint32)
+                    pc = hip.download(hip.permute_uniform(n, plain.size, 1, ct, hip.upload(perm)))
+                    for c in (0, plain.size - 1):
+                        assert np.array_equal(pc[c * dl:(c + 1) * dl], oracle.permute_ciphertext(n, perm, got[c * dl:(c + 1) * dl]))
+                stream.synchronize()
+        except Exception as e:          # noqa: BLE001
+            import traceback
+            errors.append((idx, repr(e), traceback.format_exc()[-600:]))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_mul_fresh_batch_one_million(hip, oracle):
     """BASELINE config 4 per-GPU shape and beyond: 1,048,576 independent 1x1 products."""
     n, batch, dl = 1247, 1 << 20, 20
