@@ -566,7 +566,7 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 //     LDS-tiled kernel, 6.2 against 3.9 at 32x32, 5.7 against 4.6 at 8x8.  The touch is a second
 //     read of the operands, hence the 4x condition, and is done per <= 64 MB of operands so that
 //     they are still in the 256 MB cache when their pairs run.
-//   * otherwise rows shorter than a workgroup (t2*U < 256 units; < 64 for the 8-byte units of an
+//   * otherwise rows shorter than half a workgroup (t2*U < 128 units; < 64 for the 8-byte units of an
 //     odd dL, whose flat kernel only writes 2 KiB per workgroup): the flat kernel, no touch (the
 //     tiled kernel leaves column lanes idle: 1.4 vs 6.0 TB/s at t2 = 1).
 //   * everything else (thin products with long rows, 8-byte units): the LDS-tiled kernel.
@@ -603,7 +603,11 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
     if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && ((streaming && !shared) || touch_env > 0)) {
         p.flat = 1;
         p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
-    } else if (t2 * U < (unit_bytes == 16 ? 256u : 64u)) {
+    } else if (t2 * U < (unit_bytes == 16 ? 128u : 64u)) {
+        // rows shorter than 2 KiB: the tiled kernel's workgroups would be mostly idle lanes.  From 128 units on it
+        // wins on thin products whose operands the previous kernel has just written (round 3, profiles/r03/
+        // ab_fresh_operands_thin.log: 4x16 at N=1247 4.65 -> 6.0 TB/s, 4x4 / 16x4 / 64x4 at N=4096 +10-20 %;
+        // at 64 units -- 64x2 at N=4096 -- the flat kernel still leads 5.7 to 4.6)
         p.flat = 1;
         p.touch = touch_env > 0 ? (touch_env & 3) : 0;
     }

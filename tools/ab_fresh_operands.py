@@ -1,6 +1,8 @@
+#!/usr/bin/env python3
 """Are operands that the previous kernel just WROTE warm or cold for the multiply?  (dev probe)
 L and R are produced by csgn_add_uniform right before every timed multiply, into buffers that rotate through
-more memory than the 256 MB memory-side cache; multiply timed alone, default touch policy vs none."""
+more memory than the 256 MB memory-side cache; the multiply is timed alone under several dispatch choices.
+    python tools/ab_fresh_operands.py [thin]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,33 +10,40 @@ from csgn_amd.batch import HipPath
 from csgn_amd import capi
 from csgn_amd.capi import check
 hip = HipPath(0)
+SQUARE = [(8, 8, 32768), (16, 16, 16384), (32, 32, 4096), (64, 64, 1024), (8, 8, 131072)]
+THIN = [(2, 2, 262144), (4, 4, 131072), (4, 16, 32768), (16, 4, 32768), (2, 64, 16384), (64, 2, 16384), (4, 64, 8192),
+        (64, 4, 8192), (2, 1024, 1024), (1024, 2, 1024), (8, 32, 8192), (32, 8, 8192)]
+VARIANTS = [("default", {}), ("touch0", {"mul_touch": 0}), ("touch3", {"mul_touch": 3}), ("tiled", {"mul_flat": -1}),
+            ("flat2+touch", {"mul_flat": 2, "mul_touch": 3})]
+shapes = THIN if "thin" in sys.argv[1:] else SQUARE
 for n in (1247, 4096):
     dl = hip.default_len(n)
-    for t, batch in [(8, 32768), (16, 16384), (32, 4096), (64, 1024), (8, 131072)]:
-        h = t // 2
-        A1 = hip.synth_fill(1, n, 0, batch * h * dl); A2 = hip.synth_fill(2, n, 0, batch * h * dl)
-        B1 = hip.synth_fill(3, n, 0, batch * h * dl); B2 = hip.synth_fill(4, n, 0, batch * h * dl)
-        op_bytes = batch * t * dl * 8
-        nsets = max(3, int(600e6 // (2 * op_bytes)) + 1)
-        Ls = [hip.empty_words(batch * t * dl) for _ in range(nsets)]
-        Rs = [hip.empty_words(batch * t * dl) for _ in range(nsets)]
-        out = hip.empty_words(batch * t * t * dl)
+    for t1, t2, batch in shapes:
+        h1, h2 = t1 // 2, t2 // 2
+        A1 = hip.synth_fill(1, n, 0, batch * h1 * dl); A2 = hip.synth_fill(2, n, 0, batch * h1 * dl)
+        B1 = hip.synth_fill(3, n, 0, batch * h2 * dl); B2 = hip.synth_fill(4, n, 0, batch * h2 * dl)
+        op_bytes = batch * (t1 + t2) * dl * 8
+        nsets = max(3, int(600e6 // op_bytes) + 1)
+        Ls = [hip.empty_words(batch * t1 * dl) for _ in range(nsets)]
+        Rs = [hip.empty_words(batch * t2 * dl) for _ in range(nsets)]
+        out = hip.empty_words(batch * t1 * t2 * dl)
         row = []
-        for name, kn in [("default", {}), ("touch0", {"mul_touch": 0}), ("default", {}), ("touch0", {"mul_touch": 0})]:
+        for name, kn in VARIANTS:
             ts = []
-            for it in range(12):
+            for it in range(10):
                 k = it % nsets
                 capi.reset_tuning()
-                check(hip.lib.csgn_add_uniform(n, batch, h, h, A1.data_ptr(), A2.data_ptr(), Ls[k].data_ptr(), hip.stream))
-                check(hip.lib.csgn_add_uniform(n, batch, h, h, B1.data_ptr(), B2.data_ptr(), Rs[k].data_ptr(), hip.stream))
+                check(hip.lib.csgn_add_uniform(n, batch, h1, h1, A1.data_ptr(), A2.data_ptr(), Ls[k].data_ptr(), hip.stream))
+                check(hip.lib.csgn_add_uniform(n, batch, h2, h2, B1.data_ptr(), B2.data_ptr(), Rs[k].data_ptr(), hip.stream))
                 for kk, v in kn.items():
                     capi.set_tuning(kk, v)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); hip.mul_uniform(n, batch, t, t, Ls[k], Rs[k], out=out); b.record(); b.synchronize()
+                a.record(); hip.mul_uniform(n, batch, t1, t2, Ls[k], Rs[k], out=out); b.record(); b.synchronize()
                 if it >= 2:
                     ts.append(a.elapsed_time(b) / 1e3)
             tm = statistics.median(ts)
-            row.append("%s %.0f" % (name, batch * 8 * dl * (2 * t + t * t) / tm / 1e9))
+            kname = hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode()
+            row.append("%s %.0f%s" % (name, batch * 8 * dl * (t1 + t2 + t1 * t2) / tm / 1e9, " [" + kname + "]" if name == "default" else ""))
         capi.reset_tuning()
-        print(f"N={n} {t}x{t} x{batch} (operands {2*op_bytes/1e6:.0f} MB, {nsets} sets): " + " | ".join(row), flush=True)
+        print(f"N={n} {t1}x{t2} x{batch} (operands {op_bytes/1e6:.0f} MB, {nsets} sets): " + " | ".join(row), flush=True)
         del Ls, Rs, out, A1, A2, B1, B2
