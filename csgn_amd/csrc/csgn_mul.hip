@@ -607,8 +607,12 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
         // rows shorter than 2 KiB: the tiled kernel's workgroups would be mostly idle lanes.  From 128 units on it
         // wins on thin products whose operands the previous kernel has just written (round 3, profiles/r03/
         // ab_fresh_operands_thin.log: 4x16 at N=1247 4.65 -> 6.0 TB/s, 4x4 / 16x4 / 64x4 at N=4096 +10-20 %;
-        // at 64 units -- 64x2 at N=4096 -- the flat kernel still leads 5.7 to 4.6)
-        p.flat = 1;
+        // at 64 units -- 64x2 at N=4096 -- the flat kernel still leads 5.7 to 4.6).
+        // Tall products (every few lanes start a new row, i.e. a new left term that nobody has loaded yet) take
+        // two output units per lane: twice the loads in flight per wave against the miss latency -- 16x4 at
+        // N=1247 4.33 -> 5.03 TB/s, 64x2 / 1024x2 / 16x2 / 4x4 +7-10 % at both N, 2x2 unchanged
+        // (profiles/r03/ab_fresh_operands_tall.log)
+        p.flat = t1 >= 4 ? 2 : 1;
         p.touch = touch_env > 0 ? (touch_env & 3) : 0;
     }
     return p;

@@ -15,7 +15,12 @@ THIN = [(2, 2, 262144), (4, 4, 131072), (4, 16, 32768), (16, 4, 32768), (2, 64, 
         (64, 4, 8192), (2, 1024, 1024), (1024, 2, 1024), (8, 32, 8192), (32, 8, 8192)]
 VARIANTS = [("default", {}), ("touch0", {"mul_touch": 0}), ("touch3", {"mul_touch": 3}), ("tiled", {"mul_flat": -1}),
             ("flat2+touch", {"mul_flat": 2, "mul_touch": 3})]
-shapes = THIN if "thin" in sys.argv[1:] else SQUARE
+TALL = [(2, 2, 262144), (4, 4, 131072), (16, 4, 32768), (64, 4, 8192), (64, 2, 16384), (1024, 2, 1024), (256, 8, 1024), (16, 2, 65536)]
+if "tall" in sys.argv[1:]:
+    VARIANTS = [("default", {}), ("flat1", {"mul_flat": 1, "mul_touch": 0}), ("flat2", {"mul_flat": 2, "mul_touch": 0}),
+                ("flat4", {"mul_flat": 4, "mul_touch": 0}), ("flat8", {"mul_flat": 8, "mul_touch": 0}),
+                ("flat1+touchL", {"mul_flat": 1, "mul_touch": 1}), ("flat2+touchL", {"mul_flat": 2, "mul_touch": 1}), ("default", {})]
+shapes = THIN if "thin" in sys.argv[1:] else TALL if "tall" in sys.argv[1:] else SQUARE
 for n in (1247, 4096):
     dl = hip.default_len(n)
     for t1, t2, batch in shapes:
