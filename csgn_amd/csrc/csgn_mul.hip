@@ -601,7 +601,12 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
     // fetches each left term once per 4 rows x 4 KiB whatever the cache holds, keeps 4.8.
     const bool shared = csgn::tune(TUNE_SHARED_GPU) != 0;
     if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && ((streaming && !shared) || touch_env > 0)) {
-        p.flat = 1;
+        // rows shorter than a workgroup's 256 units: a wave crosses row boundaries, every crossing is a new
+        // left term, and two units per lane keep twice the loads in flight -- N=1247 16x16 4.7 -> 5.4 TB/s,
+        // 16x8 / 8x16 +5 %, 8x8 +10 % at 32 768 pairs and -2 % at 131 072; with rows of 256 units and more
+        // (every N=4096 shape from 8x8 up, the bench shape) one unit per lane stays 1-3 % ahead
+        // (profiles/r03/ab_fresh_operands_mid.log)
+        p.flat = t2 * U < 256u ? 2 : 1;
         p.touch = touch_env >= 0 ? (touch_env & 3) : 3;
     } else if (t2 * U < (unit_bytes == 16 ? 128u : 64u)) {
         // rows shorter than 2 KiB: the tiled kernel's workgroups would be mostly idle lanes.  From 128 units on it

@@ -20,7 +20,12 @@ if "tall" in sys.argv[1:]:
     VARIANTS = [("default", {}), ("flat1", {"mul_flat": 1, "mul_touch": 0}), ("flat2", {"mul_flat": 2, "mul_touch": 0}),
                 ("flat4", {"mul_flat": 4, "mul_touch": 0}), ("flat8", {"mul_flat": 8, "mul_touch": 0}),
                 ("flat1+touchL", {"mul_flat": 1, "mul_touch": 1}), ("flat2+touchL", {"mul_flat": 2, "mul_touch": 1}), ("default", {})]
-shapes = THIN if "thin" in sys.argv[1:] else TALL if "tall" in sys.argv[1:] else SQUARE
+MID = [(8, 8, 32768), (8, 8, 131072), (6, 6, 65536), (8, 16, 16384), (16, 8, 16384), (12, 12, 16384), (16, 16, 16384), (24, 24, 4096), (32, 32, 4096)]
+if "mid" in sys.argv[1:]:
+    VARIANTS = [("(warm-up)", {}), ("default", {}), ("flat2+touch", {"mul_flat": 2, "mul_touch": 3}), ("default", {}),
+                ("flat2+touch", {"mul_flat": 2, "mul_touch": 3}), ("flat2", {"mul_flat": 2, "mul_touch": 0}), ("tiled", {"mul_flat": -1}),
+                ("default", {}), ("flat2+touch", {"mul_flat": 2, "mul_touch": 3})]
+shapes = THIN if "thin" in sys.argv[1:] else TALL if "tall" in sys.argv[1:] else MID if "mid" in sys.argv[1:] else SQUARE
 for n in (1247, 4096):
     dl = hip.default_len(n)
     for t1, t2, batch in shapes:
@@ -48,7 +53,7 @@ for n in (1247, 4096):
                     ts.append(a.elapsed_time(b) / 1e3)
             tm = statistics.median(ts)
             kname = hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode()
-            row.append("%s %.0f%s" % (name, batch * 8 * dl * (t1 + t2 + t1 * t2) / tm / 1e9, " [" + kname + "]" if name == "default" else ""))
+            row.append("%s %.0f%s" % (name, batch * 8 * dl * (t1 + t2 + t1 * t2) / tm / 1e9, " [" + kname + "]" if name == "default" and not any("[" in r for r in row) else ""))
         capi.reset_tuning()
         print(f"N={n} {t1}x{t2} x{batch} (operands {op_bytes/1e6:.0f} MB, {nsets} sets): " + " | ".join(row), flush=True)
         del Ls, Rs, out, A1, A2, B1, B2
