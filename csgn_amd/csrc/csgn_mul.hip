@@ -559,8 +559,8 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 // that are not in any cache, tools/bench_cold.py, profiles/r01/bench_cold*.log):
 //   * output >= 4x the operands (t1*t2 >= 4*(t1+t2)), 16-byte units, and at least 4 MB of operands
 //     in the launch (a stream, not a single product): the flat kernel (one output
-//     unit per lane, linear 4 KiB per workgroup, XCD-contiguous order) AFTER a touch pass that
-//     reads one dword of every operand line.  The flat kernel alone stalls on the first touch of
+//     unit per lane -- two when a row is shorter than a workgroup --, linear 4 KiB per workgroup,
+//     XCD-contiguous order) AFTER a touch pass that reads one dword of every operand line.  The flat kernel alone stalls on the first touch of
 //     every left term (an HBM miss under full write load, 4.6 TB/s at 1024x1024); with the
 //     operands already in the memory-side cache it runs at 7.2-7.5 TB/s against 6.9 for the
 //     LDS-tiled kernel, 6.2 against 3.9 at 32x32, 5.7 against 4.6 at 8x8.  The touch is a second
@@ -568,7 +568,11 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 //     they are still in the 256 MB cache when their pairs run.
 //   * otherwise rows shorter than half a workgroup (t2*U < 128 units; < 64 for the 8-byte units of an
 //     odd dL, whose flat kernel only writes 2 KiB per workgroup): the flat kernel, no touch (the
-//     tiled kernel leaves column lanes idle: 1.4 vs 6.0 TB/s at t2 = 1).
+//     tiled kernel leaves column lanes idle: 1.4 vs 6.0 TB/s at t2 = 1), two units per lane when
+//     the product is tall (t1 >= 4).
+// Round 3 re-measured the small and thin shapes with operands that the PREVIOUS KERNEL HAD JUST WRITTEN
+// (tools/ab_fresh_operands.py): such lines are not in the memory-side cache, so a multiply chain is
+// the cold case and the touch stays; the thresholds below come from those runs.
 //   * everything else (thin products with long rows, 8-byte units): the LDS-tiled kernel.
 // CSGN_MUL_FLAT (-1 tiled, k > 0 flat with k units per lane) and CSGN_MUL_TOUCH (0..3: bit 0 left,
 // bit 1 right operand) override for sweeps.
