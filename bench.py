@@ -240,6 +240,10 @@ def main():
             print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}; refusing to run",
                   file=sys.stderr)
         sys.exit(2)
+    # dmabuf IPC is the only mode this pool's host driver supports; RCCL's peer mappings between rank
+    # processes fail with "hipIpcGetMemHandle: invalid argument" without it.  Set before anything
+    # initialises HIP in this process (the spawning parent sets it for its children as well).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a
     # communicator is created, so everything but the final line goes to stderr: fd 1 is pointed at
     # fd 2 for the run and the line is written to the saved descriptor.

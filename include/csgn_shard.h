@@ -84,7 +84,10 @@ int csgn_comm_device_count(int *h_count);
 int csgn_comm_init_all(int ndev, const int *devices, csgn_comm **comms);               /* flags = CSGN_COMM_STRICT */
 int csgn_comm_init_all_ex(int ndev, const int *devices, unsigned flags, csgn_comm **comms);
 /* One process per GPU: rank 0 makes the id, every rank (0 included) joins with it.  csgn_comm_init_rank*
- * leaves the calling thread ON `device` (the thread that owns the rank). */
+ * leaves the calling thread ON `device` (the thread that owns the rank).  Rank PROCESSES map one another's
+ * buffers through HIP IPC: on hosts whose driver only supports dmabuf IPC (this pool), export
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 before the process makes its first HIP call -- the library cannot set it
+ * late enough to matter. */
 int csgn_comm_unique_id(unsigned char h_id[CSGN_COMM_ID_BYTES]);
 int csgn_comm_init_rank(const unsigned char h_id[CSGN_COMM_ID_BYTES], int rank, int world, int device,
                         csgn_comm **comm);                                             /* flags = CSGN_COMM_STRICT */
