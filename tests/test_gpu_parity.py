@@ -286,6 +286,85 @@ def test_mul_rejects_bad_arguments(hip):
         check(hip.lib.csgn_mul_uniform(1 << 20, 1, 1, 1, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0))
 
 
+def test_c_abi_refuses_bad_arguments_before_any_launch(hip):
+    """Every compute entry point of include/csgn_hip.h turns a null pointer, N = 0, an oversized N, a bad generator
+    or a bad circuit id into a non-zero status with a message -- checked on the host before anything is
+    launched, so a caller's mistake can never become a device fault."""
+    import ctypes as C
+    import torch
+    from csgn_amd import capi
+    L = hip.lib
+    x = hip.empty_words(4096)
+    b = torch.zeros(4096, dtype=torch.uint8, device=hip.device)
+    X, B, S, n = x.data_ptr(), b.data_ptr(), hip.stream, 1247
+    rng = hip.rng_from_seed(1, 8)
+    bad_rng = hip.rng_from_seed(1, 8)
+    bad_rng.rounds = 7
+    plan = (C.c_uint64 * 4)()
+    cases = {
+        "mul N=0": lambda: L.csgn_mul_uniform(0, 1, 1, 1, X, X, X, 0, S),
+        "mul N too large": lambda: L.csgn_mul_uniform(1 << 40, 1, 1, 1, X, X, X, 0, S),
+        "mul null out": lambda: L.csgn_mul_uniform(n, 1, 1, 1, X, X, 0, 0, S),
+        "plan null": lambda: L.csgn_mul_ragged_plan(1, X, 0, X, C.byref(plan), S),
+        "mul_ragged null offsets": lambda: L.csgn_mul_ragged(n, 1, X, 0, X, X, X, X, 1, 1, 1, S),
+        "mul_ragged N=0": lambda: L.csgn_mul_ragged(0, 1, X, X, X, X, X, X, 1, 1, 1, S),
+        "add null out": lambda: L.csgn_add_uniform(n, 1, 1, 1, X, X, 0, S),
+        "add null left with terms": lambda: L.csgn_add_uniform(n, 1, 1, 1, 0, X, X, S),
+        "add N=0": lambda: L.csgn_add_uniform(0, 1, 1, 1, X, X, X, S),
+        "add_ragged null offsets": lambda: L.csgn_add_ragged(n, 1, X, 0, X, X, X, X, 2, S),
+        "add_ragged null data": lambda: L.csgn_add_ragged(n, 1, 0, X, X, X, X, X, 2, S),
+        "decrypt null mask": lambda: L.csgn_decrypt_uniform(n, 1, 1, X, 0, B, X, S),
+        "decrypt null scratch": lambda: L.csgn_decrypt_uniform(n, 1, 1, X, X, B, 0, S),
+        "decrypt N=0": lambda: L.csgn_decrypt_uniform(0, 1, 1, X, X, B, X, S),
+        "decrypt_ragged null offsets": lambda: L.csgn_decrypt_ragged(n, 1, 1, X, 0, X, B, X, S),
+        "decrypt_product null bits": lambda: L.csgn_decrypt_product_uniform(n, 1, 1, 1, X, X, X, 0, X, S),
+        "compact null scratch": lambda: L.csgn_compact_ragged(n, 1, 1, X, X, X, X, 0, S),
+        "encrypt_explicit d=0": lambda: L.csgn_encrypt_explicit(n, 0, 1, B, X, X, X, X, X, S),
+        "encrypt_explicit null": lambda: L.csgn_encrypt_explicit(n, 16, 1, B, 0, X, X, X, X, S),
+        "encrypt_keyed null rng": lambda: L.csgn_encrypt_keyed(n, 16, 1, 0, B, X, X, 0, X, S),
+        "encrypt_keyed bad rounds": lambda: L.csgn_encrypt_keyed(n, 16, 1, 0, B, X, X, C.byref(bad_rng), X, S),
+        "encrypt_keyed d=0": lambda: L.csgn_encrypt_keyed(n, 0, 1, 0, B, X, X, C.byref(rng), X, S),
+        "encrypt_keyed null key": lambda: L.csgn_encrypt_keyed(n, 16, 1, 0, B, 0, X, C.byref(rng), X, S),
+        "encrypt_keyed position overflow": lambda: L.csgn_encrypt_keyed(n, 16, 2, (1 << 56) - 1, B, X, X, C.byref(rng), X, S),
+        "encrypt_mul same generator": lambda: L.csgn_encrypt_mul_keyed(n, 16, 1, 0, B, B, X, X, C.byref(rng), C.byref(rng), X, 0, S),
+        "encrypt_mul null plain": lambda: L.csgn_encrypt_mul_keyed(n, 16, 1, 0, B, 0, X, X, C.byref(rng), C.byref(bad_rng), X, 0, S),
+        "permute null perm": lambda: L.csgn_permute_uniform(n, 1, 1, 0, X, 0, X, S),
+        "permute null terms": lambda: L.csgn_permute_uniform(n, 1, 1, 0, 0, X, X, S),
+        "synth N=0": lambda: L.csgn_synth_fill(1, 0, 0, 16, X, S),
+        "synth null": lambda: L.csgn_synth_fill(1, n, 0, 16, 0, S),
+        "digest null": lambda: L.csgn_digest(0, 16, 0, X, S),
+        "key_mask index out of range": lambda: L.csgn_key_mask(n, (C.c_uint64 * 2)(5, n), 2, (C.c_uint64 * 20)()),
+        "key_mask d=0": lambda: L.csgn_key_mask(n, (C.c_uint64 * 2)(5, 6), 0, (C.c_uint64 * 20)()),
+        "rng bad rounds": lambda: L.csgn_rng_from_seed(C.byref(capi.CsgnRng()), 1, 9),
+        "tuning unknown knob": lambda: L.csgn_set_tuning(b"no_such_knob", 1),
+    }
+    for name, call in cases.items():
+        rc = call()
+        assert rc != 0, name
+        assert L.csgn_last_error(), name
+    # circuits: ids that do not exist, building twice, running before building
+    c = C.c_void_p()
+    assert L.csgn_circuit_create(n, 0, C.byref(c)) != 0                     # batch 0
+    capi.check(L.csgn_circuit_create(n, 4, C.byref(c)))
+    try:
+        v, w = C.c_uint32(), C.c_uint32()
+        assert L.csgn_circuit_run(c, S) != 0                                # not built
+        assert L.csgn_circuit_build(c) != 0                                 # no operations
+        assert L.csgn_circuit_input(c, 0, C.byref(v)) != 0                  # zero terms
+        capi.check(L.csgn_circuit_input(c, 1, C.byref(v)))
+        assert L.csgn_circuit_mul(c, v.value, 99, C.byref(w)) != 0          # no such value
+        assert L.csgn_circuit_decrypt(c, 99, X, C.byref(w)) != 0
+        assert L.csgn_circuit_permute(c, v.value, 0, C.byref(w)) != 0       # null permutation
+        capi.check(L.csgn_circuit_mul(c, v.value, v.value, C.byref(w)))
+        capi.check(L.csgn_circuit_build(c))
+        assert L.csgn_circuit_build(c) != 0                                 # already built
+        assert L.csgn_circuit_input(c, 1, C.byref(v)) != 0                  # no inputs after build
+    finally:
+        L.csgn_circuit_destroy(c)
+    torch.cuda.synchronize()                                                # and the device is still alive
+    assert int(torch.arange(10, device=hip.device).sum().item()) == 45
+
+
 # ---------------------------------------------------------------------------------- add
 
 @pytest.mark.parametrize("n,d", CONTEXTS)
