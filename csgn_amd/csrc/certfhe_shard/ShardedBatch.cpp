@@ -505,9 +505,45 @@ ShardedBatch ShardedBatch::operator+(const ShardedBatch &rhs) const
     return ShardedBatch(out);
 }
 
-std::vector<unsigned char> ShardedBatch::decrypt(const SecretKey &key) const
+ShardedBatch ShardedBatch::applyPermutation(const Permutation &permutation) const
 {
     const ShardedData *a = data.get();
+    const uint64_t n = a->ctx.getN();
+    if (permutation.getLength() < n)
+        throw std::invalid_argument("certFHE::ShardedBatch::applyPermutation: permutation shorter than N");
+    std::vector<uint32_t> table(n);
+    const uint64_t *src = permutation.getPermutation();
+    for (uint64_t i = 0; i < n; ++i)
+        table[i] = (uint32_t)src[i];
+    std::shared_ptr<ShardedData> out = std::make_shared<ShardedData>(a->g, a->ctx, a->count, 1);
+    ShardedData *o = out.get();
+    a->g->runAll([&](ShardWorker &me) {
+        o->alloc(me);
+        const uint64_t mine = a->mine(me.rank);
+        if (mine == 0)
+            return;
+        const size_t tb = ((size_t)n * 4 + 255) & ~(size_t)255;
+        void *d_perm = me.take(tb);
+        try {
+            ck(csgn_memcpy_h2d(d_perm, table.data(), (size_t)n * 4, me.stream), "csgn_memcpy_h2d");
+            ck(csgn_permute_uniform(n, mine, a->terms, 0, a->words(me.rank), static_cast<const uint32_t *>(d_perm),
+                                    o->words(me.rank), me.stream),
+               "csgn_permute_uniform");
+        } catch (...) {
+            me.give(d_perm, tb);
+            throw;
+        }
+        me.give(d_perm, tb);              // stream-ordered: the next user of the block queues behind the kernel
+    });
+    return ShardedBatch(out);
+}
+
+std::vector<unsigned char> ShardedBatch::decryptWith(const ShardedBatch *rhs, bool product, const SecretKey &key) const
+{
+    const ShardedData *a = data.get();
+    const ShardedData *b = rhs ? rhs->data.get() : nullptr;
+    if (b)
+        requireSame(*a, *b);
     std::vector<unsigned char> bits(a->count, 0);
     if (a->count == 0)
         return bits;
@@ -515,15 +551,25 @@ std::vector<unsigned char> ShardedBatch::decrypt(const SecretKey &key) const
     a->g->runAll([&](ShardWorker &me) {
         const uint64_t mine = a->mine(me.rank);
         Staging st(me, km, 0);
-        const size_t scratch = (csgn_decrypt_scratch_bytes(mine, mine * a->terms) + 255) & ~(size_t)255;
+        const size_t need = b ? csgn_decrypt_combined_scratch_bytes(mine, a->terms, b->terms)
+                              : csgn_decrypt_scratch_bytes(mine, mine * a->terms);
+        const size_t scratch = (need + 255) & ~(size_t)255;
         const size_t local_b = ((size_t)mine + 255) & ~(size_t)255;
         const size_t total = scratch + local_b + (size_t)a->count;
         void *work = me.take(total);
         uint8_t *d_local = static_cast<uint8_t *>(work) + scratch, *d_all = d_local + local_b;
         try {
-            if (mine)
+            if (mine && !b)
                 ck(csgn_decrypt_uniform(a->ctx.getN(), mine, a->terms, a->words(me.rank), st.mask(), d_local, work, me.stream),
                    "csgn_decrypt_uniform");
+            else if (mine && product)
+                ck(csgn_decrypt_product_uniform(a->ctx.getN(), mine, a->terms, b->terms, a->words(me.rank),
+                                                b->words(me.rank), st.mask(), d_local, work, me.stream),
+                   "csgn_decrypt_product_uniform");
+            else if (mine)
+                ck(csgn_decrypt_sum_uniform(a->ctx.getN(), mine, a->terms, b->terms, a->words(me.rank), b->words(me.rank),
+                                            st.mask(), d_local, work, me.stream),
+                   "csgn_decrypt_sum_uniform");
             // the second exchange of SURVEY 8e: one byte per element
             ck(csgn_comm_gather_bytes(me.comm, d_local, a->count, d_all, me.stream), "csgn_comm_gather_bytes");
             ck(csgn_comm_barrier(me.comm, me.stream), "csgn_comm_barrier");
@@ -538,6 +584,18 @@ std::vector<unsigned char> ShardedBatch::decrypt(const SecretKey &key) const
         me.give(work, total);
     });
     return bits;
+}
+
+std::vector<unsigned char> ShardedBatch::decrypt(const SecretKey &key) const { return decryptWith(nullptr, false, key); }
+
+std::vector<unsigned char> ShardedBatch::decryptProduct(const ShardedBatch &rhs, const SecretKey &key) const
+{
+    return decryptWith(&rhs, true, key);
+}
+
+std::vector<unsigned char> ShardedBatch::decryptSum(const ShardedBatch &rhs, const SecretKey &key) const
+{
+    return decryptWith(&rhs, false, key);
 }
 
 std::vector<uint64_t> ShardedBatch::termCounts() const

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "Context.h"
+#include "Permutation.h"
 #include "SecretKey.h"
 
 namespace certFHE {
@@ -61,6 +62,7 @@ class ShardGroup {
 class ShardedBatch {
     std::shared_ptr<detail::ShardedData> data;
     explicit ShardedBatch(const std::shared_ptr<detail::ShardedData> &d) : data(d) {}
+    std::vector<unsigned char> decryptWith(const ShardedBatch *rhs, bool product, const SecretKey &key) const;
     static const Context &keyContext(const SecretKey &key);
     static ShardedBatch encryptWith(ShardGroup &group, const SecretKey &key, const std::vector<unsigned char> &bits,
                                     const void *rng, uint64_t first_ciphertext);
@@ -90,9 +92,18 @@ class ShardedBatch {
     ShardedBatch operator*(const ShardedBatch &rhs) const;   // element-wise product, shard by shard
     ShardedBatch operator+(const ShardedBatch &rhs) const;   // element-wise sum
 
+    // Ciphertext::applyPermutation on every element, shard by shard (as in the reference and in
+    // CiphertextBatch the result has ONE term: the permuted first term of each element,
+    // src/Ciphertext.cpp:7-89).  No exchange between GPUs.
+    ShardedBatch applyPermutation(const Permutation &permutation) const;
+
     // One plaintext bit per element, in global order: every GPU decrypts its shard, the bytes are
     // all-gathered (csgn_comm_gather_bytes), rank 0's copy is returned.
     std::vector<unsigned char> decrypt(const SecretKey &key) const;
+    // Dec(this[i] * rhs[i]) / Dec(this[i] + rhs[i]) without materialising the results
+    // (csgn_decrypt_product_uniform / csgn_decrypt_sum_uniform on every shard, then the same byte gather).
+    std::vector<unsigned char> decryptProduct(const ShardedBatch &rhs, const SecretKey &key) const;
+    std::vector<unsigned char> decryptSum(const ShardedBatch &rhs, const SecretKey &key) const;
     // Per-element result term counts in global order = the gathered vector of
     // csgn_comm_gather_counts (ncclAllGather of one uint64 per element).  Every rank receives the
     // whole vector; they are compared with one another and rank 0's is returned.

@@ -1,7 +1,7 @@
 // sharded_driver.cpp -- certFHE::ShardedBatch (include/certfhe/ShardedBatch.h) against
 // certFHE::CiphertextBatch (include/certfhe/Batch.h) on whatever GPUs are visible (world 1 on the
 // one-GPU box): the sharded batch must hold exactly the words the one-GPU batch holds, element by
-// element, for encrypt / * / + / decrypt / termCounts, in both forms of the gather; the fused
+// element, for encrypt / * / + / decrypt (plain and fused) / applyPermutation / termCounts, in both forms of the gather; the fused
 // Enc*Enc must equal the unfused chain; and an injected failure must surface as an exception that
 // names the rank, at once, and leave the group dead instead of hanging.
 //
@@ -102,6 +102,18 @@ static int cmd_compare(uint64_t count, uint64_t n_bits, uint64_t d_key)
             fused_ok = sf.values(i) == su.values(i);
         CHECK(fused_ok, "encryptProduct == encrypt * encrypt (words)");
         CHECK(sf.decrypt(key) == su.decrypt(key), "encryptProduct decrypts like the unfused product");
+        // fused decrypt (no product / sum materialised) and the permutation, against the one-GPU batch
+        CHECK(ss.decryptProduct(sp, key) == bs.decryptProduct(bp, key) && ss.decryptProduct(sp, key) == dq,
+              "decryptProduct == Dec of the materialised product");
+        CHECK(sa.decryptSum(sb, key) == ba.decryptSum(bb, key) && sa.decryptSum(sb, key) == ds,
+              "decryptSum == Dec of the materialised sum");
+        Permutation perm(ctx);
+        ShardedBatch spm = sq.applyPermutation(perm);                    // 2 terms in, ONE term out (first term permuted)
+        CiphertextBatch bpm = bq.applyPermutation(perm);
+        CHECK(spm.terms() == 1 && sameElements(spm, bpm, step), "applyPermutation: element i == CiphertextBatch's");
+        SecretKey pkey = key.applyPermutation(perm);
+        CHECK(sa.applyPermutation(perm).decrypt(pkey) == std::vector<unsigned char>(pa.begin(), pa.end()),
+              "a permuted fresh batch decrypts under the permuted key");
     }
     int sum = 0;
     ShardedBatch probe = ShardedBatch::synthetic(group, ctx, count, 3, 9);
