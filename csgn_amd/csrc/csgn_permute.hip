@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) k_permute(u64 n_bits, u32 dL, FastDiv ddL
 // ---------------------------------------------------------------------------------------
 // Permutation, bit-plane form.  One wave owns 64 terms and the permutation is the same for all of
 // them, so it turns the 64 x N bit matrix on its side: a 64x64 bit transpose inside the wave
-// (6 exchange stages: v_permlane32_swap / v_permlane16_swap for the two coarse ones, DPP lane
-// exchange + v_alignbit + v_bfi for the four inside a 16-bit field) leaves "bit j of 64 terms"
+// (6 exchange stages: v_permlane32_swap; ds_swizzle + v_perm for the half-word and DPP + v_perm for the
+// byte stage; lane exchange + v_alignbit + v_bfi for the three inside a byte) leaves "bit j of 64 terms"
 // in one 64-bit word.  Moving bit j to bit j' is then a plain 8-byte LDS move, and a second
 // transpose turns the planes back into terms.
 // ~1.2 lane-operations per bit instead of ~6 for the ballot form above.
@@ -96,6 +96,7 @@ struct TrLane {
     u32 rot[4];     // rotate-right amount that lines the partner's half up with mine
     u32 keep[4];    // bits of my own word that stay
     u32 sel8;       // v_perm_b32 selector of the byte stage
+    u32 sel16;      // ... of the half-word stage when it goes through the LDS crossbar
 };
 
 __device__ inline TrLane tr_lane(u32 lane)
@@ -110,6 +111,7 @@ __device__ inline TrLane tr_lane(u32 lane)
         c.keep[i] = upper ? ~M[i] : M[i];
     }
     c.sel8 = (lane & 8u) ? 0x03070105u : 0x06020400u;
+    c.sel16 = (lane & 16u) ? 0x03020706u : 0x05040100u;
     return c;
 }
 
@@ -140,38 +142,31 @@ __device__ inline void tr_stage_n(u32 (&h)[R], const TrLane &c)
 // and lane groups:
 //   32: lanes 0..31 hand their high words to lanes 32..63 and take those lanes' low words
 //       (v_permlane32_swap);
-//   16: the same between 16-bit halves and 16-lane rows -- gather the low halves of (lo,hi) in
-//       one register and the high halves in another (v_perm_b32), v_permlane16_swap, scatter back.
+//   16: between 16-bit halves and 16-lane rows: the partner's register comes over the LDS crossbar
+//       (ds_swizzle xor 16) and one v_perm_b32 keeps my half and takes the partner's -- 1 VALU + 1 DS
+//       per register where gather / v_permlane16_swap / scatter took 2.5 VALU (round 3: +2-4 % at
+//       N=1247 and 4096, +8 % at N=1300, profiles/r03/ab_permute_swizzle16.log).
 template <int Q>
 __device__ inline void wave_transpose64_n(u32 (&h)[2 * Q], const TrLane &c)
 {
-    u32 a[Q], b[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         auto s32 = __builtin_amdgcn_permlane32_swap(h[2 * q], h[2 * q + 1], false, false);
-        a[q] = s32[0];
-        b[q] = s32[1];
+        h[2 * q] = s32[0];
+        h[2 * q + 1] = s32[1];
     }
     __builtin_amdgcn_sched_barrier(0);
+    {
+        u32 y[2 * Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        h[2 * q] = __builtin_amdgcn_perm(b[q], a[q], 0x05040100u);       // low halves
-        h[2 * q + 1] = __builtin_amdgcn_perm(b[q], a[q], 0x07060302u);   // high halves
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 2 * Q; ++r)
+            y[r] = (u32)__builtin_amdgcn_ds_swizzle((int)h[r], (16 << 10) | 0x1F);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        auto s16 = __builtin_amdgcn_permlane16_swap(h[2 * q], h[2 * q + 1], false, false);
-        a[q] = s16[0];
-        b[q] = s16[1];
+        for (int r = 0; r < 2 * Q; ++r)
+            h[r] = __builtin_amdgcn_perm(y[r], h[r], c.sel16);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        h[2 * q] = __builtin_amdgcn_perm(b[q], a[q], 0x05040100u);
-        h[2 * q + 1] = __builtin_amdgcn_perm(b[q], a[q], 0x07060302u);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     // stage 8 moves whole bytes: one v_perm_b32 picks {own b0, partner b0, own b2, partner b2}
     // (lanes with bit 3 clear) or {partner b1, own b1, partner b3, own b3}
     {
