@@ -537,7 +537,7 @@ hipError_t permute(u64 n_bits, u64 batch, u64 terms_in, bool per_term, const u64
         CSGN_PERMUTE_LAUNCH(16);
     else if (dL <= 20)
         CSGN_PERMUTE_LAUNCH(20);
-    else if (dL <= 32 || dL % 32 == 0 && dL % 64 != 0)
+    else if (dL <= 32 || (dL % 32 == 0 && dL % 64 != 0))
         CSGN_PERMUTE_LAUNCH(32);
     else
         CSGN_PERMUTE_LAUNCH(64);
