@@ -13,11 +13,19 @@ VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_R
           ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
-    fn(); torch.cuda.synchronize(); ts=[]
-    for _ in range(rounds):
+    """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
+    (>= 2 ms) between one pair of events -- the shader clock needs milliseconds to come back after an idle gap."""
+    def bracket(k):
         a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b)/1e3)
-    return statistics.median(ts)
+        a.record()
+        for _ in range(k): fn()
+        b.record(); b.synchronize()
+        return a.elapsed_time(b)/1e3/k
+    est=bracket(1); spent=est
+    while spent<30e-3:
+        k=max(1,min(64,int(5e-3/max(est,1e-6)))); est=bracket(k); spent+=est*k
+    k=max(1,min(64,int(2e-3/max(est,1e-6))+1))
+    return statistics.median([bracket(k) for _ in range(rounds)])
 def csr(c):
     o=np.zeros(len(c)+1,dtype=np.uint64); o[1:]=np.cumsum(np.asarray(c,dtype=np.uint64)); return o
 n=1247; dl=20
