@@ -862,6 +862,11 @@ void csgn_circuit_destroy(csgn_circuit *c)
         (void)hipGraphDestroy(c->graph);
     if (c->block)
         (void)hipFree(c->block);
+    for (auto &op : c->ops) {                 // the encrypt nodes' generator keys: not left in freed host memory
+        volatile uint32_t *a = op.rng.key, *b = op.rng_b.key;
+        for (int i = 0; i < 8; ++i)
+            a[i] = b[i] = 0;
+    }
     delete c;
 }
 
