@@ -151,6 +151,25 @@ def test_integration_md_binding_stub_compiles(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
 
 
+def test_integration_md_sharded_class_snippet_compiles(tmp_path):
+    """INTEGRATION.md section C's C++ example of certFHE::ShardedBatch is real code against the shipped
+    header: wrapped into a function and compiled (syntax and types only)."""
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```cpp\n(.*?)```", text, flags=re.S) if "ShardGroup gpus" in b]
+    assert len(blocks) == 1
+    lines = blocks[0].splitlines()
+    head = [l for l in lines if l.startswith("#include") or l.startswith("using namespace")]
+    body = [l for l in lines if l not in head]
+    src = tmp_path / "sharded_snippet.cpp"
+    src.write_text("\n".join(head) + "\nvoid example(const SecretKey &key, const std::vector<unsigned char> &bits_a,\n"
+                   "             const std::vector<unsigned char> &bits_b, uint64_t seed_a, uint64_t seed_b, const Permutation &perm)\n{\n"
+                   + "\n".join(body) + "\n(void)counts; (void)plain; (void)fast;\n}\nint main() { return 0; }\n")
+    p = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "include", "certfhe"), str(src)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+
+
 def test_tuning_knobs_api(lib, knobs):
     """csgn_set_tuning / csgn_get_tuning / csgn_reset_tuning: per-thread knobs, no environment
     reads after load (VERDICT r1 #9)."""
