@@ -401,13 +401,13 @@ __device__ inline bool unit_covers_chain(unit16 v, unit16 m)
 // N=1247 group, four workgroups per CU) ONE 4-byte entry per unit -- local ciphertext number, byte
 // offset of its key-mask unit, "last unit of a ciphertext" flag -- and the U mask units themselves
 // (5.3 KB): five more VALU instructions per unit, four times the resident waves.
-// plw: the plaintext bytes of the group's Gc ciphertexts, put into LDS by the wave before the call
-// (0 for ciphertexts outside the launch's range).  NOTHING in the unit loop loads from global memory:
+// plw: the plaintext bits of the group's Gc ciphertexts as bytes 0x00 / 0xFF, put into LDS by the wave before
+// the call (0 for ciphertexts outside the launch's range).  NOTHING in the unit loop loads from global memory:
 // a load's s_waitcnt vmcnt() also waits for the non-temporal stores issued before it, i.e. for an HBM
 // write round trip per unit (round 2's form did exactly that and sat at 67 % of the issue rate).
 template <int ROUNDS, int P, bool FULL, bool COMPACT>
 __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, const uint2 *ttab,
-                                     const unsigned short *ctab, u64 *cover, const unsigned char *plw, u32 lane,
+                                     const unsigned short *ctab, u64 *cover, const signed char *plw, u32 lane,
                                      u64 group, u32 nonce_lo, u32 nonce_hi)
 {
     const u32 U = a.U;
@@ -429,6 +429,7 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
         const u64 ctr = blk0 + (u64)p * 64u;
         u32 x[16];
         chacha_block<ROUNDS>(a.rng, nonce_lo, nonce_hi, (u32)ctr, (u32)(ctr >> 32), x);
+        unit16 *const outp = outg + ((u32)p * 256u + lane);   // one address per pass; the four stores differ by an immediate
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 r = (u32)p * 256u + (u32)q * 64u + lane;
@@ -440,30 +441,32 @@ __device__ inline void encrypt_group(const EncWaveArgs &a, const unit16 *mtab, c
                 const u32 e = reinterpret_cast<const u32 *>(ttab)[r];
                 cl = e & 0xFFFFu;
                 m = *reinterpret_cast<const unit16 *>(reinterpret_cast<const unsigned char *>(mtab) + ((e >> 16) & 0x7FFFu));
-                const u32 lastm = (u32)((int)e >> 31);                    // ~0 on a ciphertext's last unit
-                tl.x = a.tail_lo | ~lastm;
-                tl.y = a.tail_hi | ~lastm;
+                const u32 inner = (u32)((int)e >> 31);                    // ~0 unless this is a ciphertext's last unit
+                tl.x = a.tail_lo | inner;
+                tl.y = a.tail_hi | inner;
             } else {
                 m = mtab[r];
                 tl = ttab[r];
                 cl = ctab[r];
             }
             const bool inr = FULL || (cl - cl_lo < cl_hi - cl_lo);
-            const u32 pl = plw[cl];
+            // plaintext 1 -> ~0 (the byte is 0x00 or 0xFF, read sign-extended): OR the key mask in (src/SecretKey.cpp:44-45)
+            const u32 pm = (u32)(int)plw[cl];
             unit16 v;
             v.x = x[4 * q];
             v.y = x[4 * q + 1];
-            v.z = x[4 * q + 2] & tl.x;                      // padding bits of a ciphertext's last word stay 0
-            v.w = x[4 * q + 3] & tl.y;
-            const u64 b = __ballot(unit_covers_chain(v, m)); // all secret positions of this unit came out 1
+            v.z = x[4 * q + 2];
+            v.w = x[4 * q + 3];
+            // all secret positions of this unit came out 1?  Tested on the words BEFORE the tail mask: the key mask
+            // has no bit in the padding, so the padding bits cannot change the verdict
+            const u64 b = __ballot(unit_covers_chain(v, m));
             write_lane64(b, p * 4 + q, acc_lo, acc_hi);
-            const u32 pm = (u32)__builtin_amdgcn_sbfe((int)pl, 0, 1);   // plaintext 1 -> ~0: OR the key mask in (src/SecretKey.cpp:44-45)
             v.x |= m.x & pm;
             v.y |= m.y & pm;
-            v.z |= m.z & pm;
-            v.w |= m.w & pm;
+            v.z = (v.z & tl.x) | (m.z & pm);                // padding bits of a ciphertext's last word stay 0
+            v.w = (v.w & tl.y) | (m.w & pm);
             if (inr)
-                unit_store<unit16, true>(outg + r, v);
+                unit_store<unit16, true>(outp + q * 64, v);
         }
     }
     if (lane < (u32)P * 4u)
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
     uint2 *ttab = reinterpret_cast<uint2 *>(smem_raw + m_bytes);
     const size_t t_bytes = COMPACT ? (size_t)R * 4u : (size_t)R * 8u;
     u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + ((m_bytes + t_bytes + 7u) & ~(size_t)7u));
-    unsigned char *plw = reinterpret_cast<unsigned char *>(cover_all + 4u * P * 4u) + wave * 256u;   // Gc <= 256 bytes per wave
+    signed char *plw = reinterpret_cast<signed char *>(cover_all + 4u * P * 4u) + wave * 256u;   // Gc <= 256 bytes per wave: 0x00 / 0xFF
     unsigned short *ctab = reinterpret_cast<unsigned short *>(cover_all + 4u * P * 4u + 4u * 32u);
     if (COMPACT) {
         for (u32 k = tid; k < U; k += 256u)
@@ -492,7 +495,7 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
         u32 *etab = reinterpret_cast<u32 *>(ttab);
         for (u32 r = tid; r < R; r += 256u) {
             const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
-            etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0x80000000u : 0u);
+            etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0u : 0x80000000u);   // bit 31: NOT the last unit
         }
     } else {
         for (u32 r = tid; r < R; r += 256u) {
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(256) k_encrypt_wave(EncWaveArgs a)
         for (u32 cl = lane; cl < a.Gc; cl += kWave) {
             const u64 c = cbase + cl;
             const bool in = c >= a.first_ct && c < a.first_ct + a.batch;
-            plw[cl] = in ? (unsigned char)(a.plain[c - a.first_ct] & 1u) : (unsigned char)0;
+            plw[cl] = in ? (signed char)(0 - (int)(a.plain[c - a.first_ct] & 1u)) : (signed char)0;
         }
         __builtin_amdgcn_wave_barrier();
         if (full)
@@ -666,7 +669,7 @@ struct EncMulPassCtx {
     const EncMulArgs &a;
     const unit16 *mtab;
     const u32 *etab;
-    const unsigned char *plw_a, *plw_b;
+    const signed char *plw_a, *plw_b;                              // plaintext bits as bytes 0x00 / 0xFF
     unit16 *outg;
     u64 blk0;
     u32 lane, cl_lo, cl_hi, na_lo, na_hi, nb_lo, nb_hi;
@@ -680,21 +683,25 @@ __device__ __forceinline__ void encmul_unit(const EncMulPassCtx &c, const u32 (&
     const u32 e = c.etab[r];
     const u32 cl = e & 0xFFFFu;
     const unit16 m = *reinterpret_cast<const unit16 *>(reinterpret_cast<const unsigned char *>(c.mtab) + ((e >> 16) & 0x7FFFu));
-    const u32 lastm = (u32)((int)e >> 31);                         // ~0 on a ciphertext's last unit
-    const u32 tlx = c.a.tail_lo | ~lastm, tly = c.a.tail_hi | ~lastm;
+    const u32 inner = (u32)((int)e >> 31);                         // ~0 unless this is a ciphertext's last unit
+    const u32 tlx = c.a.tail_lo | inner, tly = c.a.tail_hi | inner;
     unit16 va, vb;
-    va.x = xa[4 * Q]; va.y = xa[4 * Q + 1]; va.z = xa[4 * Q + 2] & tlx; va.w = xa[4 * Q + 3] & tly;
-    vb.x = xb[4 * Q]; vb.y = xb[4 * Q + 1]; vb.z = xb[4 * Q + 2] & tlx; vb.w = xb[4 * Q + 3] & tly;
+    va.x = xa[4 * Q]; va.y = xa[4 * Q + 1]; va.z = xa[4 * Q + 2]; va.w = xa[4 * Q + 3];
+    vb.x = xb[4 * Q]; vb.y = xb[4 * Q + 1]; vb.z = xb[4 * Q + 2]; vb.w = xb[4 * Q + 3];
+    // cover verdicts on the words before the tail mask: the key mask has no bit in the padding
     write_lane64(__ballot(unit_covers_chain(va, m)), PI * 4 + Q, aa_lo, aa_hi);
     write_lane64(__ballot(unit_covers_chain(vb, m)), PI * 4 + Q, ab_lo, ab_hi);
-    const u32 pma = 0u - (u32)c.plw_a[cl], pmb = 0u - (u32)c.plw_b[cl];   // plaintext 1: OR the key mask in (src/SecretKey.cpp:44-45)
+    // plaintext 1 (byte 0xFF, read sign-extended -> ~0): OR the key mask in (src/SecretKey.cpp:44-45)
+    const u32 pma = (u32)(int)c.plw_a[cl], pmb = (u32)(int)c.plw_b[cl];
     unit16 v;                                                      // Ciphertext::defaultN_multiply, src/Ciphertext.cpp:124-131
     v.x = (va.x | (m.x & pma)) & (vb.x | (m.x & pmb));
     v.y = (va.y | (m.y & pma)) & (vb.y | (m.y & pmb));
-    v.z = (va.z | (m.z & pma)) & (vb.z | (m.z & pmb));
-    v.w = (va.w | (m.w & pma)) & (vb.w | (m.w & pmb));
+    // the padding bits of a last word: masked once, on the product (the key mask has none, so masking each
+    // operand first gives the same word)
+    v.z = (va.z | (m.z & pma)) & (vb.z | (m.z & pmb)) & tlx;
+    v.w = (va.w | (m.w & pma)) & (vb.w | (m.w & pmb)) & tly;
     if (cl - c.cl_lo < c.cl_hi - c.cl_lo)
-        unit_store<unit16, true>(c.outg + r, v);
+        unit_store<unit16, true>(c.outg + ((u32)PI * 256u + c.lane) + Q * 64, v);
 }
 
 template <int ROUNDS, int PI>
@@ -722,8 +729,8 @@ __global__ void __launch_bounds__(256) k_encrypt_mul_wave(EncMulArgs a)
     u32 *etab = reinterpret_cast<u32 *>(smem_raw + (size_t)U * 16u);
     u64 *cover_all = reinterpret_cast<u64 *>(smem_raw + (((size_t)U * 16u + (size_t)R * 4u + 7u) & ~(size_t)7u));
     u64 *cover_a = cover_all + wave * (P * 4), *cover_b = cover_all + (4u + wave) * (P * 4);
-    unsigned char *plw_a = reinterpret_cast<unsigned char *>(cover_all + 8u * P * 4u) + wave * 256u;
-    unsigned char *plw_b = plw_a + 4u * 256u;
+    signed char *plw_a = reinterpret_cast<signed char *>(cover_all + 8u * P * 4u) + wave * 256u;
+    signed char *plw_b = plw_a + 4u * 256u;
     u32 *secret_bits = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(cover_all + 8u * P * 4u) + 8u * 256u);
     if (tid == 0)
         *secret_bits = 0;
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(256) k_encrypt_mul_wave(EncMulArgs a)
         atomicAdd(secret_bits, pop);
     for (u32 r = tid; r < R; r += 256u) {
         const u32 cl = csgn_fastdiv(r, a.dU), j = r - cl * U;
-        etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0x80000000u : 0u);
+        etab[r] = cl | ((j * 16u) << 16) | (j == U - 1u ? 0u : 0x80000000u);   // bit 31: NOT the last unit
     }
     __syncthreads();
     // with a single distinct secret position the reference never clears (src/SecretKey.cpp:55-76)
@@ -763,8 +770,8 @@ __global__ void __launch_bounds__(256) k_encrypt_mul_wave(EncMulArgs a)
         for (u32 cl = lane; cl < a.Gc; cl += kWave) {
             const bool in = cl - cl_lo < cl_hi - cl_lo;
             const u64 i = cbase + cl - a.first_ct;
-            plw_a[cl] = in ? (unsigned char)(a.plain_a[i] & 1u) : (unsigned char)0;
-            plw_b[cl] = in ? (unsigned char)(a.plain_b[i] & 1u) : (unsigned char)0;
+            plw_a[cl] = in ? (signed char)(0 - (int)(a.plain_a[i] & 1u)) : (signed char)0;
+            plw_b[cl] = in ? (signed char)(0 - (int)(a.plain_b[i] & 1u)) : (signed char)0;
         }
         __builtin_amdgcn_wave_barrier();
         const long long origin = (long long)cbase - (long long)a.first_ct;
