@@ -638,6 +638,21 @@ __global__ void __launch_bounds__(256) k_touch(const u32 *__restrict__ p, u64 li
     }
 }
 
+// Both operands in ONE launch (the usual case): a mid-shape stream is cut into <= 64 MB of operands per touch +
+// multiply, so a launch saved per cut is several per cent of its time (8x8 at N=1247: 4 touch launches + 2
+// multiplies in 76 us).
+__global__ void __launch_bounds__(256) k_touch2(const u32 *__restrict__ a, u64 lines_a, const u32 *__restrict__ b,
+                                                u64 lines_b, u32 dwords_per_line)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    u32 v = 0;
+    if (i < lines_a)
+        v = a[i * dwords_per_line];
+    else if (i - lines_a < lines_b)
+        v = b[(i - lines_a) * dwords_per_line];
+    asm volatile("" ::"v"(v));
+}
+
 // The same for a slice of a ragged launch: the operands of the pairs that own output terms
 // [term_lo, term_hi) are looked up on the device (the host never sees the offsets) and touched,
 // unless they are too large a share of the slice's traffic (> 1/4 of its output) or more than the
@@ -740,9 +755,12 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
             if (plan.touch) {
                 const u32 lb = 128;       // the L2 fills whole 128-byte lines (a 256-byte stride loses the gain)
                 const u64 ll = (np * t1 * U * sizeof(Unit) + lb - 1) / lb, rl = (np * t2 * U * sizeof(Unit) + lb - 1) / lb;
-                if (plan.touch & 1)
+                if ((plan.touch & 3) == 3)
+                    k_touch2<<<ceil_div_u64(ll + rl, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Lc), ll,
+                                                                         reinterpret_cast<const u32 *>(Rc), rl, lb / 4);
+                else if (plan.touch & 1)
                     k_touch<<<ceil_div_u64(ll, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Lc), ll, lb / 4);
-                if (plan.touch & 2)
+                else if (plan.touch & 2)
                     k_touch<<<ceil_div_u64(rl, 256u), 256, 0, s>>>(reinterpret_cast<const u32 *>(Rc), rl, lb / 4);
             }
 #define CSGN_FLAT(MF)                                                                                  \

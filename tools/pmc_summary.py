@@ -34,7 +34,7 @@ def read_counter(dirname, counter, kernel_subs):
 
 def per_launch(vals, main):
     """Sum over all listed kernels divided by the number of dispatches of the main kernel: helper
-    kernels (k_touch runs twice per multiply launch) are charged to the launch they serve."""
+    kernels (the operand touch in front of every multiply launch) are charged to the launch they serve."""
     n = len(vals.get(main, []))
     return (sum(sum(v) for v in vals.values()) / n, n) if n else (None, 0)
 
