@@ -739,9 +739,15 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
         u64 pairs_per = (0xFFFFFF00ull / PU) ? (0xFFFFFF00ull / PU) : 1;   // units (= threads) per launch < 2^32
         if (plan.touch) {
             // touched operands must still be in the 256 MB memory-side cache when their pair runs:
-            // at most 64 MB of them per touch + launch
+            // at most 64 MB of them per touch + launch (96-200 MB lose 10-25 %, round 3), and 32 MB for
+            // products of 1 Ki to 64 Ki terms when the call has to be cut anyway -- 32x32 and 64x64 gain 5-9 %
+            // at both N with the smaller cut, 8x8 and 16x16 lose 1-8 % (their launches are too short to
+            // halve), 256x256 and up do not care; a call that fits one 64 MB cut is left whole (cutting a
+            // 42 MB call in two cost it 5 %)  (profiles/r03/ab_touch_chunk*_experiment.log)
             const u64 op_bytes = (u64)(t1 + t2) * U * sizeof(Unit);
-            pairs_per = std::min<u64>(pairs_per, std::max<u64>(1, (64ull << 20) / op_bytes));
+            const bool mid = (u64)t1 * t2 >= 1024u && (u64)t1 * t2 < 65536u && pairs * op_bytes > (64ull << 20);
+            const u64 cut = mid ? (32ull << 20) : (64ull << 20);
+            pairs_per = std::min<u64>(pairs_per, std::max<u64>(1, cut / op_bytes));
         }
         const FastDiv dPU = csgn_fastdiv_make((u32)PU), dCU = csgn_fastdiv_make(t2 * U),
                       dU = csgn_fastdiv_make(U);
