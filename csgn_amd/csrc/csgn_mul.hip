@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
 
 constexpr u64 kHugeTerms = 65536;        // a product of this many terms is recorded by the plan (10 MB at N=1247)
 constexpr u64 kHugeRecords = 32;
-constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6;      // [plan4][huge count][records]
+constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 2;  // [plan4][huge count][records][left terms, right terms of the batch]
 
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
 // launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
@@ -450,6 +450,10 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
                                                   u64 *__restrict__ offOut, u64 *__restrict__ huge)
 {
     const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (b == 0) {                                   // operand totals: what sizes the slices of a large product
+        huge[1 + kHugeRecords * 6] = offL[batch] - offL[0];
+        huge[2 + kHugeRecords * 6] = offR[batch] - offR[0];
+    }
     if (b < batch) {
         const u64 o = offOut[b] + partial[b >> 10];
         offOut[b] = o;
@@ -890,6 +894,7 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
 struct RememberedPlan {
     const u64 *offL = nullptr, *offR = nullptr, *offOut = nullptr;
     u64 batch = 0, total = 0, max_t1 = 0, max_t2 = 0;
+    u64 operand_terms = 0;                       // left + right terms of the whole batch
     u32 n = 0;                                   // records kept (sorted by pair)
     u64 rec[kHugeRecords][6];
 };
@@ -905,6 +910,7 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
     r.total = h_head[0];
     r.max_t1 = h_head[1];
     r.max_t2 = h_head[2];
+    r.operand_terms = h_head[5 + kHugeRecords * 6] + h_head[6 + kHugeRecords * 6];
     const u64 count = h_head[4];
     r.n = (u32)std::min<u64>(count, kHugeRecords);
     for (u32 i = 0; i < r.n; ++i)
@@ -962,13 +968,32 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const int chunks = ragged_chunks(total_units);
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
-    // Large outputs go in slices of 1 GiB, each preceded by a touch of the operands its pairs need
+    // The plan this thread made for exactly these offset arrays, if any (the documented sequence
+    // csgn_mul_ragged_plan -> csgn_mul_ragged): it knows the batch's operand size and its huge pairs.
+    const RememberedPlan &rp = t_plan;
+    const bool remembered = use_remembered_plan && rp.offL == offL && rp.offR == offR && rp.offOut == offOut &&
+                            rp.batch == batch && rp.total == total_out_terms && rp.max_t1 == max_t1 &&
+                            rp.max_t2 == max_t2;
+    // Large outputs go in slices, each preceded by a touch of the operands its pairs need
     // (k_touch_ragged): the flat kernel's first touch of a left term is then a cache hit instead of
     // an HBM miss under full write load, as in the uniform path.  Knob ragged_touch = 0 turns it off.
+    // A slice is 1 GiB of output unless the plan says that would bring more than ~80 MB of operands with
+    // it -- about what the memory-side cache keeps under the write stream (the uniform path cuts at 64 MB)
+    // and short of the 96 MB above which k_touch_ragged gives up: then 512 or 256 MiB.  A log-normal batch of
+    // mean 16x16 (344 MB of operands for 2.7 GB of products) ran untouched at 3.6 TB/s in 1 GiB slices
+    // and runs at 4.7 in 512 MiB ones; mean 32x32 and 64x64 keep 1 GiB (5.6-5.8; 5.3 and 4.7 in smaller
+    // slices) -- profiles/r03/ab_ragged_slice_experiment.log.
+    u64 slice_units = 1ull << 26;
+    if (remembered && rp.operand_terms != 0) {
+        const u64 operand_units = rp.operand_terms * U;
+        while (slice_units > (1ull << 24) &&
+               (unsigned __int128)slice_units * operand_units > (unsigned __int128)total_units * ((80ull << 20) / sizeof(unit16)))
+            slice_units >>= 1;
+    }
     auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
         const u64 range_units = range_end - range_begin;
-        const bool touch = wide && range_units > (1ull << 26) && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
-        const u64 per_launch = touch ? (1ull << 26) : kMaxBlocks256 * 256u;   // units
+        const bool touch = wide && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
             const u64 nu = (range_end - u0 < per_launch) ? range_end - u0 : per_launch;
@@ -1015,10 +1040,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // lookup of any kind inside what is usually nearly all of a skewed batch's output -- provided it
     // is worth a launch of its own (24 MB of output: ~3.5 us of HBM time against ~3 launches); the CSR
     // kernel runs on the stretches between them.  Knob ragged_flat = 1 keeps everything in the CSR kernel.
-    const RememberedPlan &rp = t_plan;
-    const bool planned = use_remembered_plan && csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0 && rp.offL == offL && rp.offR == offR &&
-                         rp.offOut == offOut && rp.batch == batch && rp.total == total_out_terms &&
-                         rp.max_t1 == max_t1 && rp.max_t2 == max_t2;
+    const bool planned = remembered && csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0;
     u64 cursor = 0;
     // ... and only when those pairs are most of the batch: every split costs launches (a uniform one and the
     // CSR kernel's on either side, each with its own ramp and tail), which a few 30 MB pairs inside a 2.8 GB

@@ -1966,6 +1966,43 @@ def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
         assert np.array_equal(got, want), b
 
 
+def test_ragged_mul_slices_shrink_when_operands_are_heavy(hip, oracle, knobs):
+    """A ragged product above 1 GiB whose operands are a large share of it (27 000 pairs of 10..22 x 10..22 terms:
+    ~138 MB of operands for 1.1 GB of products): the plan's operand totals make csgn_mul_ragged cut the output in
+    512 MiB slices (so that every slice's operands can be touched) instead of 1 GiB ones.  Same words as the
+    unsliced run (touch off), sampled pairs equal the oracle, including pairs at the 512 MiB slice boundaries."""
+    import torch
+    n, dl = 1247, 20
+    rng = np.random.default_rng(18)
+    batch = 27000
+    t1s, t2s = rng.integers(10, 23, size=batch), rng.integers(10, 23, size=batch)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    total = int(np.sum(t1s * t2s))
+    assert total * 10 > (1 << 26)                               # more than 1 GiB of 16-byte units
+    assert int(offL[-1] + offR[-1]) * 10 * (1 << 26) > total * 10 * ((80 << 20) // 16)   # > 80 MB of operands per GiB
+    L = hip.synth_fill(53, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(54, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    knobs.set("CSGN_RAGGED_TOUCH", "0")                         # one launch, no slices
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+    ref = ref.clone()
+    knobs.set("CSGN_RAGGED_TOUCH", "1")
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)                # planned on this thread: slices follow the operand share
+    assert torch.equal(out, ref) and torch.equal(off, ref_off)
+    mo = hip.download(off)
+    assert np.array_equal(mo, csr((t1s * t2s).tolist()))
+    hl, hr = hip.download(L), hip.download(R)
+    picks = {0, batch - 1}
+    for cut_unit in (1 << 25, 1 << 26, 3 << 25):                # first terms of the 512 MiB slices
+        if cut_unit // 10 >= total:
+            continue
+        b = min(batch - 1, int(np.searchsorted(mo, cut_unit // 10, side="right")) - 1)
+        picks |= {max(0, b - 1), b, min(batch - 1, b + 1)}
+    for b in sorted(picks):
+        want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+        assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
 def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
     """csgn_mul_ragged right after csgn_mul_ragged_plan: pairs of 24 MB of output and more (written down by
     the plan) get uniform launches of their own, the CSR kernel runs on the stretches between them.  Two
