@@ -1197,7 +1197,7 @@ int csgn_circuit_build(csgn_circuit *c)
             u64 *oo = reinterpret_cast<u64 *>(base + vo.csr_offset);
             if (op.kind)
                 e = vo.total ? csgn::mul_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, va.max_terms,
-                                                vb.max_terms, vo.total, s)
+                                                vb.max_terms, vo.total, s, false, va.total + vb.total)
                              : hipSuccess;
             else
                 e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s);

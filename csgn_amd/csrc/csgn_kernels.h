@@ -32,10 +32,12 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);
 // use_remembered_plan: consult what the calling thread's last mul_ragged_plan wrote down about huge
-// pairs (only the C entry point does: a circuit's offsets never came from that plan)
+// pairs and operand size (only the C entry point does: a circuit's offsets never came from that plan).
+// operand_terms: left + right terms of the whole batch when the caller knows them (a circuit does: its
+// shapes are static), 0 = unknown; sizes the output slices of a large product.
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan = false);
+                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan = false, u64 operand_terms = 0);
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        hipStream_t s);
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,

@@ -925,7 +925,7 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
 
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan)
+                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan, u64 operand_terms)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
@@ -984,8 +984,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // and runs at 4.7 in 512 MiB ones; mean 32x32 and 64x64 keep 1 GiB (5.6-5.8; 5.3 and 4.7 in smaller
     // slices) -- profiles/r03/ab_ragged_slice_experiment.log.
     u64 slice_units = 1ull << 26;
-    if (remembered && rp.operand_terms != 0) {
-        const u64 operand_units = rp.operand_terms * U;
+    if (remembered && rp.operand_terms != 0)
+        operand_terms = rp.operand_terms;
+    if (operand_terms != 0) {
+        const u64 operand_units = operand_terms * U;
         while (slice_units > (1ull << 24) &&
                (unsigned __int128)slice_units * operand_units > (unsigned __int128)total_units * ((80ull << 20) / sizeof(unit16)))
             slice_units >>= 1;
