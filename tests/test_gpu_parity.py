@@ -103,6 +103,43 @@ def test_mul_flat_variants_do_not_change_results(hip, oracle, knobs, flat, xcd):
             assert np.array_equal(out[b * per:(b + 1) * per], want)
 
 
+@pytest.mark.parametrize("n,t1,t2,batch,kernel", [
+    (1247, 16, 16, 20000, "k_touch+k_mul_flat"),   # rows of 160 units: two units per lane behind the touch; 102 MB of operands: two cuts
+    (1247, 32, 32, 9000, "k_touch+k_mul_flat"),    # 92 MB of operands, 1 Ki-term products: 32 MB cuts (three launches)
+    (1247, 16, 4, 40000, "k_mul_flat"),            # tall and thin: two units per lane, no touch
+    (1247, 4, 16, 40000, "k_mul_tiled"),           # rows of 160 units: the tiled kernel from 128 units on
+    (4096, 4, 4, 30000, "k_mul_tiled"),            # 128-unit rows exactly
+    (4096, 64, 2, 6000, "k_mul_flat"),             # 64-unit rows stay with the flat kernel, tall: two units per lane
+    (1247, 8, 8, 40000, "k_touch+k_mul_flat"),     # the boundary of the touch rule, two cuts
+])
+def test_mul_default_dispatch_of_streaming_small_shapes(hip, oracle, knobs, n, t1, t2, batch, kernel):
+    """The dispatch rules round 3 re-tuned (mul_plan: units per lane by row length, tiled kernel from 128-unit rows,
+    touch cuts of 32 / 64 MB) on batches large enough to be STREAMS (>= 4 MB of operands, several cuts): the default
+    dispatch gives the words the other kernel gives, and sampled pairs -- first, last, and the pairs either side of
+    every cut -- equal the oracle."""
+    import torch
+    dl = oracle.default_len(n)
+    assert hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode() == kernel
+    L = hip.synth_fill(81, n, 0, batch * t1 * dl)
+    R = hip.synth_fill(82, n, 0, batch * t2 * dl)
+    out = hip.mul_uniform(n, batch, t1, t2, L, R).clone()
+    knobs.set("mul_flat", 1 if kernel == "k_mul_tiled" else -1)          # the other kernel family, no touch
+    knobs.set("mul_touch", 0)
+    other = hip.mul_uniform(n, batch, t1, t2, L, R)
+    assert torch.equal(out, other)
+    op_bytes = (t1 + t2) * dl * 8
+    picks = {0, 1, batch // 2, batch - 2, batch - 1}
+    for cut_mb in (32, 64):
+        step = (cut_mb << 20) // op_bytes
+        for k in range(1, 4):
+            picks |= {min(batch - 1, max(0, k * step + dpair)) for dpair in (-1, 0, 1)}
+    hl, hr = hip.download(L), hip.download(R)
+    per = t1 * t2 * dl
+    for b in sorted(picks):
+        want, _ = oracle.mul(n, hl[b * t1 * dl:(b + 1) * t1 * dl], hr[b * t2 * dl:(b + 1) * t2 * dl])
+        assert np.array_equal(hip.download(out[b * per:(b + 1) * per]), want), (n, t1, t2, b)
+
+
 @pytest.mark.parametrize("n,d", CONTEXTS)
 @pytest.mark.parametrize("t1,t2", [(1, 2), (3, 5), (33, 65), (5, 300), (129, 130)])
 def test_mul_tiled_kernel_matches_oracle(hip, oracle, knobs, n, d, t1, t2):
