@@ -140,8 +140,10 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
  * documented sequence -- it also knows from the plan the batch's HUGE pairs (24 MB of output and more,
  * up to 32 of them), each of which gets a uniform launch of its own, and the batch's operand size,
  * which sets the size of the slices a product above 1 GiB is written in (each slice's operands are
- * read once ahead of it); the offsets must therefore not change between the two calls.  Without a
- * matching plan the same words come out of the general kernel in 1 GiB slices. */
+ * read once ahead of it); the offsets must therefore not change between the two calls, and a thread
+ * that writes NEW offsets into the same three arrays has to plan again before it multiplies (the match is
+ * by array addresses, batch and the plan's four numbers).  Without a matching plan the same words come
+ * out of the general kernel in 1 GiB slices. */
 int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
