@@ -497,8 +497,10 @@ hipError_t launch_tiled_m(const MulArgs &a, u32 bs, bool samek, bool nt, u32 blo
 }
 
 // Launch the tiled kernel for `pairs` pairs whose shapes are bounded by (t1, t2).
+// bs_hint / ti_hint: block size and left terms per tile chosen by mul_plan for short rows (0 = the defaults
+// below); the knobs mul_bs (non-zero) and mul_ti (other than its default 4) still override.
 template <typename Unit, bool RAGGED>
-hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
+hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s, u32 bs_hint = 0, u32 ti_hint = 0)
 {
     const MulTuning tune = mul_tuning();
     // With M > 1 a block size that U divides lets every column of a lane share one LDS read
@@ -507,7 +509,7 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
     // auto: 256 threads x 4 KiB row segments -- one 16-byte unit per lane, or two 8-byte units
     // when dL is odd (measured at N=1300: 5.3 -> 6.4 TB/s, the 2 KiB segments of M=1 lose)
     const int m_req = tune.m ? tune.m : (sizeof(Unit) == 8 ? 2 : 1);
-    u32 bs = tune.bs ? (u32)tune.bs : (tune.m > 1 ? samek_block(U) : 256u);
+    u32 bs = tune.bs ? (u32)tune.bs : (tune.m > 1 ? samek_block(U) : (bs_hint ? bs_hint : 256u));
     if (bs == 0)
         bs = 256;
     const bool samek = bs % U == 0;
@@ -517,7 +519,7 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
     while (m > 1 && (u64)bs * (m / 2) >= cu)
         m /= 2;
     // left tile: TI terms, capped so the LDS image stays <= 32 KB
-    u32 ti = (u32)tune.ti;
+    u32 ti = (ti_hint && tune.ti == 4) ? ti_hint : (u32)tune.ti;
     const u32 cap = (u32)(32768u / (U * sizeof(Unit)));
     if (ti > cap)
         ti = cap ? cap : 1;
@@ -583,13 +585,14 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s)
 struct MulPlan {
     int flat;       // 0 = LDS-tiled kernel, k > 0 = flat kernel with k units per lane
     int touch;      // operands to pull into the memory-side cache first (bit 0 left, bit 1 right)
+    u32 bs, ti;     // tiled kernel: threads per workgroup and left terms per tile, 0 = the launcher's defaults
 };
 
 static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
 {
     const MulTuning tune = mul_tuning();
     const u64 PU = t1 * t2 * U;
-    MulPlan p = {0, 0};
+    MulPlan p = {0, 0, 0, 0};
     if (PU >= (1ull << 31) || tune.flat == -1)
         return p;
     const int touch_env = csgn::tune(TUNE_MUL_TOUCH);
@@ -608,6 +611,24 @@ static MulPlan mul_plan(size_t unit_bytes, u32 U, u64 t1, u64 t2, u64 pairs)
     // cotenant_ab.json) evicts them and the pair falls to 3.5 TB/s, where the LDS-tiled kernel, which
     // fetches each left term once per 4 rows x 4 KiB whatever the cache holds, keeps 4.8.
     const bool shared = csgn::tune(TUNE_SHARED_GPU) != 0;
+    // Short rows and small pairs (round 3, operands fresh from the previous kernel, profiles/r03/ab_short_rows*.log):
+    // the tiled kernel with a workgroup no wider than the row (64 or 128 threads) and 8 left terms per tile
+    // turns a whole small pair, or 8 rows of a thin one, into ONE workgroup -- operands staged once, coalesced,
+    // no per-row miss.  8x8 at N=1247 4.8-5.0 -> 5.9 TB/s; 4x4 5.5 -> 6.1; 8x4 / 16x4 / 64x4 5.3 / 5.1 / 4.8 ->
+    // 6.0 / 5.9 / 5.9; N=4096 16x4 / 64x4 5.5 -> 6.2.  Taller or wider products (16x8 and up,
+    // 10x10, 12x12) stay with the flat kernel, which leads there.
+    const u64 row_units = t2 * U;
+    const bool touch_regime = unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && ((streaming && !shared) || touch_env > 0);
+    if (unit_bytes == 16 && touch_env <= 0 && row_units <= 128u &&
+        ((touch_regime && t1 <= 8u) ||                                   // a whole small pair per workgroup
+         (!touch_regime && t1 >= 4u && t2 >= 4u && row_units >= 32u && row_units < 128u) ||   // thin and small products
+                                                                         // (two-term rows stay flat: config 5's tall x 2
+                                                                         // products at N=4096 ran 2-20 % slower tiled)
+         (!touch_regime && t1 >= 8u && row_units == 128u))) {            // 128-unit rows: half the default block
+        p.bs = row_units <= 64u ? 64u : 128u;
+        p.ti = 8u;
+        return p;
+    }
     if (unit_bytes == 16 && t1 * t2 >= 4 * (t1 + t2) && ((streaming && !shared) || touch_env > 0)) {
         // rows shorter than a workgroup's 256 units: a wave crosses row boundaries, every crossing is a new
         // left term, and two units per lane keep twice the loads in flight -- N=1247 16x16 4.7 -> 5.4 TB/s,
@@ -799,7 +820,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
     a.out = out;
     a.t1 = t1;
     a.t2 = t2;
-    return launch_tiled<Unit, false>(a, pairs, U, s);
+    return launch_tiled<Unit, false>(a, pairs, U, s, plan.bs, plan.ti);
 }
 
 } // namespace

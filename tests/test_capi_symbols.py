@@ -80,10 +80,13 @@ def test_mul_dispatch_names(lib, knobs):
     assert name(1247, 1024, 1024, 128) == "k_touch+k_mul_flat"     # the bench launch: 128 pairs, 42 MB of operands
     assert name(1247, 1024, 1024, 1) == "k_mul_tiled"              # a single product is not a stream
     assert name(4096, 256, 256) == "k_touch+k_mul_flat"
-    assert name(1247, 8, 8) == "k_touch+k_mul_flat"                # output = 4x operands
+    assert name(1247, 16, 8) == "k_touch+k_mul_flat"               # output >= 4x operands: touch + flat
+    assert name(1247, 8, 8) == "k_mul_tiled"                       # a whole small pair per 128-thread workgroup
     assert name(1247, 64, 64, 1) == "k_mul_tiled"
-    assert name(1247, 4, 4) == "k_mul_flat"                        # operands too large a share to read twice
-    assert name(1247, 1024, 1) == "k_mul_flat"                     # rows shorter than a workgroup
+    assert name(1247, 4, 4) == "k_mul_tiled"                       # thin and small: 64-thread workgroups, 8 rows per tile
+    assert name(1247, 2, 2) == "k_mul_flat"                        # two rows: the flat kernel
+    assert name(1247, 1024, 1) == "k_mul_flat"                     # rows of 10 units: the flat kernel
+    assert name(4096, 64, 4) == "k_mul_tiled" and name(4096, 2, 2) == "k_mul_flat"
     assert name(1247, 2, 383) == "k_mul_tiled"                     # thin product, long rows
     assert name(1300, 128, 128) == "k_mul_tiled"                   # odd dL: 8-byte units
     assert name(1300, 200, 2) == "k_mul_flat"

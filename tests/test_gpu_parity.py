@@ -106,11 +106,15 @@ def test_mul_flat_variants_do_not_change_results(hip, oracle, knobs, flat, xcd):
 @pytest.mark.parametrize("n,t1,t2,batch,kernel", [
     (1247, 16, 16, 20000, "k_touch+k_mul_flat"),   # rows of 160 units: two units per lane behind the touch; 102 MB of operands: two cuts
     (1247, 32, 32, 9000, "k_touch+k_mul_flat"),    # 92 MB of operands, 1 Ki-term products: 32 MB cuts (three launches)
-    (1247, 16, 4, 40000, "k_mul_flat"),            # tall and thin: two units per lane, no touch
-    (1247, 4, 16, 40000, "k_mul_tiled"),           # rows of 160 units: the tiled kernel from 128 units on
-    (4096, 4, 4, 30000, "k_mul_tiled"),            # 128-unit rows exactly
-    (4096, 64, 2, 6000, "k_mul_flat"),             # 64-unit rows stay with the flat kernel, tall: two units per lane
-    (1247, 8, 8, 40000, "k_touch+k_mul_flat"),     # the boundary of the touch rule, two cuts
+    (1247, 16, 4, 40000, "k_mul_tiled"),           # thin, rows of 40 units: 64-thread workgroups, 8 rows per tile
+    (1247, 4, 16, 40000, "k_mul_tiled"),           # rows of 160 units: the tiled kernel's default block
+    (4096, 4, 4, 30000, "k_mul_tiled"),            # 128-unit rows, 4 rows: default block
+    (4096, 64, 4, 6000, "k_mul_tiled"),            # 128-unit rows, tall: 128-thread workgroups, 8 rows per tile
+    (4096, 64, 2, 6000, "k_mul_flat"),             # two-term rows stay with the flat kernel (two units per lane)
+    (1247, 8, 8, 40000, "k_mul_tiled"),            # a whole small pair per 128-thread workgroup
+    (1247, 4, 4, 100000, "k_mul_tiled"),           # 40-unit rows, 4 rows per pair
+    (1247, 64, 2, 20000, "k_mul_flat"),            # rows of 20 units stay with the flat kernel (tall: two units per lane)
+    (1247, 16, 8, 20000, "k_touch+k_mul_flat"),    # taller than 8 rows: touch + flat, two units per lane
 ])
 def test_mul_default_dispatch_of_streaming_small_shapes(hip, oracle, knobs, n, t1, t2, batch, kernel):
     """The dispatch rules round 3 re-tuned (mul_plan: units per lane by row length, tiled kernel from 128-unit rows,
@@ -177,20 +181,20 @@ def test_mul_flat_kernel_with_touch_matches_oracle(hip, oracle, knobs, n, d, tou
 
 def test_mul_touch_chunking_across_64mb_of_operands(hip, oracle):
     """Default dispatch on a batch whose operands exceed one touch chunk (64 MB): 30 000 pairs of
-    8x8 terms at N=1247 are cut after pair 26 214; pairs on both sides of the cut, the ends and a
+    16x8 terms at N=1247 are cut after pair 17 476; pairs on both sides of the cut, the ends and a
     random sample are compared with the oracle."""
-    n, dl, t, batch = 1247, 20, 8, 30000
-    assert hip.lib.csgn_mul_uniform_kernel(n, batch, t, t).decode() == "k_touch+k_mul_flat"
-    L = hip.synth_fill(11, n, 0, batch * t * dl)
-    R = hip.synth_fill(12, n, 0, batch * t * dl)
-    out = hip.mul_uniform(n, batch, t, t, L, R)
+    n, dl, t1, t2, batch = 1247, 20, 16, 8, 30000
+    assert hip.lib.csgn_mul_uniform_kernel(n, batch, t1, t2).decode() == "k_touch+k_mul_flat"
+    L = hip.synth_fill(11, n, 0, batch * t1 * dl)
+    R = hip.synth_fill(12, n, 0, batch * t2 * dl)
+    out = hip.mul_uniform(n, batch, t1, t2, L, R)
     hl, hr, ho = hip.download(L), hip.download(R), hip.download(out)
-    per = t * t * dl
-    cut = (64 << 20) // (2 * t * dl * 8)
+    per = t1 * t2 * dl
+    cut = (64 << 20) // ((t1 + t2) * dl * 8)
     picks = {0, 1, batch - 1, cut - 1, cut, cut + 1, 2 * cut - 1} | set(
         np.random.default_rng(5).integers(0, batch, 200).tolist())
     for b in sorted(p for p in picks if 0 <= p < batch):
-        want, _ = oracle.mul(n, hl[b * t * dl:(b + 1) * t * dl], hr[b * t * dl:(b + 1) * t * dl])
+        want, _ = oracle.mul(n, hl[b * t1 * dl:(b + 1) * t1 * dl], hr[b * t2 * dl:(b + 1) * t2 * dl])
         assert np.array_equal(ho[b * per:(b + 1) * per], want), b
 
 

@@ -25,7 +25,15 @@ if "mid" in sys.argv[1:]:
     VARIANTS = [("(warm-up)", {}), ("default", {}), ("flat2+touch", {"mul_flat": 2, "mul_touch": 3}), ("default", {}),
                 ("flat2+touch", {"mul_flat": 2, "mul_touch": 3}), ("flat2", {"mul_flat": 2, "mul_touch": 0}), ("tiled", {"mul_flat": -1}),
                 ("default", {}), ("flat2+touch", {"mul_flat": 2, "mul_touch": 3})]
-shapes = THIN if "thin" in sys.argv[1:] else TALL if "tall" in sys.argv[1:] else MID if "mid" in sys.argv[1:] else SQUARE
+if "bs" in sys.argv[1:]:
+    VARIANTS = [("(warm-up)", {}), ("default", {}), ("tiled bs=256", {"mul_flat": -1}), ("tiled bs=128", {"mul_flat": -1, "mul_bs": 128}),
+                ("tiled bs=64", {"mul_flat": -1, "mul_bs": 64}), ("tiled bs=128 ti=8", {"mul_flat": -1, "mul_bs": 128, "mul_ti": 8}), ("default", {})]
+SHORT = [(4, 4, 131072), (8, 4, 65536), (16, 4, 32768), (64, 4, 8192), (8, 8, 32768), (16, 8, 16384), (32, 8, 8192), (64, 8, 4096),
+         (256, 8, 1024), (10, 10, 16384), (12, 12, 16384), (64, 2, 16384), (1024, 2, 1024)]
+if "short" in sys.argv[1:]:
+    VARIANTS = [("(warm-up)", {}), ("default", {})] + [("bs%d ti%d" % (b, t), {"mul_flat": -1, "mul_bs": b, "mul_ti": t})
+                                                        for b, t in ((128, 8), (128, 16), (128, 4), (64, 8), (64, 16))] + [("default", {})]
+shapes = SHORT if "short" in sys.argv[1:] else MID if "bs" in sys.argv[1:] else THIN if "thin" in sys.argv[1:] else TALL if "tall" in sys.argv[1:] else MID if "mid" in sys.argv[1:] else SQUARE
 for n in (1247, 4096):
     dl = hip.default_len(n)
     for t1, t2, batch in shapes:
