@@ -580,6 +580,8 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s, u32 bs_hint 
 // (tools/ab_fresh_operands.py): such lines are not in the memory-side cache, so a multiply chain is
 // the cold case and the touch stays; the thresholds below come from those runs.
 //   * everything else (thin products with long rows, 8-byte units): the LDS-tiled kernel.
+//   * and, ahead of all of these, small pairs and thin products with rows of <= 128 units (16-byte units):
+//     the LDS-tiled kernel with a 64- or 128-thread workgroup and 8 left terms per tile (see mul_plan).
 // CSGN_MUL_FLAT (-1 tiled, k > 0 flat with k units per lane) and CSGN_MUL_TOUCH (0..3: bit 0 left,
 // bit 1 right operand) override for sweeps.
 struct MulPlan {
