@@ -2044,6 +2044,36 @@ def test_ragged_mul_slices_shrink_when_operands_are_heavy(hip, oracle, knobs):
         assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
 
 
+@pytest.mark.parametrize("n,lo,hi,batch", [(1247, 0, 6, 300000), (1247, 4, 13, 60000), (4096, 1, 9, 40000), (128, 0, 6, 200000)])
+def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
+    """Batches of SMALL pairs (0..5, 4..12, 1..8 terms; also N=128 with its one-unit terms): every turn of the CSR
+    kernel spans dozens of pairs and takes the offset-window path.  Same words for every chunk / turn setting,
+    sampled pairs equal the oracle (incl. empty pairs, the first and the last pair)."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n + hi)
+    t1s, t2s = rng.integers(lo, hi, size=batch), rng.integers(lo, hi, size=batch)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    L = hip.synth_fill(91, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(92, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+    out = out.clone()
+    for m, c in ((1, 8), (2, 2), (4, 16), (1, 1)):
+        knobs.set("ragged_m", m)
+        knobs.set("ragged_c", c)
+        other, other_off = hip.mul_ragged(n, L, dOL, R, dOR)
+        assert torch.equal(out, other) and torch.equal(off, other_off), (m, c)
+    mo = hip.download(off)
+    assert np.array_equal(mo, csr((t1s * t2s).tolist()))
+    hl, hr = hip.download(L), hip.download(R)
+    picks = {0, 1, batch // 3, batch // 2, batch - 2, batch - 1} | set(rng.integers(0, batch, 60).tolist())
+    for b in sorted(picks):
+        if t1s[b] and t2s[b]:
+            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+            assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
 def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
     """csgn_mul_ragged right after csgn_mul_ragged_plan: pairs of 24 MB of output and more (written down by
     the plan) get uniform launches of their own, the CSR kernel runs on the stretches between them.  Two
