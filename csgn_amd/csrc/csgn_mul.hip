@@ -1002,22 +1002,31 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // an HBM miss under full write load, as in the uniform path.  Knob ragged_touch = 0 turns it off.
     // A slice is 1 GiB of output unless the plan says that would bring more than ~80 MB of operands with
     // it -- about what the memory-side cache keeps under the write stream (the uniform path cuts at 64 MB)
-    // and short of the 96 MB above which k_touch_ragged gives up: then 512 or 256 MiB.  A log-normal batch of
+    // and short of the 96 MB above which k_touch_ragged gives up: then 512 MiB.  A log-normal batch of
     // mean 16x16 (344 MB of operands for 2.7 GB of products) ran untouched at 3.6 TB/s in 1 GiB slices
     // and runs at 4.7 in 512 MiB ones; mean 32x32 and 64x64 keep 1 GiB (5.6-5.8; 5.3 and 4.7 in smaller
     // slices) -- profiles/r03/ab_ragged_slice_experiment.log.
+    // Where even a 512 MiB slice would come with more than that -- batches of small pairs, whose operands are a
+    // quarter of their products and more -- nothing is sliced or touched: a dozen 256 MiB slices, each a touch and
+    // a launch of its own, ran 7-16 % SLOWER than one untouched launch (pairs of 0-5, 4-12 and mean-8 log-normal
+    // terms: 3.7 / 3.0 / 2.9 TB/s sliced, 4.3 / 3.2 / 3.4 whole).
     u64 slice_units = 1ull << 26;
+    bool slice_touch = true;
     if (remembered && rp.operand_terms != 0)
         operand_terms = rp.operand_terms;
     if (operand_terms != 0) {
         const u64 operand_units = operand_terms * U;
-        while (slice_units > (1ull << 24) &&
-               (unsigned __int128)slice_units * operand_units > (unsigned __int128)total_units * ((80ull << 20) / sizeof(unit16)))
+        auto too_much = [&](u64 su) {
+            return (unsigned __int128)su * operand_units > (unsigned __int128)total_units * ((80ull << 20) / sizeof(unit16));
+        };
+        if (too_much(slice_units))
             slice_units >>= 1;
+        if (too_much(slice_units))
+            slice_touch = false;
     }
     auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
         const u64 range_units = range_end - range_begin;
-        const bool touch = wide && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
