@@ -988,7 +988,14 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // C=4 4.47, C=8 4.28 -- small outputs want many short workgroups, which the rule gives them.  A per-workgroup
     // start table from a pre-kernel (instead of each workgroup's 64-ary search) was tried and measured 0-8 % SLOWER
     // on all four batches, so it is not here.
-    const int chunks = ragged_chunks(total_units);
+    // Batches of small pairs (mean product under 512 terms) take 16: nearly every turn of theirs pays the offset
+    // window, the start-up search is the one phase a longer workgroup saves, and +3-5 % on four such batches says so
+    // (pairs of 0-5, 4-12, mean-8 and mean-16 log-normal terms: 3.66 / 3.03 / 2.94 / 4.73 -> 3.87 / 3.19 / 3.05 / 4.92);
+    // at mean 32x32 it costs 5-10 %.
+    int chunks = ragged_chunks(total_units);
+    if (chunks == 8 && csgn::tune(TUNE_RAGGED_C) == 0 && total_out_terms / batch < 512u &&
+        total_units / (256u * 16u) >= 8192u)
+        chunks = 16;
     const u32 pf_pairs = (u32)std::max(0, csgn::tune(TUNE_RAGGED_PF));    // operand prefetch distance in pairs, 0 = off
     const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
     // The plan this thread made for exactly these offset arrays, if any (the documented sequence
