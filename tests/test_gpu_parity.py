@@ -2046,9 +2046,10 @@ def test_ragged_mul_slices_shrink_when_operands_are_heavy(hip, oracle, knobs):
 
 @pytest.mark.parametrize("n,lo,hi,batch", [(1247, 0, 6, 300000), (1247, 4, 13, 60000), (4096, 1, 9, 40000), (128, 0, 6, 200000)])
 def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
-    """Batches of SMALL pairs (0..5, 4..12, 1..8 terms; also N=128 with its one-unit terms): every turn of the CSR
-    kernel spans dozens of pairs and takes the offset-window path.  Same words for every chunk / turn setting,
-    sampled pairs equal the oracle (incl. empty pairs, the first and the last pair)."""
+    """Batches of SMALL pairs (0..5, 4..12, 1..8 terms; also N=128 with its one-unit terms): by default the tiled kernel
+    with one narrow workgroup per pair (no lookup); with knob ragged_flat = 1 the CSR kernel, whose every turn spans
+    dozens of pairs there and takes the offset-window path.  Same words either way and for every chunk / turn
+    setting, sampled pairs equal the oracle (incl. empty pairs, the first and the last pair)."""
     import torch
     dl = oracle.default_len(n)
     rng = np.random.default_rng(n + hi)
@@ -2057,9 +2058,10 @@ def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
     L = hip.synth_fill(91, n, 0, int(offL[-1]) * dl)
     R = hip.synth_fill(92, n, 0, int(offR[-1]) * dl)
     dOL, dOR = hip.upload(offL), hip.upload(offR)
-    out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)                 # default: one narrow workgroup per pair (tiled kernel)
     out = out.clone()
-    for m, c in ((1, 8), (2, 2), (4, 16), (1, 1)):
+    knobs.set("ragged_flat", 1)                                 # the CSR kernel, every chunk / turn setting
+    for m, c in ((4, 0), (1, 8), (2, 2), (4, 16), (1, 1)):
         knobs.set("ragged_m", m)
         knobs.set("ragged_c", c)
         other, other_off = hip.mul_ragged(n, L, dOL, R, dOR)
