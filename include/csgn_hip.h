@@ -133,7 +133,8 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
                          uint64_t *d_off_out, uint64_t h_plan[4], void *stream);
 /* Step 2: the products, into d_out[h_plan[0]*dL] at the planned offsets; pass the plan's
  * max_t1 = h_plan[1], max_t2 = h_plan[2], total_out_terms = h_plan[0].  Nearly uniform batches
- * of large products run the LDS-tiled kernel; a batch whose pairs ALL have the largest shape runs
+ * of large products run the LDS-tiled kernel, and so do batches of small pairs whose largest shape is
+ * small too (one narrow workgroup per pair); a batch whose pairs ALL have the largest shape runs
  * the uniform kernels; skewed or small ones a flat kernel whose grid is the real output (a workgroup
  * finds its first pair by a 64-ary search over d_off_out and stages the offsets it needs in LDS).
  * Called right after csgn_mul_ragged_plan on the same host thread with the same offset arrays -- the
