@@ -2044,6 +2044,38 @@ def test_ragged_mul_slices_shrink_when_operands_are_heavy(hip, oracle, knobs):
         assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
 
 
+@pytest.mark.parametrize("n,mu,batch", [(1247, 1.6, 120000), (4096, 1.2, 50000)])
+def test_ragged_long_tailed_small_pairs(hip, oracle, knobs, n, mu, batch):
+    """A log-normal batch of small pairs with a long tail (mean ~8 x 8 terms, a few pairs of hundreds): unsliced,
+    untouched, 16 chunks per workgroup by default.  Same words for other chunk / turn / touch settings; the largest
+    pairs, the smallest and a sample equal the oracle."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(int(mu * 10) + n)
+    t1s = np.clip(rng.lognormal(mu, 1, batch), 1, 600).astype(int)
+    t2s = np.clip(rng.lognormal(mu, 1, batch), 1, 600).astype(int)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    total = int(np.sum(t1s * t2s))
+    assert total >= 65536 and total // batch < 512 and int(t1s.max()) > 16
+    L = hip.synth_fill(93, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(94, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+    out = out.clone()
+    for c, m in ((8, 4), (2, 2), (1, 1)):
+        knobs.set("ragged_c", c)
+        knobs.set("ragged_m", m)
+        ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+        assert torch.equal(out, ref) and torch.equal(off, ref_off), (c, m)
+    mo = hip.download(off)
+    hl, hr = hip.download(L), hip.download(R)
+    order = np.argsort(t1s * t2s)
+    picks = set(order[-6:].tolist()) | set(order[:3].tolist()) | {0, batch - 1} | set(rng.integers(0, batch, 40).tolist())
+    for b in sorted(picks):
+        want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+        assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
 @pytest.mark.parametrize("n,lo,hi,batch", [(1247, 0, 6, 300000), (1247, 4, 13, 60000), (4096, 1, 9, 40000), (128, 0, 6, 200000)])
 def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
     """Batches of SMALL pairs (0..5, 4..12, 1..8 terms; also N=128 with its one-unit terms): by default the tiled kernel
