@@ -154,18 +154,28 @@ class HipPath:
         return bits[:batch]
 
     def compact_ragged(self, n_bits: int, words: torch.Tensor, off: torch.Tensor,
-                       total_terms: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Extension: mod-2 compaction (identical terms cancel in pairs).  Returns (terms, CSR offsets)."""
+                       total_terms: Optional[int] = None, max_terms: int = 0,
+                       out: Optional[torch.Tensor] = None, off_out: Optional[torch.Tensor] = None,
+                       scratch: Optional[torch.Tensor] = None,
+                       sync: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Extension: mod-2 compaction (identical terms cancel in pairs).  Returns (terms, CSR offsets).
+        max_terms: upper bound on any one ciphertext's terms if known (0 = unknown).  With sync=False
+        nothing is read back and `out` is returned whole (benchmarks)."""
         batch = off.numel() - 1
         dl = self.default_len(n_bits)
         if total_terms is None:
             total_terms = int(self.download(off[-1:])[0])
-        out = self.empty_words(max(total_terms * dl, 1))
-        off_out = self.empty_words(batch + 1)
-        scratch = torch.empty(int(self.lib.csgn_compact_scratch_bytes(total_terms)), dtype=torch.uint8,
-                              device=self.device)
-        check(self.lib.csgn_compact_ragged(n_bits, batch, total_terms, _ptr(words), _ptr(off), _ptr(out),
-                                           _ptr(off_out), _ptr(scratch), self.stream))
+        if out is None:
+            out = self.empty_words(max(total_terms * dl, 1))
+        if off_out is None:
+            off_out = self.empty_words(batch + 1)
+        if scratch is None:
+            scratch = torch.empty(int(self.lib.csgn_compact_scratch_bytes(n_bits, batch, total_terms)),
+                                  dtype=torch.uint8, device=self.device)
+        check(self.lib.csgn_compact_ragged(n_bits, batch, total_terms, max_terms, _ptr(words), _ptr(off),
+                                           _ptr(out), _ptr(off_out), _ptr(scratch), self.stream))
+        if not sync:
+            return out, off_out
         kept = int(self.download(off_out[-1:])[0])
         return out[: kept * dl], off_out
 

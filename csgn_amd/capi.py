@@ -61,8 +61,8 @@ SIGNATURES = {
     "csgn_decrypt_combined_scratch_bytes": (C.c_size_t, [u64, u64, u64]),
     "csgn_decrypt_product_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_decrypt_sum_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
-    "csgn_compact_scratch_bytes": (C.c_size_t, [u64]),
-    "csgn_compact_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_compact_scratch_bytes": (C.c_size_t, [u64, u64, u64]),
+    "csgn_compact_ragged": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_encrypt_explicit": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp, vp]),
     "csgn_rng_from_os": (C.c_int, [vp, C.c_uint32]),
     "csgn_rng_from_seed": (C.c_int, [vp, u64, C.c_uint32]),

@@ -543,9 +543,14 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
     return CSGN_OK;
 }
 
-size_t csgn_compact_scratch_bytes(uint64_t total_terms) { return csgn::compact_scratch_bytes(total_terms); }
+size_t csgn_compact_scratch_bytes(uint64_t n_bits, uint64_t batch, uint64_t total_terms)
+{
+    if (n_bits == 0 || !csgn::compact_supported(n_bits))
+        return 0;
+    return csgn::compact_scratch_bytes(n_bits, batch, total_terms);
+}
 
-int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms, uint64_t max_terms,
                         const uint64_t *d_terms, const uint64_t *d_off,
                         uint64_t *d_out, uint64_t *d_off_out, void *d_scratch, void *stream)
 {
@@ -555,10 +560,12 @@ int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
         return CSGN_OK;
     REQUIRE(d_off && d_off_out && d_scratch && ((d_terms && d_out) || total_terms == 0),
             "null device pointer");
-    hipError_t e = csgn::compact(n_bits, batch, total_terms, (const u64 *)d_terms, (const u64 *)d_off,
+    REQUIRE(d_terms != d_out || total_terms == 0, "compaction is not done in place");
+    hipError_t e = csgn::compact(n_bits, batch, total_terms, max_terms, (const u64 *)d_terms, (const u64 *)d_off,
                                  (u64 *)d_out, (u64 *)d_off_out, d_scratch, S(stream));
     if (e == hipErrorInvalidValue)
-        return fail(CSGN_ERR_UNSUPPORTED, "compaction handles fewer than 2^31 ciphertexts and terms per call");
+        return fail(CSGN_ERR_UNSUPPORTED,
+                    "compaction handles fewer than 2^31 ciphertexts and terms per call");
     HIP_TRY(e);
     return CSGN_OK;
 }

@@ -44,9 +44,13 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                       const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s);
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
                    const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s);
-size_t compact_scratch_bytes(u64 total_terms);
-hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, const u64 *terms, const u64 *off, u64 *out,
-                   u64 *off_out, void *scratch, hipStream_t s);
+// mod-2 compaction (csgn_compact.hip).  max_terms: an upper bound on the terms of any one ciphertext when
+// the caller knows it (0 = unknown); it only decides whether the kernels for ciphertexts larger than a
+// workgroup's group are launched at all.
+bool compact_supported(u64 n_bits);
+size_t compact_scratch_bytes(u64 n_bits, u64 batch, u64 total_terms);
+hipError_t compact(u64 n_bits, u64 batch, u64 total_terms, u64 max_terms, const u64 *terms, const u64 *off,
+                   u64 *out, u64 *off_out, void *scratch, hipStream_t s);
 hipError_t encrypt(u64 n_bits, u64 d, u64 batch, const uint8_t *plain, const u64 *rnd,
                    const u32 *chosen, const uint8_t *last, const u64 *mask, u64 *out, hipStream_t s);
 // Keyed (ChaCha) device-RNG encrypt; keystream layout in csgn_encrypt.hip.

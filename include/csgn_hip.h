@@ -204,10 +204,19 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
  * replaced by its distinct odd-multiplicity terms without changing Dec under ANY key.  Output
  * keeps one copy of each such term at the position order of first occurrence; d_off_out
  * receives the compacted CSR offsets (d_off_out[batch] = terms kept).  d_out needs room for
- * total_terms*dL words, d_scratch for csgn_compact_scratch_bytes(total_terms) bytes.  Never
- * called on a parity path. */
-size_t csgn_compact_scratch_bytes(uint64_t total_terms);
-int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+ * total_terms*dL words and must not overlap d_terms; d_scratch needs
+ * csgn_compact_scratch_bytes(n_bits, batch, total_terms) bytes.
+ * max_terms: an upper bound on the term count of any ONE ciphertext of the batch when the caller
+ * knows it, 0 = unknown.  It is a launch hint only: a ciphertext up to one workgroup's group (1024
+ * terms at N=1247) is read once and deduplicated in LDS, larger ones go through a hash table in
+ * HBM whose kernels are skipped when the bound rules them out.  A ciphertext that exceeds a
+ * non-zero bound it was promised to respect is copied through uncompacted (still a legal result).
+ * Bit-exact for every input: terms are matched by a 48-bit hash tag first and then compared in
+ * full; a tag collision between unequal terms only costs time.
+ * Limits: fewer than 2^31 ciphertexts and terms per call (CSGN_ERR_UNSUPPORTED).
+ * Never called on a parity path. */
+size_t csgn_compact_scratch_bytes(uint64_t n_bits, uint64_t batch, uint64_t total_terms);
+int csgn_compact_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms, uint64_t max_terms,
                         const uint64_t *d_terms, const uint64_t *d_off,
                         uint64_t *d_out, uint64_t *d_off_out, void *d_scratch, void *stream);
 

@@ -252,7 +252,7 @@ def test_size_guards_do_not_wrap(lib):
     assert lib.csgn_decrypt_uniform(1247, 1 << 40, 1 << 40, p, p, p, p, None) == -2
     assert lib.csgn_decrypt_product_uniform(1247, 1 << 40, 1 << 40, 1, p, p, p, p, p, None) == -2
     # compaction keeps slot indices in 32 bits: 2^31 terms or more are refused
-    assert lib.csgn_compact_ragged(1247, 3, 1 << 31, p, p, p, p, p, None) == -2
+    assert lib.csgn_compact_ragged(1247, 3, 1 << 31, 0, p, p, p + 0x100000, p, p, None) == -2
     assert b"2^31" in lib.csgn_last_error()
     c = C.c_void_p()
     assert lib.csgn_circuit_create(1024, 1 << 40, C.byref(c)) == 0

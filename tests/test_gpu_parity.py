@@ -359,7 +359,7 @@ def test_c_abi_refuses_bad_arguments_before_any_launch(hip):
         "decrypt N=0": lambda: L.csgn_decrypt_uniform(0, 1, 1, X, X, B, X, S),
         "decrypt_ragged null offsets": lambda: L.csgn_decrypt_ragged(n, 1, 1, X, 0, X, B, X, S),
         "decrypt_product null bits": lambda: L.csgn_decrypt_product_uniform(n, 1, 1, 1, X, X, X, 0, X, S),
-        "compact null scratch": lambda: L.csgn_compact_ragged(n, 1, 1, X, X, X, X, 0, S),
+        "compact null scratch": lambda: L.csgn_compact_ragged(n, 1, 1, 0, X, X, X, X, 0, S),
         "encrypt_explicit d=0": lambda: L.csgn_encrypt_explicit(n, 0, 1, B, X, X, X, X, X, S),
         "encrypt_explicit null": lambda: L.csgn_encrypt_explicit(n, 16, 1, B, 0, X, X, X, X, S),
         "encrypt_keyed null rng": lambda: L.csgn_encrypt_keyed(n, 16, 1, 0, B, X, X, 0, X, S),
@@ -1404,6 +1404,150 @@ def test_compaction_of_squared_sum(hip, oracle):
     assert hip.download(off_out).tolist() == [0, 2]
     bit = hip.download(hip.decrypt_uniform(n, 1, 2, out, dmask))[0]
     assert bit == hip.download(hip.decrypt_uniform(n, 1, 4, sq, dmask))[0] == 1
+
+
+def _dup_ciphertext(oracle, rng, n, seed, pool, draws):
+    """`draws` terms drawn with repetition from `pool` distinct synthetic terms (pool 0 = no terms)."""
+    dl = oracle.default_len(n)
+    if draws == 0:
+        return np.zeros(0, dtype=np.uint64)
+    base = oracle.synth(seed, n, 0, pool * dl).reshape(pool, dl)
+    return np.ascontiguousarray(base[rng.integers(0, pool, size=draws)].reshape(-1))
+
+
+def _check_compaction(hip, oracle, n, cts, max_terms=0, expect_compacted=True):
+    dl = oracle.default_len(n)
+    off = csr([c.size // dl for c in cts])
+    flat = np.concatenate(cts) if off[-1] else np.zeros(0, dtype=np.uint64)
+    out, off_out = hip.compact_ragged(n, hip.upload(flat) if flat.size else hip.empty_words(1), hip.upload(off),
+                                      total_terms=int(off[-1]), max_terms=max_terms)
+    out, off_out = hip.download(out), hip.download(off_out)
+    assert off_out[0] == 0 and np.all(np.diff(off_out.astype(np.int64)) >= 0)
+    for b, ct in enumerate(cts):
+        got = out[int(off_out[b]) * dl:int(off_out[b + 1]) * dl]
+        want = oracle.compact(n, ct) if expect_compacted else ct
+        assert np.array_equal(got, want), (n, b, ct.size // dl, got.size // dl, want.size // dl)
+    assert out.size == int(off_out[-1]) * dl
+    return off_out
+
+
+@pytest.mark.parametrize("n", [1247, 4096, 130, 129, 63])
+def test_compaction_many_groups_and_sizes(hip, oracle, n):
+    """Several hundred ciphertexts of every size class in one call: runs of small ones that share a
+    workgroup, ciphertexts that fill one alone, empty ones in every position, and (at the wider contexts)
+    ciphertexts beyond a workgroup's group that go through the HBM table -- all behind one look-back
+    chain of output offsets.  Term lists identical to the checker's."""
+    rng = np.random.default_rng(n + 11)
+    cts = []
+    for b in range(260):
+        kind = rng.integers(0, 10)
+        if kind == 0:
+            draws = 0
+        elif kind < 6:
+            draws = int(rng.integers(1, 40))
+        elif kind < 9:
+            draws = int(rng.integers(40, 700))
+        else:
+            draws = int(rng.integers(700, 1400))
+        pool = max(1, int(draws * rng.choice([0.05, 0.5, 1.0, 3.0])))
+        cts.append(_dup_ciphertext(oracle, rng, n, 3000 + b, pool, draws))
+    cts[0] = np.zeros(0, dtype=np.uint64)                      # leading, trailing and adjacent empties
+    cts[-1] = np.zeros(0, dtype=np.uint64)
+    cts[100] = cts[101] = cts[102] = np.zeros(0, dtype=np.uint64)
+    _check_compaction(hip, oracle, n, cts)
+
+
+def test_compaction_large_ciphertexts(hip, oracle):
+    """Ciphertexts of many workgroup groups (3 000 to 40 000 terms at N=1247: the HBM-table path), between
+    small ones, with 0 %, 50 % and 97 % duplicates."""
+    n = 1247
+    rng = np.random.default_rng(5)
+    cts = [_dup_ciphertext(oracle, rng, n, 1, 5, 9),
+           _dup_ciphertext(oracle, rng, n, 2, 40000, 3000),
+           _dup_ciphertext(oracle, rng, n, 3, 20000, 40000),
+           np.zeros(0, dtype=np.uint64),
+           _dup_ciphertext(oracle, rng, n, 4, 300, 10000),
+           _dup_ciphertext(oracle, rng, n, 5, 100, 1024),
+           _dup_ciphertext(oracle, rng, n, 6, 2000, 1025),
+           _dup_ciphertext(oracle, rng, n, 7, 3, 2)]
+    off_out = _check_compaction(hip, oracle, n, cts)
+    assert int(off_out[6]) - int(off_out[5]) <= 100
+
+
+def test_compaction_one_million_single_terms_and_empties(hip, oracle):
+    """A batch of 2^20 ciphertexts of 0, 1 or 2 terms: groups are runs of hundreds of ciphertexts whose
+    offsets the workgroup stages in LDS; x + x vanishes."""
+    n, dl = 1247, 20
+    rng = np.random.default_rng(9)
+    counts = rng.integers(0, 3, size=1 << 20)
+    same = rng.integers(0, 2, size=counts.size).astype(bool)          # a 2-term ciphertext of two equal terms
+    total = int(counts.sum())
+    words_ = oracle.synth(77, n, 0, total * dl).reshape(total, dl)
+    off = csr(counts)
+    starts = off[:-1].astype(np.int64)
+    twin = np.nonzero((counts == 2) & same)[0]
+    words_[starts[twin] + 1] = words_[starts[twin]]
+    out, off_out = hip.compact_ragged(n, hip.upload(words_.reshape(-1)), hip.upload(off), total_terms=total,
+                                      max_terms=2)
+    out, off_out = hip.download(out).reshape(-1, dl), hip.download(off_out)
+    want_counts = counts.copy()
+    want_counts[twin] = 0
+    assert np.array_equal(np.diff(off_out.astype(np.int64)), want_counts)
+    keep = np.ones(total, dtype=bool)
+    keep[starts[twin]] = keep[starts[twin] + 1] = False
+    assert np.array_equal(out, words_[keep])
+
+
+@pytest.mark.parametrize("bits", [1, 3])
+def test_compaction_survives_tag_collisions(hip, oracle, knobs, bits):
+    """With the hash tags narrowed to a few bits, unequal terms collide all the time: the verify pass
+    catches it and the group (or the HBM table) is redone with full compares -- the words stay exact."""
+    knobs.set("compact_tag_bits", bits)
+    rng = np.random.default_rng(bits)
+    for n in (1247, 129):
+        cts = [_dup_ciphertext(oracle, rng, n, 10, 50, 200),
+               _dup_ciphertext(oracle, rng, n, 11, 1000, 1000),
+               _dup_ciphertext(oracle, rng, n, 12, 700, 2500),
+               _dup_ciphertext(oracle, rng, n, 13, 2, 7),
+               np.zeros(0, dtype=np.uint64),
+               _dup_ciphertext(oracle, rng, n, 14, 30, 31)]
+        _check_compaction(hip, oracle, n, cts)
+
+
+def test_compaction_sparse_terms(hip, oracle):
+    """Deep products are sparse (a bit survives ten ANDs with probability 2^-10): terms with one or two set
+    bits, many of them equal or all zero, must hash apart and merge exactly."""
+    n, dl = 1247, 20
+    rng = np.random.default_rng(3)
+    cts = []
+    for t in (1000, 64, 1024, 2000):
+        rows = np.zeros((t, dl), dtype=np.uint64)
+        for r in range(t):
+            for _ in range(int(rng.integers(0, 3))):
+                bit = int(rng.integers(0, 200))                # few positions: plenty of equal terms
+                rows[r, bit // 64] |= np.uint64(1) << np.uint64(63 - bit % 64)
+        cts.append(rows.reshape(-1))
+    _check_compaction(hip, oracle, n, cts)
+
+
+def test_compaction_bound_that_is_exceeded_copies_the_ciphertext(hip, oracle):
+    """max_terms is a launch hint: a ciphertext larger than one group that breaks a promised bound is
+    copied through as it is (legal: Dec unchanged), everything else is compacted."""
+    n = 1247
+    rng = np.random.default_rng(8)
+    big = _dup_ciphertext(oracle, rng, n, 21, 10, 3000)
+    small = _dup_ciphertext(oracle, rng, n, 22, 10, 300)
+    dl = oracle.default_len(n)
+    off = csr([small.size // dl, big.size // dl, small.size // dl])
+    out, off_out = hip.compact_ragged(n, hip.upload(np.concatenate([small, big, small])), hip.upload(off),
+                                      max_terms=512)
+    out, off_out = hip.download(out), hip.download(off_out)
+    want_small = oracle.compact(n, small)
+    k = want_small.size // dl
+    assert off_out.tolist() == [0, k, k + 3000, 2 * k + 3000]
+    assert np.array_equal(out[:k * dl], want_small)
+    assert np.array_equal(out[k * dl:(k + 3000) * dl], big)
+    assert np.array_equal(out[(k + 3000) * dl:], want_small)
 
 
 ENC_FORMS = {"seg": {}, "lds": {"CSGN_ENC_LDS": "1"}}
