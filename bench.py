@@ -24,9 +24,14 @@ ncclAllGather, include/csgn_shard.h) on the SAME explicit HIP stream as the mult
 that time it.  The ranks rendezvous over gloo (the ncclUniqueId is 128 bytes; barrier and the
 max-over-ranks time are host-side too), so a rank holds ONE RCCL communicator -- the native one --
 and no torch NCCL process group; `config.collective` names the RCCL version and file the process
-bound.  A rank that fails aborts its communicator and exits non-zero (torchrun then ends the
-others): no fall-back to another collective path once RCCL initialisation has begun.
-`--collective torch` is the opt-in alternative (torch.distributed's own RCCL process group).
+bound (a torch process has torch/lib/librccl.so mapped already: a minor-version difference from the
+header libcsgn_shard.so was built against is accepted with CSGN_COMM_ALLOW_MINOR_SKEW and reported
+there; a major one is refused).  Set-up failures are handled by agreement, never rank by rank: if the
+native library cannot be loaded on every rank the job exits 1; if the communicator cannot be formed
+on every rank, ALL ranks (a MIN all-reduce over gloo decides) drop it together and form
+torch.distributed's RCCL group for the same gather, and `config.collective` says FALLBACK.  Once the
+timed loop runs, a rank that fails aborts its communicator and exits non-zero (torchrun then ends the
+others).  `--collective torch` is the opt-in alternative (torch.distributed's own RCCL process group).
 
 Rank 0 prints ONE JSON line (contract in the task description), including
   "roofline":     algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak

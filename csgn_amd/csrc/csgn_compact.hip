@@ -36,10 +36,10 @@ namespace csgn {
 
 namespace {
 
-constexpr u32 kCT = 1024;                 // threads of a group's workgroup
-constexpr int kCR = 10;                   // units per lane held in registers: 10 240 units = 1024 terms at N=1247
+constexpr u32 kCT = 512;                  // threads of a group's workgroup: two workgroups share a CU
+constexpr int kCR = 20;                   // units per lane held in registers: 10 240 units = 1024 terms at N=1247
 constexpr u32 kCapUnits = kCT * kCR;
-constexpr u32 kMaxGroupTerms = 1536;      // LDS: 40 B per term + tables stay under 64 KiB
+constexpr u32 kMaxGroupTerms = 1024;      // two one-lane-per-term passes; LDS: 40 B per term
 
 // control words (u64 each) at the head of the scratch block; zeroed, with the status granules, per call
 enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlWords = 32 };
@@ -66,8 +66,10 @@ Geom make_geom(u32 U)
 // groups a call can produce at most: one per window, two per big ciphertext, the chunks of large ones
 u64 group_bound(u64 total_terms, const Geom &g) { return 4 + 10 * (total_terms / g.capT + 1); }
 
+struct GroupDesc;
 struct Layout {
-    u64 *ctrl, *status, *groups, *chunks, *partial, *hash, *tab;
+    GroupDesc *groups;
+    u64 *ctrl, *status, *chunks, *partial, *hash, *tab;
     u32 *gpos, *par, *slot_of;
     size_t bytes, head_bytes;
 };
@@ -87,7 +89,7 @@ Layout make_layout(void *scratch, u64 batch, u64 total_terms, const Geom &g)
     l.ctrl = reinterpret_cast<u64 *>(take((kCtrlWords + ng) * 8));
     l.status = l.ctrl + kCtrlWords;
     l.head_bytes = (kCtrlWords + ng) * 8;
-    l.groups = reinterpret_cast<u64 *>(take(ng * 8));
+    l.groups = reinterpret_cast<GroupDesc *>(take(ng * 32));
     l.chunks = reinterpret_cast<u64 *>(take(ng * 8));
     l.gpos = reinterpret_cast<u32 *>(take(batch * 4));
     l.partial = reinterpret_cast<u64 *>(take((batch / 256 + 2) * 8));
@@ -100,24 +102,49 @@ Layout make_layout(void *scratch, u64 batch, u64 total_terms, const Geom &g)
 }
 
 // ------------------------------------------------------------------------------- hashing
-constexpr u64 kHashA = 0xA0761D6478BD642Full, kHashB = 0xE7037ED1A0B428DBull, kHashP = 0x8EBC6AF09C88C6E3ull;
+// Contribution of unit k of a term to the term's hash; the contributions are summed mod 2^64 (and the
+// sum is finished with splitmix64).  UMAC's NH step: 32-bit words plus 32-bit keys, multiplied in pairs
+// to 64 bits -- two v_mad_u64_u32 per 16-byte unit.  The keys move with the unit's position in the term
+// (two full-rate 24-bit multiplies), so equal units in different places contribute differently.  A
+// contribution cannot be the same for two units that differ in ONE word (a product of two non-zero 32-bit
+// numbers is not 0 mod 2^64); anything else is a ~2^-64 accident -- and an accident only costs the
+// exact redo, never a wrong merge.
+constexpr u32 kNhA = 0x9E3779B9u, kNhB = 0x85EBCA6Bu, kNhC = 0xC2B2AE35u, kNhD = 0x27D4EB2Fu;
+constexpr u32 kNhP = 0x9E3779u, kNhQ = 0xC2B2AFu;            // 24-bit odd position multipliers
 
-__device__ inline u64 fold_mul(u64 a, u64 b)
-{
-    const unsigned __int128 m = (unsigned __int128)a * b;
-    return (u64)m ^ (u64)(m >> 64);
-}
-// contribution of unit k of a term to the term's hash; the contributions are summed mod 2^64
 __device__ inline u64 unit_hash(unit16 v, u32 k)
 {
-    const u64 pk = (u64)(k + 1u) * kHashP;
-    const u64 lo = ((u64)v.y << 32) | v.x, hi = ((u64)v.w << 32) | v.z;
-    return fold_mul(lo ^ (kHashA + pk), hi ^ kHashB ^ ((pk >> 23) | (pk << 41)));
+    const u32 p = __umul24(k + 1u, kNhP), q = __umul24(k + 1u, kNhQ);
+    return (u64)(v.x + kNhA + p) * (u64)(v.y + kNhB + q) + (u64)(v.z + kNhC + q) * (u64)(v.w + kNhD + p);
 }
 __device__ inline u64 unit_hash(unit8 v, u32 k)
 {
-    const u64 pk = (u64)(k + 1u) * kHashP;
-    return fold_mul(v ^ (kHashA + pk), kHashB ^ ((pk >> 23) | (pk << 41)));
+    const u32 p = __umul24(k + 1u, kNhP), q = __umul24(k + 1u, kNhQ);
+    return (u64)((u32)v + kNhA + p) * (u64)((u32)(v >> 32) + kNhB + q);
+}
+// term and position of a lane's units: unit j = i * kCT + lane for i = 0, 1, ... walks on by a fixed stride
+struct UnitPos {
+    u32 t, k;
+};
+struct UnitWalk {
+    u32 U, step_t, step_k;       // kCT = step_t * U + step_k
+    FastDiv dU;
+};
+__device__ inline UnitPos walk_first(const UnitWalk &w, u32 lane_unit)
+{
+    UnitPos p;
+    p.t = csgn_fastdiv(lane_unit, w.dU);
+    p.k = lane_unit - p.t * w.U;
+    return p;
+}
+__device__ inline void walk_next(const UnitWalk &w, UnitPos &p)
+{
+    p.k += w.step_k;
+    p.t += w.step_t;
+    if (p.k >= w.U) {
+        p.k -= w.U;
+        p.t += 1u;
+    }
 }
 __device__ inline bool unit_same(unit16 a, unit16 b)
 {
@@ -230,27 +257,54 @@ __global__ void __launch_bounds__(1024) k_cg_scan(u64 nblocks, u64 *__restrict__
     }
 }
 
-// group descriptor = first ciphertext | chunk << 32; the chunks of large ciphertexts are listed a
-// second time (any order) for the k_cl_* kernels
+// What a workgroup needs to know about a group, complete, so that one 32-byte (scalar) load after the
+// ticket is all that stands between two groups.
+struct GroupDesc {
+    u64 tb, te;              // the group's terms
+    u32 c0, c1;              // its ciphertexts [c0, c1)
+    u32 chunk, large;        // a chunk of a large ciphertext: which one
+};
+
+// The thread of a group's FIRST ciphertext writes {tb, c0, chunk, large}, the thread of its LAST one
+// {te, c1} (the same thread for a group of one); the chunks of large ciphertexts are listed a second
+// time (any order) for the k_cl_* kernels.
 __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restrict__ off, Geom g,
                                                  const u32 *__restrict__ gpos, const u64 *__restrict__ partial,
-                                                 u64 *__restrict__ groups, u64 *__restrict__ chunks,
+                                                 GroupDesc *__restrict__ groups, u64 *__restrict__ chunks,
                                                  u64 *__restrict__ ctrl)
 {
     const u32 c = blockIdx.x * 256u + threadIdx.x;
     if (c >= batch)
         return;
-    bool large;
+    bool large, next_large;
     const u32 n = group_count(off, c, g, large);
-    if (n == 0)
-        return;
-    const u64 base = partial[blockIdx.x] + gpos[c];
-    for (u32 i = 0; i < n; ++i)
-        groups[base + i] = (u64)c | ((u64)i << 32);
+    const u64 before = partial[blockIdx.x] + gpos[c];             // groups started before c
+    const u64 o0 = off[c], o1 = off[c + 1];
     if (large) {
         const u64 at = atomicAdd(ull(ctrl + kCtrlChunks), (unsigned long long)n);
-        for (u32 i = 0; i < n; ++i)
+        for (u32 i = 0; i < n; ++i) {
+            GroupDesc d;
+            d.tb = o0 + (u64)i * g.capT;
+            d.te = min(d.tb + g.capT, o1);
+            d.c0 = c;
+            d.c1 = c + 1u;
+            d.chunk = i;
+            d.large = 1u;
+            groups[before + i] = d;
             chunks[at + i] = (u64)c | ((u64)i << 32);
+        }
+        return;
+    }
+    const u64 gid = n ? before : before - 1u;                     // the run c belongs to
+    if (n) {
+        groups[gid].tb = o0;
+        groups[gid].c0 = c;
+        groups[gid].chunk = 0u;
+        groups[gid].large = 0u;
+    }
+    if (c + 1u == batch || group_count(off, c + 1u, g, next_large) > 0u) {
+        groups[gid].te = o1;
+        groups[gid].c1 = c + 1u;
     }
 }
 
@@ -262,7 +316,7 @@ struct CompactArgs {
     u64 *off_out;
     u64 *ctrl;
     u64 *status;
-    const u64 *groups;
+    const GroupDesc *groups;
     const u64 *tab;          // HBM table of the large ciphertexts (k_cl_*), two slots per term
     const u32 *par;
     const u32 *slot_of;
@@ -272,7 +326,16 @@ struct CompactArgs {
     u32 batch;
     u32 dL;
     u32 large_ready;         // the k_cl_* kernels ran: large ciphertexts have a keep decision
+    u64 *stamps;             // dev only (CSGN_COMPACT_STAMPS)
 };
+
+// dev-only phase stamps (tools/prof_compact_phases.py builds with -DCSGN_COMPACT_STAMPS): 100 MHz ticks of
+// thread 0 per group and phase, written just past the scratch block (the tool allocates the extra room)
+#ifdef CSGN_COMPACT_STAMPS
+#define CSGN_STAMP(i) do { if (tid == 0) a.stamps[(u64)gid * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSGN_STAMP(i) do { } while (0)
+#endif
 
 constexpr u64 kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 
@@ -312,127 +375,157 @@ __device__ inline u64 lookback(u64 *status, u32 gid, u64 count)
     return excl;
 }
 
-// One lane per term: find the term's slot in its ciphertext's region [2*a0, 2*b0) of the LDS table.
-// EXACT compares the words of a tag match before joining its class (the redo after a collision).
-template <bool EXACT>
-__device__ inline u32 lds_insert(u64 *s_tab, u32 *s_par, u64 h, u64 tag_mask, u32 t, u32 a0, u32 b0,
-                                 const u64 *words, u32 dL)
+constexpr int kSub = 5;                                          // register rows hashed per staging round
+static_assert(kCR % kSub == 0, "hash staging rounds must tile the register rows");
+constexpr int kPasses = (int)((kMaxGroupTerms + kCT - 1) / kCT);  // term passes of the one-lane-per-term steps
+
+// dynamic LDS of the main kernel for groups of capT terms
+__host__ __device__ inline size_t main_lds_bytes(u32 capT)
 {
-    const u32 ns = 2u * (b0 - a0);
-    u32 slot = 2u * a0 + (u32)(((u64)(u32)h * ns) >> 32);
-    const u64 tag = (h >> 16) & tag_mask;
-    const u64 entry = (tag << 16) | (u64)(t + 1u);
-    for (;;) {
-        const u64 cur = atomicCAS(ull(s_tab + slot), 0ull, entry);
-        if (cur == 0ull)
-            break;
-        if ((cur >> 16) == tag) {
-            bool same = true;
-            if (EXACT) {
-                const u32 r = (u32)(cur & 0xFFFFu) - 1u;
-                same = words_equal(words + (u64)t * dL, words + (u64)r * dL, dL);
-            }
-            if (same) {
-                atomicMin(ull(s_tab + slot), entry);
-                break;
-            }
-        }
-        slot = slot + 1u == 2u * b0 ? 2u * a0 : slot + 1u;
-    }
-    atomicXor(s_par + slot, 1u);
-    return slot;
+    return (size_t)capT * (8 + 4 + 4 + 4 + 4) + 64 + (size_t)(kCT / kWave) * kSub * kWave * 8;
 }
 
+// Unit j of a group sits in wave w = j / (64 R), register row i = (j / 64) % R, lane j % 64: every wave
+// owns a contiguous span of 64 R units (coalesced 1 KiB wave loads all the same), so the hashes of a
+// term's units meet inside ONE wave.
 template <typename Unit, int R>
-__global__ void __launch_bounds__(kCT) k_compact_main(CompactArgs a)
+__global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs a)
 {
     extern __shared__ u64 s_dyn[];
     const u32 capT = a.g.capT, U = a.g.U;
-    u64 *s_hash = s_dyn;                                          // [capT] hash sums, then {slot, representative}
-    u64 *s_tab = s_hash + capT;                                   // [2 capT] {tag, smallest index + 1}
-    u32 *s_par = reinterpret_cast<u32 *>(s_tab + 2 * capT);       // [2 capT] parity of the class
-    u32 *s_rk = s_par + 2 * capT;                                 // [capT + 1] rank << 1 | keep
+    u64 *s_node = s_dyn;                                          // [capT] hash sum, then {tag, next in bucket}
+    u64 *s_part = s_node + capT;                                  // [waves][kSub * 64] unit hashes in flight
+    u32 *s_head = reinterpret_cast<u32 *>(s_part + (kCT / kWave) * kSub * kWave);   // [capT] bucket heads
+    u32 *s_rep = s_head + capT;                                   // [capT] smallest equal term
+    u32 *s_rk = s_rep + capT;                                     // [capT + 1] rank << 1 | keep
     u32 *s_coff = s_rk + capT + 2;                                // [capT + 2] ciphertext starts inside the group
-    __shared__ u32 s_ticket, s_flag, s_wsum[kCT / kWave];
+    __shared__ u64 s_desc[4];                                     // {tb, te, c0 | c1 << 32, chunk | large << 32 | ticket << 33}
+    __shared__ u32 s_join, s_bad, s_wsum[kPasses * (kCT / kWave)];
     __shared__ u64 s_prefix;
     const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
     Unit *__restrict__ out = static_cast<Unit *>(a.out);
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const u32 ngroups = (u32)a.ctrl[kCtrlGroups];
-    constexpr int PASSES = (kMaxGroupTerms + kCT - 1) / kCT;      // term passes of the one-lane-per-term steps
+    UnitWalk walk;                                                // from one register row to the next: 64 units on
+    walk.U = U;
+    walk.step_t = kWave / U;
+    walk.step_k = kWave - walk.step_t * U;
+    walk.dU = a.dU;
 
-    for (;;) {
-        if (tid == 0) {
-            s_ticket = atomicAdd(reinterpret_cast<u32 *>(a.ctrl + kCtrlTicket), 1u);
-            s_flag = 0u;
+    const u64 *gwords = reinterpret_cast<const u64 *>(a.groups);  // a descriptor = four 8-byte words
+    if (wave == 0) {
+        u32 gid = 0u;
+        if (lane == 0)
+            gid = atomicAdd(reinterpret_cast<u32 *>(a.ctrl + kCtrlTicket), 1u);
+        gid = __builtin_amdgcn_readfirstlane(gid);
+        if (lane < 4u) {
+            u64 w = gid < ngroups ? gwords[(u64)gid * 4u + lane] : 0ull;
+            if (lane == 3u)
+                w = (w & 0x1FFFFFFFFull) | ((u64)gid << 33);      // the ticket rides in the descriptor
+            s_desc[lane] = w;
         }
-        __syncthreads();
-        const u32 gid = s_ticket;
+        if (lane == 0) {
+            s_join = 0u;
+            s_bad = 0u;
+        }
+    }
+    __syncthreads();
+    for (;;) {
+        const u64 d0 = s_desc[0], d1 = s_desc[1], d2 = s_desc[2], d3 = s_desc[3];
+        const u32 gid = (u32)(d3 >> 33);
         if (gid >= ngroups)
             break;
-        // opaque copy of the thread index: everything derived from it (unit -> term, position tweaks of
-        // the hash) would otherwise be hoisted out of the ticket loop, ten units at a time, and spill
-        u32 ltid = tid;
-        asm volatile("" : "+v"(ltid));
-        const u64 desc = a.groups[gid];
-        const u32 c0 = (u32)desc, chunk = (u32)(desc >> 32);
-        const u64 o0 = a.off[c0], o1 = a.off[c0 + 1];
-        const bool large = o1 - o0 > capT;
-        u32 c1;
-        u64 tb, te;
-        if (large) {
-            c1 = c0 + 1u;
-            tb = o0 + (u64)chunk * capT;
-            te = min(tb + capT, o1);
-        } else {
-            c1 = gid + 1u < ngroups ? (u32)a.groups[gid + 1u] : a.batch;
-            tb = o0;
-            te = a.off[c1];
-        }
-        const u32 nt = (u32)(te - tb), nunits = nt * U, ncts = c1 - c0;
+        CSGN_STAMP(0);
+        const bool large = ((d3 >> 32) & 1ull) != 0ull;
+        const u32 c0 = (u32)d2, c1 = (u32)(d2 >> 32), chunk = (u32)d3;
+        const u64 tb = d0;
+        const u32 nt = (u32)(d1 - tb), nunits = nt * U, ncts = c1 - c0;
         const u64 ub = tb * U;
         const bool multi = !large && ncts > 1u, staged = multi && ncts <= capT + 1u;
+        // The thread index is made opaque once per group: otherwise everything derived from it (LDS
+        // addresses, unit -> term maps, lane masks, twenty rows' worth of each) is hoisted out of the ticket
+        // loop as loop-invariant and spilled -- and a spill reload queues behind the stores in flight.
+        asm volatile("" : "+v"(tid));
+        lane = tid & (kWave - 1);
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const u32 j0 = wave * (kWave * R) + lane;
+        CSGN_STAMP(1);
 
         // 1. the group's units -> registers
         Unit reg[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const u32 j = (u32)i * kCT + ltid;
+            const u32 j = j0 + (u32)i * kWave;
             reg[i] = j < nunits ? terms[ub + j] : unit_zero<Unit>();
         }
-        for (u32 x = tid; x < nt; x += kCT)
-            s_hash[x] = 0ull;
-        for (u32 x = tid; x < 2u * nt; x += kCT) {
-            s_tab[x] = 0ull;
-            s_par[x] = 0u;
+        for (u32 x = tid; x < nt; x += kCT) {
+            s_node[x] = 0ull;
+            s_head[x] = 0u;
         }
         if (staged)
             for (u32 x = tid; x <= ncts; x += kCT)
                 s_coff[x] = (u32)(a.off[c0 + x] - tb);
         __syncthreads();
+#ifdef CSGN_COMPACT_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // so that stamp 2 - stamp 1 is the load time
+        __syncthreads();
+#endif
+        CSGN_STAMP(2);
 
-        u32 keep[PASSES];
+        u32 keep[kPasses];
         if (!large) {
-            // 2. term hashes
+            // 2. term hashes: kSub rows of unit hashes at a time through the wave's own LDS strip, then
+            //    one lane per term of the strip adds its units up (DS operations of one wave run in order:
+            //    no barrier); only a term cut by the strip's edge needs an atomic
+            {
+                u64 *part = s_part + wave * (kSub * kWave);
+                u32 jh = j0;                                      // (a copy of its own per phase: the twenty
+                asm volatile("" : "+v"(jh));                      //  {term, position} pairs must not stay live)
+                UnitPos pos = walk_first(walk, jh);
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const u32 j = (u32)i * kCT + ltid;
-                if (j < nunits) {
-                    const u32 t = csgn_fastdiv(j, a.dU), k = j - t * U;
-                    atomicAdd(ull(s_hash + t), unit_hash(reg[i], k));
+                for (int r = 0; r < R / kSub; ++r) {
+                    const u32 w0 = wave * (kWave * R) + (u32)r * (kSub * kWave);      // first unit of the strip
+#pragma unroll
+                    for (int q = 0; q < kSub; ++q) {
+                        part[q * (int)kWave + (int)lane] = unit_hash(reg[r * kSub + q], pos.k);
+                        walk_next(walk, pos);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (w0 < nunits) {                            // wave-uniform
+                        const u32 w1 = min(w0 + kSub * kWave, nunits);
+                        const u32 tf = csgn_fastdiv(w0, a.dU), tl = csgn_fastdiv(w1 - 1u, a.dU);
+                        for (u32 t = tf + lane; t <= tl; t += kWave) {
+                            const u32 u0 = max(t * U, w0), u1 = min(t * U + U, w1);
+                            u64 s0 = 0ull, s1 = 0ull;
+                            u32 u = u0;
+                            for (; u + 1u < u1; u += 2u) {
+                                s0 += part[u - w0];
+                                s1 += part[u + 1u - w0];
+                            }
+                            if (u < u1)
+                                s0 += part[u - w0];
+                            if (u1 - u0 == U)
+                                s_node[t] = s0 + s1;
+                            else
+                                atomicAdd(ull(s_node + t), s0 + s1);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_sched_barrier(0);                // one hash at a time: ten interleaved ones spill
             }
             __syncthreads();
-            // 3. one lane per term: its ciphertext's table region, then the insert
-            u32 a0[PASSES], b0[PASSES], slot[PASSES];
-            u64 h[PASSES];
+            CSGN_STAMP(3);
+            // 3. one lane per term: chain the term into a bucket of its ciphertext (as many buckets as the
+            //    ciphertext has terms): ONE exchange on the bucket's head, no probing
+            u32 bucket[kPasses];
+            u64 tag[kPasses];
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
+            for (int p = 0; p < kPasses; ++p) {
                 const u32 t = (u32)p * kCT + tid;
-                a0[p] = 0u;
-                b0[p] = nt;
+                bucket[p] = 0u;
+                tag[p] = 0ull;
                 if (t < nt) {
+                    u32 a0 = 0u, b0 = nt;
                     if (staged) {                                 // largest i with s_coff[i] <= t
                         u32 lo = 0u, hi = ncts;
                         while (hi - lo > 1u) {
@@ -442,63 +535,95 @@ __global__ void __launch_bounds__(kCT) k_compact_main(CompactArgs a)
                             else
                                 hi = mid;
                         }
-                        a0[p] = s_coff[lo];
-                        b0[p] = s_coff[lo + 1u];
+                        a0 = s_coff[lo];
+                        b0 = s_coff[lo + 1u];
                     } else if (multi) {
                         const u32 c = csr_find(a.off, c0, c1, tb + t);
-                        a0[p] = (u32)(a.off[c] - tb);
-                        b0[p] = (u32)(a.off[c + 1u] - tb);
+                        a0 = (u32)(a.off[c] - tb);
+                        b0 = (u32)(a.off[c + 1u] - tb);
                     }
-                    h[p] = csgn_splitmix64(s_hash[t]);
-                    slot[p] = lds_insert<false>(s_tab, s_par, h[p], a.tag_mask, t, a0[p], b0[p], nullptr, 0u);
+                    const u64 h = csgn_splitmix64(s_node[t]);
+                    tag[p] = (h >> 16) & a.tag_mask;
+                    bucket[p] = a0 + (u32)(((u64)(u32)h * (b0 - a0)) >> 32);
+                    const u32 next = atomicExch(s_head + bucket[p], t + 1u);
+                    s_node[t] = (tag[p] << 16) | (u64)next;
                 }
             }
             __syncthreads();
+            // ... and walk the bucket: the smallest term with the same tag is the class's representative
+            u32 cnt[kPasses];
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
+            for (int p = 0; p < kPasses; ++p) {
                 const u32 t = (u32)p * kCT + tid;
-                if (t < nt)
-                    s_hash[t] = ((u64)slot[p] << 32) | (u64)((u32)(s_tab[slot[p]] & 0xFFFFu) - 1u);
+                u32 rep = t;
+                cnt[p] = 0u;
+                if (t < nt) {
+                    for (u32 e = s_head[bucket[p]]; e != 0u;) {
+                        const u64 node = s_node[e - 1u];
+                        if ((node >> 16) == tag[p]) {
+                            ++cnt[p];
+                            rep = min(rep, e - 1u);
+                        }
+                        e = (u32)(node & 0xFFFFu);
+                    }
+                    s_rep[t] = rep;
+                    if (rep != t)
+                        s_join = 1u;
+                }
+                keep[p] = (t < nt && rep == t && (cnt[p] & 1u)) ? 1u : 0u;
             }
             __syncthreads();
+            CSGN_STAMP(4);
             // 4. every unit of a term that joined a class is compared with its representative's
+            if (s_join) {
+                u32 jv = j0;
+                asm volatile("" : "+v"(jv));
+                UnitPos pos = walk_first(walk, jv);
+                bool bad = false;
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const u32 j = (u32)i * kCT + ltid;
-                if (j < nunits) {
-                    const u32 t = csgn_fastdiv(j, a.dU), k = j - t * U;
-                    const u32 rep = (u32)s_hash[t];
-                    if (rep != t && !unit_same(terms[(tb + rep) * U + k], reg[i]))
-                        s_flag = 1u;
+                for (int i = 0; i < R; ++i) {
+                    const u32 j = jv + (u32)i * kWave;
+                    if (j < nunits) {
+                        const u32 rep = s_rep[pos.t];
+                        if (rep != pos.t)
+                            bad |= !unit_same(terms[(tb + rep) * U + pos.k], reg[i]);
+                    }
+                    walk_next(walk, pos);
                 }
-            }
-            __syncthreads();
-            if (s_flag) {                                         // a tag collision: redo with full compares
-                for (u32 x = tid; x < 2u * nt; x += kCT) {
-                    s_tab[x] = 0ull;
-                    s_par[x] = 0u;
+                if (bad)
+                    s_bad = 1u;
+                __syncthreads();
+                if (s_bad) {                                      // a tag collision: walk again with full compares
+                    const u64 *words = reinterpret_cast<const u64 *>(a.terms) + tb * a.dL;
+#pragma unroll
+                    for (int p = 0; p < kPasses; ++p) {
+                        const u32 t = (u32)p * kCT + tid;
+                        u32 rep = t;
+                        cnt[p] = 0u;
+                        if (t < nt) {
+                            for (u32 e = s_head[bucket[p]]; e != 0u;) {
+                                const u64 node = s_node[e - 1u];
+                                if ((node >> 16) == tag[p] &&
+                                    (e - 1u == t || words_equal(words + (u64)t * a.dL, words + (u64)(e - 1u) * a.dL, a.dL))) {
+                                    ++cnt[p];
+                                    rep = min(rep, e - 1u);
+                                }
+                                e = (u32)(node & 0xFFFFu);
+                            }
+                        }
+                        keep[p] = (t < nt && rep == t && (cnt[p] & 1u)) ? 1u : 0u;
+                    }
                 }
                 __syncthreads();
-                const u64 *words = reinterpret_cast<const u64 *>(a.terms) + tb * a.dL;
-#pragma unroll
-                for (int p = 0; p < PASSES; ++p) {
-                    const u32 t = (u32)p * kCT + tid;
-                    if (t < nt)
-                        slot[p] = lds_insert<true>(s_tab, s_par, h[p], a.tag_mask, t, a0[p], b0[p], words, a.dL);
+                if (tid == 0) {
+                    s_join = 0u;
+                    s_bad = 0u;
                 }
-                __syncthreads();
             }
-            // 5. survivors: the smallest index of a class of odd size
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const u32 t = (u32)p * kCT + tid;
-                keep[p] = 0u;
-                if (t < nt)
-                    keep[p] = ((u32)(s_tab[slot[p]] & 0xFFFFu) - 1u == t && (s_par[slot[p]] & 1u)) ? 1u : 0u;
-            }
+            CSGN_STAMP(5);
         } else {
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
+            for (int p = 0; p < kPasses; ++p) {
                 const u32 t = (u32)p * kCT + tid;
                 keep[p] = 0u;
                 if (t < nt) {
@@ -511,31 +636,39 @@ __global__ void __launch_bounds__(kCT) k_compact_main(CompactArgs a)
                 }
             }
         }
-        // ranks of the survivors
-        u32 count = 0u;
+        CSGN_STAMP(6);
+        // ranks of the survivors: per pass the waves' ballots, then one look at all the wave counts
+        u32 before[kPasses];
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            if ((u32)p * kCT < nt) {                              // uniform
-                const u32 t = (u32)p * kCT + tid;
-                const u64 m = __ballot(keep[p] != 0u);
-                const u32 before = (u32)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0)
-                    s_wsum[wave] = (u32)__popcll(m);
-                __syncthreads();
-                u32 wbase = 0u, tot = 0u;
-                for (u32 w = 0; w < kCT / kWave; ++w) {
-                    const u32 v = s_wsum[w];
-                    wbase += w < wave ? v : 0u;
-                    tot += v;
-                }
-                if (t < nt)
-                    s_rk[t] = ((count + wbase + before) << 1) | keep[p];
-                count += tot;
-                __syncthreads();
-            }
+        for (int p = 0; p < kPasses; ++p) {
+            const u64 m = __ballot(keep[p] != 0u);
+            before[p] = (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                s_wsum[(u32)p * (kCT / kWave) + wave] = (u32)__popcll(m);
         }
-        if (tid == 0)
-            s_rk[nt] = count << 1;
+        __syncthreads();
+        u32 count = 0u;
+        {
+            u32 mybase[kPasses];
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                mybase[p] = count;
+                for (u32 w = 0; w < kCT / kWave; ++w) {
+                    const u32 v = s_wsum[(u32)p * (kCT / kWave) + w];
+                    mybase[p] += w < wave ? v : 0u;
+                    count += v;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                const u32 t = (u32)p * kCT + tid;
+                if (t < nt)
+                    s_rk[t] = ((mybase[p] + before[p]) << 1) | keep[p];
+            }
+            if (tid == 0)
+                s_rk[nt] = count << 1;
+        }
+        CSGN_STAMP(7);
         // where the group's survivors go
         if (wave == 0) {
             const u64 excl = lookback(a.status, gid, count);
@@ -544,6 +677,20 @@ __global__ void __launch_bounds__(kCT) k_compact_main(CompactArgs a)
         }
         __syncthreads();
         const u64 prefix = s_prefix;
+        CSGN_STAMP(8);
+        // The next ticket, taken by the last wave while the others write; its descriptor is loaded before
+        // that wave's own stores are issued, so it does not queue behind them.
+        u64 nd = 0ull;
+        if (wave == kCT / kWave - 1u) {
+            u32 ngid = 0u;
+            if (lane == 0)
+                ngid = atomicAdd(reinterpret_cast<u32 *>(a.ctrl + kCtrlTicket), 1u);
+            ngid = __builtin_amdgcn_readfirstlane(ngid);
+            if (lane < 4u && ngid < ngroups)
+                nd = gwords[(u64)ngid * 4u + lane];
+            if (lane == 3u)
+                nd = (nd & 0x1FFFFFFFFull) | ((u64)ngid << 33);
+        }
         if (!large) {
             for (u32 x = tid; x < ncts; x += kCT) {
                 const u32 rel = staged ? s_coff[x] : (u32)(a.off[c0 + x] - tb);
@@ -554,17 +701,27 @@ __global__ void __launch_bounds__(kCT) k_compact_main(CompactArgs a)
         }
         if (gid == ngroups - 1u && tid == 0)
             a.off_out[a.batch] = prefix + count;
+        CSGN_STAMP(9);
         // 6. registers -> their final place
+        {
+            u32 js = j0;
+            asm volatile("" : "+v"(js));
+            UnitPos pos = walk_first(walk, js);
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const u32 j = (u32)i * kCT + ltid;
-            if (j < nunits) {
-                const u32 t = csgn_fastdiv(j, a.dU), k = j - t * U;
-                const u32 rk = s_rk[t];
-                if (rk & 1u)
-                    out[(prefix + (rk >> 1)) * U + k] = reg[i];
+            for (int i = 0; i < R; ++i) {
+                const u32 j = js + (u32)i * kWave;
+                if (j < nunits) {
+                    const u32 rk = s_rk[pos.t];
+                    if (rk & 1u)
+                        out[(prefix + (rk >> 1)) * U + pos.k] = reg[i];
+                }
+                walk_next(walk, pos);
             }
         }
+        CSGN_STAMP(10);
+        __syncthreads();                                          // everybody is done with s_desc and the tables
+        if (wave == kCT / kWave - 1u && lane < 4u)
+            s_desc[lane] = nd;
         __syncthreads();
     }
 }
@@ -768,7 +925,10 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     a.batch = (u32)batch;
     a.dL = (u32)dL;
     a.large_ready = maybe_large ? 1u : 0u;
-    const size_t lds = (size_t)g.capT * 40 + 64;
+    // dev only: just past the scratch block as csgn_compact_scratch_bytes sizes it
+    a.stamps = reinterpret_cast<u64 *>(static_cast<char *>(scratch) +
+                                       make_layout(nullptr, batch, total_terms, make_geom((u32)min(dL, (u64)kCapUnits / 2))).bytes);
+    const size_t lds = main_lds_bytes(g.capT);
     k_compact_main<Unit, kCR><<<(u32)min(ng, (u64)512), kCT, lds, s>>>(a);
     return hipGetLastError();
 }

@@ -12,16 +12,29 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 static_assert(CSGN_COMM_ID_BYTES == sizeof(ncclUniqueId), "id buffer must hold an ncclUniqueId");
 
+// Use of `nccl` against csgn_comm_abort from another thread: ncclCommAbort FREES the
+// communicator, so nobody may be on its way into an RCCL call with the old handle when it runs.
+//   * every RCCL call sits between comm_enter() (refuses once aborted; counts the caller in) and
+//     comm_leave();
+//   * csgn_comm_abort sets the flag and, when nobody is inside, aborts at once; otherwise the LAST caller
+//     to leave does it.  A caller that is stuck inside RCCL (a peer that never connects) is waited for
+//     for kAbortGraceMs and then aborted under its feet -- what ncclCommAbort is for -- which is the one
+//     case left where the handle is freed while in use.
 struct csgn_comm {
-    ncclComm_t nccl = nullptr;
+    ncclComm_t nccl = nullptr;      // guarded by `m` (nullptr once aborted)
+    std::mutex m;
+    std::condition_variable cv;
+    int inside = 0;                 // threads between comm_enter and comm_leave
     hipStream_t stream = nullptr;
     int rank = 0, world = 1, device = 0;
     int *d_flag = nullptr;          // 1-element buffer of the barrier all-reduce
@@ -88,6 +101,46 @@ struct DeviceGuard {
         if (saved >= 0)
             (void)hipSetDevice(saved);
     }
+};
+
+constexpr int kAbortGraceMs = 2000;
+
+// -> the handle to use, or nullptr when the communicator is (being) aborted
+ncclComm_t comm_enter(csgn_comm *c)
+{
+    std::lock_guard<std::mutex> g(c->m);
+    if (c->aborted.load() || !c->nccl)
+        return nullptr;
+    ++c->inside;
+    return c->nccl;
+}
+
+void comm_leave(csgn_comm *c)
+{
+    ncclComm_t victim = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->m);
+        if (--c->inside == 0 && c->aborted.load()) {
+            victim = c->nccl;               // the abort that was asked for while we were inside
+            c->nccl = nullptr;
+        }
+    }
+    if (victim)
+        (void)ncclCommAbort(victim);
+    c->cv.notify_all();
+}
+
+struct CommUse {
+    csgn_comm *c;
+    ncclComm_t nccl;
+    explicit CommUse(csgn_comm *comm) : c(comm), nccl(comm_enter(comm)) {}
+    ~CommUse()
+    {
+        if (nccl)
+            comm_leave(c);
+    }
+    CommUse(const CommUse &) = delete;
+    CommUse &operator=(const CommUse &) = delete;
 };
 
 int finish_comm(csgn_comm *c)
@@ -158,8 +211,9 @@ int gather_plan(uint64_t total, int world, uint64_t *lo, uint64_t *len, int *equ
 template <typename T>
 int gather(csgn_comm *c, const T *d_local, uint64_t total, T *d_all, ncclDataType_t dt, void *stream)
 {
-    REQUIRE(c && c->nccl, "null communicator");
-    REQUIRE(!c->aborted.load(), "communicator was aborted");
+    REQUIRE(c, "null communicator");
+    CommUse use(c);
+    REQUIRE(use.nccl, "communicator was aborted");
     if (total == 0)
         return CSGN_OK;
     REQUIRE(d_all, "d_all is null");
@@ -171,7 +225,7 @@ int gather(csgn_comm *c, const T *d_local, uint64_t total, T *d_all, ncclDataTyp
     REQUIRE(d_local || len[c->rank] == 0, "d_local is null");
     if (equal && !c->force_grouped.load()) {
         // equal shards: the slices of d_all are exactly the all-gather layout
-        NCCL_TRY(ncclAllGather(d_local, d_all, (size_t)len[c->rank], dt, c->nccl, s));
+        NCCL_TRY(ncclAllGather(d_local, d_all, (size_t)len[c->rank], dt, use.nccl, s));
         return CSGN_OK;
     }
     // uneven shards: rank r broadcasts its len[r] elements into d_all[lo[r] ..); one group.  A rank's own
@@ -181,7 +235,7 @@ int gather(csgn_comm *c, const T *d_local, uint64_t total, T *d_all, ncclDataTyp
         if (len[r] == 0)
             continue;
         const ncclResult_t res = ncclBroadcast(r == c->rank ? (const void *)d_local : (const void *)(d_all + lo[r]),
-                                               d_all + lo[r], (size_t)len[r], dt, r, c->nccl, s);
+                                               d_all + lo[r], (size_t)len[r], dt, r, use.nccl, s);
         if (res != ncclSuccess) {
             (void)ncclGroupEnd();
             return fail(CSGN_ERR_HIP, "ncclBroadcast: %s", ncclGetErrorString(res));
@@ -351,20 +405,29 @@ int csgn_comm_destroy(csgn_comm *c)
 int csgn_comm_abort(csgn_comm *c)
 {
     REQUIRE(c, "null communicator");
-    if (c->aborted.exchange(true))
-        return CSGN_OK;                          // once: ncclCommAbort frees the communicator
-    if (c->nccl)
-        NCCL_TRY(ncclCommAbort(c->nccl));
+    ncclComm_t victim = nullptr;
+    {
+        std::unique_lock<std::mutex> g(c->m);
+        if (c->aborted.exchange(true))
+            return CSGN_OK;                      // once: ncclCommAbort frees the communicator
+        // somebody inside an RCCL call: the last one out aborts (comm_leave); give them a moment
+        c->cv.wait_for(g, std::chrono::milliseconds(kAbortGraceMs), [c] { return c->inside == 0; });
+        victim = c->nccl;                        // still set: nobody was inside, or they are stuck in there
+        c->nccl = nullptr;
+    }
+    if (victim)
+        NCCL_TRY(ncclCommAbort(victim));
     return CSGN_OK;
 }
 
 int csgn_comm_check(csgn_comm *c)
 {
-    REQUIRE(c && c->nccl, "null communicator");
-    if (c->aborted.load())
+    REQUIRE(c, "null communicator");
+    CommUse use(c);
+    if (!use.nccl)
         return fail(CSGN_ERR_HIP, "communicator was aborted");
     ncclResult_t async = ncclSuccess;
-    NCCL_TRY(ncclCommGetAsyncError(c->nccl, &async));
+    NCCL_TRY(ncclCommGetAsyncError(use.nccl, &async));
     if (async != ncclSuccess && async != ncclInProgress)
         return fail(CSGN_ERR_HIP, "RCCL asynchronous error: %s", ncclGetErrorString(async));
     return CSGN_OK;
@@ -404,10 +467,13 @@ int csgn_comm_gather_bytes(csgn_comm *c, const uint8_t *d_local, uint64_t total_
 
 int csgn_comm_barrier(csgn_comm *c, void *stream)
 {
-    REQUIRE(c && c->nccl, "null communicator");
-    REQUIRE(!c->aborted.load(), "communicator was aborted");
+    REQUIRE(c, "null communicator");
     hipStream_t s = pick_stream(c, stream);
-    NCCL_TRY(ncclAllReduce(c->d_flag, c->d_flag, 1, ncclInt32, ncclSum, c->nccl, s));
+    {
+        CommUse use(c);
+        REQUIRE(use.nccl, "communicator was aborted");
+        NCCL_TRY(ncclAllReduce(c->d_flag, c->d_flag, 1, ncclInt32, ncclSum, use.nccl, s));
+    }
     HIP_TRY(hipEventRecord(c->done, s));
     // bounded wait: a peer that never arrives must not hold this rank for ever
     const uint64_t limit = c->timeout_ms.load();
@@ -423,7 +489,15 @@ int csgn_comm_barrier(csgn_comm *c, void *stream)
             return fail(CSGN_ERR_HIP, "communicator was aborted while waiting in the barrier");
         if (++spins > 2000) {                    // past the first ~ms: look at the clock and at RCCL, then sleep
             ncclResult_t async = ncclSuccess;
-            if (ncclCommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            bool broken = false;
+            {
+                CommUse use(c);                  // (not across the sleep: an abort must not wait for a poller)
+                if (!use.nccl)
+                    return fail(CSGN_ERR_HIP, "communicator was aborted while waiting in the barrier");
+                broken = ncclCommGetAsyncError(use.nccl, &async) == ncclSuccess && async != ncclSuccess &&
+                         async != ncclInProgress;
+            }
+            if (broken) {
                 (void)csgn_comm_abort(c);
                 return fail(CSGN_ERR_HIP, "RCCL asynchronous error in the barrier: %s", ncclGetErrorString(async));
             }

@@ -29,7 +29,9 @@
  *     of waiting for the missing rank;
  *   - the communicator is created against ONE RCCL: init compares ncclGetVersion() of the library the
  *     process really bound with the NCCL_VERSION_CODE this file was compiled against and refuses a
- *     major or minor difference (csgn_comm_rccl_info reports both and the library's path).
+ *     major difference always and a minor one unless the caller passes CSGN_COMM_ALLOW_MINOR_SKEW
+ *     (csgn_comm_init_*_ex; the plain forms are CSGN_COMM_STRICT).  csgn_comm_rccl_info reports both
+ *     versions and the library's path.
  */
 #ifndef CSGN_SHARD_H
 #define CSGN_SHARD_H
@@ -96,7 +98,12 @@ int csgn_comm_init_rank_ex(const unsigned char h_id[CSGN_COMM_ID_BYTES], int ran
 /* Waits for the communicator's stream (unless aborted), frees it; the caller's current device is unchanged. */
 int csgn_comm_destroy(csgn_comm *comm);
 /* ncclCommAbort: releases every peer blocked in a collective with this communicator's rank missing.
- * Callable from any host thread, any number of times; afterwards only csgn_comm_destroy is valid. */
+ * Callable from any host thread, any number of times; afterwards only csgn_comm_destroy is valid.
+ * ncclCommAbort frees the RCCL handle, so the call is serialised against the owner's use of it: a thread
+ * that is inside csgn_comm_gather_*, csgn_comm_barrier or csgn_comm_check at that moment finishes its
+ * (short, asynchronous) RCCL call first and the last one out performs the abort; later calls fail with
+ * "communicator was aborted".  Only an owner that stays inside RCCL for more than two seconds (blocked
+ * on a peer that never connects) is aborted under its feet -- the case ncclCommAbort exists for. */
 int csgn_comm_abort(csgn_comm *comm);
 /* CSGN_OK while the communicator is healthy; CSGN_ERR_HIP with the RCCL error text once an
  * asynchronous error was recorded (a peer died, a transport failed) or it was aborted. */

@@ -359,3 +359,48 @@ def test_abort_releases_the_communicator_and_later_calls_fail_fast(shard_lib):
     assert shard_lib.csgn_comm_check(comm) != 0
     assert shard_lib.csgn_comm_destroy(comm) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_abort_from_another_thread_while_the_owner_is_in_gather_and_barrier(shard_lib):
+    """ncclCommAbort frees the communicator, so an abort from a peer's thread must not overtake an
+    owner that has passed its `aborted` check and is on its way into RCCL.  The owner thread runs gather +
+    barrier back to back (ctypes releases the GIL inside the calls); the main thread aborts in mid-stream.
+    Every call either succeeds or fails with "aborted" -- no crash, no hang -- and destroy still works."""
+    import threading
+    import time
+    import torch
+    for _ in range(3):
+        comm = _world1_comm(shard_lib)
+        shard_lib.csgn_comm_set_timeout_ms(comm, 5000)
+        local = torch.ones(4096, dtype=torch.int64, device="cuda")
+        out = torch.zeros(4096, dtype=torch.int64, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        seen = {"ok": 0, "failed": 0, "messages": set()}
+        stop = threading.Event()
+
+        def owner():
+            while not stop.is_set():
+                for call in (lambda: shard_lib.csgn_comm_gather_counts(comm, local.data_ptr(), 4096, out.data_ptr(), s),
+                             lambda: shard_lib.csgn_comm_barrier(comm, s),
+                             lambda: shard_lib.csgn_comm_check(comm)):
+                    if call() == 0:
+                        seen["ok"] += 1
+                    else:
+                        seen["failed"] += 1
+                        seen["messages"].add(shard_lib.csgn_shard_last_error().decode())
+                if seen["failed"] > 30:
+                    break
+
+        th = threading.Thread(target=owner)
+        th.start()
+        time.sleep(0.05)
+        assert shard_lib.csgn_comm_abort(comm) == 0
+        time.sleep(0.02)
+        stop.set()
+        th.join(timeout=30)
+        assert not th.is_alive()
+        assert seen["ok"] > 0 and seen["failed"] > 0
+        assert all("aborted" in m for m in seen["messages"]), seen["messages"]
+        assert shard_lib.csgn_comm_destroy(comm) == 0
+        torch.cuda.synchronize()
