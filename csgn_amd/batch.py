@@ -84,18 +84,49 @@ class HipPath:
 
     def mul_ragged(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor,
                    right: torch.Tensor, off_right: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Plan (csgn_mul_plan_ragged, synchronises) + multiply by that plan (csgn_mul_planned)."""
         batch = off_left.numel() - 1
         dl = self.default_len(n_bits)
         off_out = self.empty_words(batch + 1)
         plan = (C.c_uint64 * 4)()
-        check(self.lib.csgn_mul_ragged_plan(batch, _ptr(off_left), _ptr(off_right), _ptr(off_out),
-                                            C.byref(plan), self.stream))
-        total, max_t1, max_t2 = int(plan[0]), int(plan[1]), int(plan[2])
-        out = self.empty_words(max(total * dl, 1))
-        check(self.lib.csgn_mul_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
-                                       _ptr(off_right), _ptr(out), _ptr(off_out), max_t1, max_t2, total,
-                                       self.stream))
+        handle = self.mul_plan()
+        try:
+            check(self.lib.csgn_mul_plan_ragged(handle, batch, _ptr(off_left), _ptr(off_right), _ptr(off_out),
+                                                C.byref(plan), self.stream))
+            total = int(plan[0])
+            out = self.empty_words(max(total * dl, 1))
+            check(self.lib.csgn_mul_planned(handle, n_bits, _ptr(left), _ptr(right), _ptr(out), self.stream))
+        finally:
+            self.lib.csgn_mul_plan_destroy(handle)
         return out[: total * dl], off_out
+
+    def mul_plan(self) -> C.c_void_p:
+        """A csgn_mul_plan object (destroy with lib.csgn_mul_plan_destroy)."""
+        handle = C.c_void_p()
+        check(self.lib.csgn_mul_plan_create(C.byref(handle)))
+        return handle
+
+    def mul_ragged_async(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor, right: torch.Tensor,
+                         off_right: torch.Tensor, capacity_terms: int, out: Optional[torch.Tensor] = None,
+                         off_out: Optional[torch.Tensor] = None, plan: Optional[torch.Tensor] = None):
+        """csgn_mul_ragged_async: nothing is read back.  Returns (out, off_out, d_plan); mul_ragged_async_result(d_plan)
+        fetches the plan numbers and the does-not-fit flag later."""
+        batch = off_left.numel() - 1
+        dl = self.default_len(n_bits)
+        if off_out is None:
+            off_out = self.empty_words(batch + 1)
+        if out is None:
+            out = self.empty_words(max(capacity_terms * dl, 1))
+        if plan is None:
+            plan = self.empty_words(int(self.lib.csgn_mul_ragged_async_plan_words(batch)))
+        check(self.lib.csgn_mul_ragged_async(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right), _ptr(off_right),
+                                             _ptr(out), _ptr(off_out), capacity_terms, _ptr(plan), self.stream))
+        return out, off_out, plan
+
+    def mul_ragged_async_result(self, plan: torch.Tensor):
+        res = (C.c_uint64 * 5)()
+        check(self.lib.csgn_mul_ragged_async_result(_ptr(plan), C.byref(res), self.stream))
+        return [int(x) for x in res]
 
     # -- add ------------------------------------------------------------------------
     def add_uniform(self, n_bits: int, batch: int, t1: int, t2: int, left: torch.Tensor,

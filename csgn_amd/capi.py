@@ -53,6 +53,15 @@ SIGNATURES = {
     "csgn_mul_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, u64, vp]),
     "csgn_mul_ragged_plan": (C.c_int, [u64, vp, vp, vp, C.POINTER(u64 * 4), vp]),
     "csgn_mul_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, u64, u64, vp]),
+    "csgn_mul_plan_create": (C.c_int, [C.POINTER(vp)]),
+    "csgn_mul_plan_destroy": (None, [vp]),
+    "csgn_mul_plan_ragged": (C.c_int, [vp, u64, vp, vp, vp, C.POINTER(u64 * 4), vp]),
+    "csgn_mul_planned": (C.c_int, [vp, u64, vp, vp, vp, vp]),
+    "csgn_mul_plan_validate": (C.c_int, [vp, vp]),
+    "csgn_mul_plan_trust": (C.c_int, [vp, C.c_int]),
+    "csgn_mul_ragged_async_plan_words": (u64, [u64]),
+    "csgn_mul_ragged_async": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
+    "csgn_mul_ragged_async_result": (C.c_int, [vp, C.POINTER(u64 * 5), vp]),
     "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
     "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
     "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64, u64]),
@@ -83,6 +92,7 @@ SIGNATURES = {
     "csgn_circuit_add": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "csgn_circuit_mul": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "csgn_circuit_decrypt": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
+    "csgn_circuit_compact": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "csgn_circuit_permute": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]),
     "csgn_circuit_encrypt": (C.c_int, [vp, u64, vp, vp, vp, vp, u64, C.POINTER(C.c_uint32)]),
     "csgn_circuit_encrypt_mul": (C.c_int, [vp, u64, vp, vp, vp, vp, vp, vp, u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -3,6 +3,7 @@
 
 #include "runtime.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace certFHE {
@@ -24,6 +25,71 @@ CiphertextBatch::CiphertextBatch(const Context &c, uint64_t count, uint64_t term
 }
 
 const uint64_t *CiphertextBatch::deviceValues() const { return payload ? payload->data() : nullptr; }
+
+uint64_t CiphertextBatch::termsOf(uint64_t i) const
+{
+    if (i >= count_)
+        throw std::out_of_range("certFHE::CiphertextBatch::termsOf");
+    return uniform() ? terms_ : offsets_[i + 1] - offsets_[i];
+}
+
+uint64_t CiphertextBatch::maxTerms() const
+{
+    if (uniform())
+        return terms_;
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < count_; ++i)
+        m = std::max(m, offsets_[i + 1] - offsets_[i]);
+    return m;
+}
+
+const uint64_t *CiphertextBatch::deviceOffsets() const
+{
+    if (!d_offsets_) {
+        if (uniform()) {
+            std::vector<uint64_t> off(count_ + 1);
+            for (uint64_t i = 0; i <= count_; ++i)
+                off[i] = i * terms_;
+            d_offsets_ = detail::uploadWords(off.data(), off.size());
+        } else {
+            d_offsets_ = detail::uploadWords(offsets_.data(), offsets_.size());
+        }
+    }
+    return d_offsets_->data();
+}
+
+CiphertextBatch CiphertextBatch::compact() const
+{
+    const uint64_t total = totalTerms(), n = ctx.getN(), dl = ctx.getDefaultN();
+    CiphertextBatch out(ctx, count_, 0);
+    out.terms_ = terms_;
+    if (count_ == 0 || total == 0) {
+        out.offsets_ = offsets_;
+        return out;
+    }
+    out.payload = detail::allocWords(total * dl);                  // room for "nothing cancels"
+    std::shared_ptr<DevicePayload> off_out = detail::allocWords(count_ + 1);
+    const size_t need = csgn_compact_scratch_bytes(n, count_, total);
+    if (need == 0)
+        throw std::runtime_error("certFHE::CiphertextBatch::compact: context not supported by csgn_compact_ragged");
+    std::shared_ptr<DevicePayload> work = detail::allocBytes(need);
+    detail::check(csgn_compact_ragged(n, count_, total, maxTerms(), deviceValues(), deviceOffsets(),
+                                      out.payload->data(), off_out->data(), work->ptr, detail::stream()),
+                  "csgn_compact_ragged");
+    std::vector<uint64_t> off(count_ + 1);
+    detail::downloadBytes(off.data(), off_out->data(), (count_ + 1) * 8);      // synchronises
+    bool same = true;
+    for (uint64_t i = 1; i < count_ && same; ++i)
+        same = off[i + 1] - off[i] == off[1] - off[0];
+    if (same) {                                                    // dense CSR of equal sizes IS the uniform layout
+        out.terms_ = off[1] - off[0];
+    } else {
+        out.terms_ = 0;
+        out.offsets_.swap(off);
+        out.d_offsets_ = off_out;
+    }
+    return out;
+}
 
 namespace {
 // encrypt `bits` under `key` with the keyed device generator (csgn_encrypt_keyed)
@@ -105,6 +171,30 @@ CiphertextBatch CiphertextBatch::pack(const std::vector<Ciphertext> &items)
 CiphertextBatch CiphertextBatch::operator*(const CiphertextBatch &rhs) const
 {
     requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    if (!uniform() || !rhs.uniform()) {                            // CSR kernels: plan, then multiply
+        CiphertextBatch out(ctx, count_, 0);
+        if (count_ == 0)
+            return out;
+        std::shared_ptr<DevicePayload> off_out = detail::allocWords(count_ + 1);
+        uint64_t plan[4] = {0, 0, 0, 0};
+        detail::check(csgn_mul_ragged_plan(count_, deviceOffsets(), rhs.deviceOffsets(), off_out->data(), plan,
+                                           detail::stream()),
+                      "csgn_mul_ragged_plan");
+        out.payload = detail::allocWords(plan[0] * ctx.getDefaultN());
+        if (plan[0])
+            detail::check(csgn_mul_ragged(ctx.getN(), count_, deviceValues(), deviceOffsets(), rhs.deviceValues(),
+                                          rhs.deviceOffsets(), out.payload->data(), off_out->data(), plan[1], plan[2],
+                                          plan[0], detail::stream()),
+                          "csgn_mul_ragged");
+        out.offsets_.resize(count_ + 1);
+        for (uint64_t i = 0, run = 0; i <= count_; ++i) {
+            out.offsets_[i] = run;
+            if (i < count_)
+                run += termsOf(i) * rhs.termsOf(i);
+        }
+        out.d_offsets_ = off_out;
+        return out;
+    }
     CiphertextBatch out(ctx, count_, terms_ * rhs.terms_);
     detail::check(csgn_mul_uniform(ctx.getN(), count_, terms_, rhs.terms_, deviceValues(),
                                    rhs.deviceValues(), out.payload->data(), 0, detail::stream()),
@@ -115,6 +205,25 @@ CiphertextBatch CiphertextBatch::operator*(const CiphertextBatch &rhs) const
 CiphertextBatch CiphertextBatch::operator+(const CiphertextBatch &rhs) const
 {
     requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    if (!uniform() || !rhs.uniform()) {
+        CiphertextBatch out(ctx, count_, 0);
+        if (count_ == 0)
+            return out;
+        const uint64_t total = totalTerms() + rhs.totalTerms();
+        std::shared_ptr<DevicePayload> off_out = detail::allocWords(count_ + 1);
+        out.payload = detail::allocWords(total * ctx.getDefaultN());
+        detail::check(csgn_add_ragged(ctx.getN(), count_, deviceValues(), deviceOffsets(), rhs.deviceValues(),
+                                      rhs.deviceOffsets(), out.payload->data(), off_out->data(), total, detail::stream()),
+                      "csgn_add_ragged");
+        out.offsets_.resize(count_ + 1);
+        for (uint64_t i = 0, run = 0; i <= count_; ++i) {
+            out.offsets_[i] = run;
+            if (i < count_)
+                run += termsOf(i) + rhs.termsOf(i);
+        }
+        out.d_offsets_ = off_out;
+        return out;
+    }
     CiphertextBatch out(ctx, count_, terms_ + rhs.terms_);
     detail::check(csgn_add_uniform(ctx.getN(), count_, terms_, rhs.terms_, deviceValues(),
                                    rhs.deviceValues(), out.payload->data(), detail::stream()),
@@ -138,6 +247,8 @@ std::shared_ptr<DevicePayload> uploadPermutation(const Permutation &p, uint64_t 
 
 CiphertextBatch CiphertextBatch::applyPermutation(const Permutation &permutation) const
 {
+    if (!uniform())
+        throw std::logic_error("certFHE::CiphertextBatch::applyPermutation: uniform batches only");
     CiphertextBatch out(ctx, count_, 1);
     if (count_ == 0)
         return out;
@@ -156,12 +267,17 @@ std::vector<unsigned char> CiphertextBatch::decrypt(const SecretKey &key) const
     if (count_ == 0)
         return bits;
     key.ensureMask();
-    const size_t scratch = (csgn_decrypt_scratch_bytes(count_, count_ * terms_) + 255) & ~(size_t)255;
+    const size_t scratch = (csgn_decrypt_scratch_bytes(count_, totalTerms()) + 255) & ~(size_t)255;
     std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch + count_);
     uint8_t *d_bits = static_cast<uint8_t *>(work->ptr) + scratch;
-    detail::check(csgn_decrypt_uniform(ctx.getN(), count_, terms_, deviceValues(), key.device_mask->data(),
-                                       d_bits, work->ptr, detail::stream()),
-                  "csgn_decrypt_uniform");
+    if (uniform())
+        detail::check(csgn_decrypt_uniform(ctx.getN(), count_, terms_, deviceValues(), key.device_mask->data(),
+                                           d_bits, work->ptr, detail::stream()),
+                      "csgn_decrypt_uniform");
+    else
+        detail::check(csgn_decrypt_ragged(ctx.getN(), count_, totalTerms(), deviceValues(), deviceOffsets(),
+                                          key.device_mask->data(), d_bits, work->ptr, detail::stream()),
+                      "csgn_decrypt_ragged");
     detail::downloadBytes(bits.data(), d_bits, count_);
     return bits;
 }
@@ -192,6 +308,8 @@ std::vector<unsigned char> CiphertextBatch::decryptProduct(const CiphertextBatch
                                                            const SecretKey &key) const
 {
     requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    if (!uniform() || !rhs.uniform())
+        throw std::logic_error("certFHE::CiphertextBatch::decryptProduct: uniform batches only");
     key.ensureMask();
     return fusedDecrypt(*this, rhs, key.device_mask->data(), true);
 }
@@ -199,6 +317,8 @@ std::vector<unsigned char> CiphertextBatch::decryptProduct(const CiphertextBatch
 std::vector<unsigned char> CiphertextBatch::decryptSum(const CiphertextBatch &rhs, const SecretKey &key) const
 {
     requireSameShape(ctx, rhs.ctx, count_, rhs.count_);
+    if (!uniform() || !rhs.uniform())
+        throw std::logic_error("certFHE::CiphertextBatch::decryptSum: uniform batches only");
     key.ensureMask();
     return fusedDecrypt(*this, rhs, key.device_mask->data(), false);
 }
@@ -207,10 +327,12 @@ Ciphertext CiphertextBatch::at(uint64_t i) const
 {
     if (i >= count_)
         throw std::out_of_range("certFHE::CiphertextBatch::at");
-    const uint64_t words = terms_ * ctx.getDefaultN();
+    const uint64_t dl = ctx.getDefaultN(), words = termsOf(i) * dl;
+    const uint64_t first = (uniform() ? i * terms_ : offsets_[i]) * dl;
     std::shared_ptr<DevicePayload> p = detail::allocWords(words);
-    detail::check(csgn_memcpy_d2d(p->data(), deviceValues() + i * words, (size_t)words * 8, detail::stream()),
-                  "csgn_memcpy_d2d");
+    if (words)
+        detail::check(csgn_memcpy_d2d(p->data(), deviceValues() + first, (size_t)words * 8, detail::stream()),
+                      "csgn_memcpy_d2d");
     Ciphertext c;
     c.certFHEcontext = new Context(ctx);
     c.publish(p, words);
@@ -354,6 +476,13 @@ unsigned BatchCircuit::mul(unsigned a, unsigned b)
     return id;
 }
 
+unsigned BatchCircuit::compact(unsigned a)
+{
+    uint32_t id = 0;
+    detail::check(csgn_circuit_compact(handle, a, &id), "csgn_circuit_compact");
+    return id;
+}
+
 unsigned BatchCircuit::permute(unsigned a, const Permutation &p)
 {
     std::shared_ptr<DevicePayload> d = uploadPermutation(p, ctx.getN(), "certFHE::BatchCircuit::permute");
@@ -392,8 +521,21 @@ CiphertextBatch BatchCircuit::value(unsigned id) const
 {
     const uint64_t terms = csgn_circuit_value_terms(handle, id);
     const uint64_t *src = csgn_circuit_value(handle, id);
-    if (!src || terms == 0)
+    if (!src)
         throw std::invalid_argument("certFHE::BatchCircuit::value: no such value or circuit not built");
+    const uint64_t *d_off = csgn_circuit_value_offsets(handle, id);
+    if (terms == 0 && !d_off)
+        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value or circuit not built");
+    if (d_off) {                                    // ragged (static shapes, or data-dependent ones behind compact())
+        CiphertextBatch out(ctx, count_, 0);
+        out.offsets_.resize(count_ + 1);
+        detail::downloadBytes(out.offsets_.data(), d_off, (count_ + 1) * 8);      // synchronises
+        const uint64_t words = out.offsets_.back() * ctx.getDefaultN();
+        out.payload = detail::allocWords(words);
+        if (words)
+            detail::check(csgn_memcpy_d2d(out.payload->ptr, src, (size_t)words * 8, detail::stream()), "csgn_memcpy_d2d");
+        return out;
+    }
     CiphertextBatch out(ctx, count_, terms);
     detail::check(csgn_memcpy_d2d(out.payload->ptr, src, (size_t)(count_ * terms * ctx.getDefaultN() * 8),
                                   detail::stream()),

@@ -24,9 +24,14 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
                                                          const u64 *__restrict__ offR,
                                                          Unit *__restrict__ out,
                                                          const u64 *__restrict__ offOut, u32 batch,
-                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU)
+                                                         u64 unit_base, u64 total_units, u32 U, FastDiv dU,
+                                                         u32 device_end)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
+    // operands whose sizes only the device knows (a circuit value behind a compaction): the launch was
+    // sized for their static bound, the real end of the output is in the offsets
+    if (device_end)
+        total_units = min(total_units, (offL[batch] + offR[batch]) * U);
     __shared__ u64 w_l[kAddWin + 2], w_r[kAddWin + 2];
     __shared__ u32 s_next;
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -197,7 +202,7 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
 }
 
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
-                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s)
+                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s, bool device_end)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch >= (1ull << 32))
@@ -223,10 +228,12 @@ hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         if (wide)                                                                                   \
             k_add_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                              \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU);           \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU,            \
+                device_end ? 1u : 0u);                                                              \
         else                                                                                        \
             k_add_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut, \
-                                                                    (u32)batch, u0, u0 + nu, U, dU); \
+                                                                    (u32)batch, u0, u0 + nu, U, dU, \
+                                                                    device_end ? 1u : 0u);          \
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                   \
     do {                                                         \

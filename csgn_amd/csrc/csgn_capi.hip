@@ -357,8 +357,13 @@ int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
     return CSGN_OK;
 }
 
-int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
-                         uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
+} // extern "C"
+
+namespace {
+
+// the plan step behind csgn_mul_ragged_plan and csgn_mul_plan_ragged; h_head_out (optional): the whole head block
+int plan_ragged(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
+                uint64_t *d_off_out, uint64_t h_plan[4], uint64_t *h_head_out, void *stream)
 {
     REQUIRE(d_off_left && d_off_right && d_off_out && h_plan, "null pointer");
     // The call returns host numbers, so it ends with a stream synchronise anyway; its small device
@@ -394,13 +399,155 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
         e = hipStreamSynchronize(S(stream));
     if (e == hipSuccess) {
         memcpy(h_plan, head.data(), 4 * sizeof(u64));
-        csgn::mul_ragged_remember_plan((const u64 *)d_off_left, (const u64 *)d_off_right, (const u64 *)d_off_out, batch,
-                                       head.data());
+        if (h_head_out)
+            memcpy(h_head_out, head.data(), head.size() * sizeof(u64));
     }
     if (&sc == &local && local.p)
         (void)hipFree(local.p);
     if (e != hipSuccess)
         return hip_fail(e, "csgn_mul_ragged_plan");
+    return CSGN_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
+                         uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
+{
+    return plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, nullptr, stream);
+}
+
+/* ---- the plan as an object of the caller's ---- */
+struct csgn_mul_plan {
+    csgn::MulPlanNotes notes;
+    bool planned = false;
+    bool trust = false;
+    u64 *d_sum = nullptr;        // one device word for the checksum check
+    int device = -1;
+};
+
+int csgn_mul_plan_create(csgn_mul_plan **plan)
+{
+    REQUIRE(plan, "plan is null");
+    *plan = new csgn_mul_plan();
+    return CSGN_OK;
+}
+
+void csgn_mul_plan_destroy(csgn_mul_plan *plan)
+{
+    if (!plan)
+        return;
+    if (plan->d_sum)
+        (void)hipFree(plan->d_sum);
+    delete plan;
+}
+
+int csgn_mul_plan_trust(csgn_mul_plan *plan, int trust)
+{
+    REQUIRE(plan, "plan is null");
+    plan->trust = trust != 0;
+    return CSGN_OK;
+}
+
+int csgn_mul_plan_ragged(csgn_mul_plan *plan, uint64_t batch, const uint64_t *d_off_left,
+                         const uint64_t *d_off_right, uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
+{
+    REQUIRE(plan, "plan is null");
+    plan->planned = false;
+    std::vector<u64> head(csgn::mul_ragged_plan_head_words(), 0);
+    if (int rc = plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, reinterpret_cast<uint64_t *>(head.data()), stream))
+        return rc;
+    csgn::mul_plan_notes_from_head(plan->notes, (const u64 *)d_off_left, (const u64 *)d_off_right,
+                                   (const u64 *)d_off_out, batch, head.data());
+    plan->planned = true;
+    return CSGN_OK;
+}
+
+int csgn_mul_plan_validate(csgn_mul_plan *plan, void *stream)
+{
+    REQUIRE(plan && plan->planned, "no plan: call csgn_mul_plan_ragged first");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (plan->d_sum && plan->device != dev) {
+        (void)hipFree(plan->d_sum);
+        plan->d_sum = nullptr;
+    }
+    if (!plan->d_sum) {
+        HIP_TRY(hipMalloc((void **)&plan->d_sum, 8));
+        plan->device = dev;
+    }
+    const csgn::MulPlanNotes &n = plan->notes;
+    HIP_TRY(csgn::offsets_checksum(n.batch, n.offL, n.offR, n.offOut, plan->d_sum, S(stream)));
+    u64 now = 0;
+    HIP_TRY(hipMemcpyAsync(&now, plan->d_sum, 8, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    if (now != n.checksum)
+        return fail(CSGN_ERR_INVALID, "the offset arrays changed since csgn_mul_plan_ragged: plan again");
+    return CSGN_OK;
+}
+
+int csgn_mul_planned(csgn_mul_plan *plan, uint64_t n_bits, const uint64_t *d_left, const uint64_t *d_right,
+                     uint64_t *d_out, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    REQUIRE(plan && plan->planned, "no plan: call csgn_mul_plan_ragged first");
+    const csgn::MulPlanNotes &n = plan->notes;
+    if (n.batch == 0 || n.max_t1 == 0 || n.max_t2 == 0 || n.total == 0)
+        return CSGN_OK;
+    REQUIRE(d_left && d_right && d_out, "null device pointer");
+    const uint64_t dl = csgn_default_len(n_bits);
+    if (n.max_t1 >= (1ull << 31) || n.max_t2 >= (1ull << 31) || !product_below(n.max_t1, n.max_t2, dl, 1ull << 32))
+        return fail(CSGN_ERR_UNSUPPORTED, "pair product of %llu x %llu terms exceeds 2^32 words",
+                    (unsigned long long)n.max_t1, (unsigned long long)n.max_t2);
+    // host copies of offsets are only used for huge pairs: that is when stale offsets would give wrong words
+    if (n.n != 0 && !plan->trust)
+        if (int rc = csgn_mul_plan_validate(plan, stream))
+            return rc;
+    hipError_t e = csgn::mul_ragged(n_bits, n.batch, (const u64 *)d_left, n.offL, (const u64 *)d_right, n.offR,
+                                    (u64 *)d_out, n.offOut, n.max_t1, n.max_t2, n.total, S(stream), &plan->notes);
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch too large for one call (2^32 pairs / one pair's tile grid)");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+uint64_t csgn_mul_ragged_async_plan_words(uint64_t batch) { return csgn::mul_ragged_async_plan_words(batch); }
+
+int csgn_mul_ragged_async(uint64_t n_bits, uint64_t batch,
+                          const uint64_t *d_left, const uint64_t *d_off_left,
+                          const uint64_t *d_right, const uint64_t *d_off_right,
+                          uint64_t *d_out, uint64_t *d_off_out, uint64_t out_capacity_terms,
+                          uint64_t *d_plan, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (batch == 0)
+        return CSGN_OK;
+    REQUIRE(d_off_left && d_off_right && d_off_out && d_plan, "null pointer");
+    REQUIRE(out_capacity_terms == 0 || (d_left && d_right && d_out), "null device pointer");
+    if (!product_below(out_capacity_terms, csgn_default_len(n_bits), 1, 1ull << 60))
+        return fail(CSGN_ERR_UNSUPPORTED, "output capacity overflows");
+    hipError_t e = csgn::mul_ragged_async(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
+                                          (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
+                                          (u64 *)d_off_out, out_capacity_terms, (u64 *)d_plan, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "ragged batch too large for one call (2^32 pairs)");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+int csgn_mul_ragged_async_result(const uint64_t *d_plan, uint64_t h_result[5], void *stream)
+{
+    REQUIRE(d_plan && h_result, "null pointer");
+    u64 head[12] = {0};                       // [gate: 8 words][plan4]
+    HIP_TRY(hipMemcpyAsync(head, d_plan, sizeof(head), hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    for (int i = 0; i < 4; ++i)
+        h_result[i] = head[8 + i];
+    h_result[4] = head[1];
     return CSGN_OK;
 }
 
@@ -421,7 +568,7 @@ int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     (unsigned long long)max_t1, (unsigned long long)max_t2);
     hipError_t e = csgn::mul_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
                                     (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
-                                    (const u64 *)d_off_out, max_t1, max_t2, total_out_terms, S(stream), true);
+                                    (const u64 *)d_off_out, max_t1, max_t2, total_out_terms, S(stream));
     if (e == hipErrorInvalidValue)
         return fail(CSGN_ERR_UNSUPPORTED, "ragged batch too large for one call (2^32 pairs / one pair's tile grid)");
     HIP_TRY(e);
@@ -782,9 +929,12 @@ struct csgn_circuit {
         size_t csr_offset;           // bytes into block of the batch+1 CSR term offsets (0 = none yet)
         uint64_t total;              // terms over the whole batch
         uint64_t max_terms;
+        // a value behind a compaction: `per`, `total`, `max_terms` are static UPPER BOUNDS (they size the
+        // buffers and the launches), the real CSR offsets are written by the device in every run
+        bool dynamic = false;
     };
     struct Op {
-        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator), 5 fused Enc*Enc (+Dec)
+        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator), 5 fused Enc*Enc (+Dec), 6 compact
         uint32_t a, b, out;
         const void *mask;     // decrypt / encrypt: key mask (u64 words); permute: permutation (u32 entries)
         size_t scratch, bits; // byte offsets (decrypt)
@@ -945,6 +1095,7 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
         if (!product_below(v.total ? v.total : 1, 1, dl, 1ull << 57))
             return fail(CSGN_ERR_UNSUPPORTED, "value of %llu terms: size overflows", (unsigned long long)v.total);
         v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
+        v.dynamic = c->values[a].dynamic || c->values[b].dynamic;
         c->values.push_back(v);
         const uint32_t out = (uint32_t)(c->values.size() - 1);
         (void)ensure_csr(c, a);
@@ -955,6 +1106,8 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
         op.a = a;
         op.b = b;
         op.out = out;
+        if (kind && v.dynamic)                     // the device-side plan of csgn_mul_ragged_async
+            op.scratch = circuit_reserve(c, (size_t)csgn::mul_ragged_async_plan_words(c->batch) * 8);
         c->ops.push_back(op);
         *value = out;
         return CSGN_OK;
@@ -983,6 +1136,38 @@ static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uin
 
 int csgn_circuit_add(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 0, a, b, value); }
 int csgn_circuit_mul(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 1, a, b, value); }
+
+int csgn_circuit_compact(csgn_circuit *c, uint32_t a, uint32_t *value)
+{
+    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
+    REQUIRE(a < c->values.size(), "operand value does not exist");
+    const uint64_t dl = csgn_default_len(c->n_bits);
+    const csgn_circuit::Value &va = c->values[a];
+    REQUIRE(va.total < (1ull << 31) && c->batch < (1ull << 31), "compaction handles fewer than 2^31 ciphertexts and terms");
+    csgn_circuit::Value v;
+    v.terms = 0;
+    v.csr_offset = 0;
+    v.total = va.total;                              // bounds: nothing may cancel
+    v.max_terms = va.max_terms;
+    v.per.resize(c->batch);
+    for (uint64_t i = 0; i < c->batch; ++i)
+        v.per[i] = terms_of(va, i);
+    v.dynamic = true;
+    v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
+    c->values.push_back(v);
+    const uint32_t out = (uint32_t)(c->values.size() - 1);
+    (void)ensure_csr(c, a);
+    (void)ensure_csr(c, out);
+    csgn_circuit::Op op = {};
+    op.kind = 6;
+    op.a = a;
+    op.b = a;
+    op.out = out;
+    op.scratch = circuit_reserve(c, csgn::compact_scratch_bytes(c->n_bits, c->batch, v.total));
+    c->ops.push_back(op);
+    *value = out;
+    return CSGN_OK;
+}
 
 int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id)
 {
@@ -1153,7 +1338,7 @@ int csgn_circuit_build(csgn_circuit *c)
     // CSR offsets of the ragged values (and of uniform values that meet one): known on the host
     for (size_t i = 0; i < c->values.size(); ++i) {
         const csgn_circuit::Value &v = c->values[i];
-        if (!v.csr_offset)
+        if (!v.csr_offset || v.dynamic)                // a dynamic value's offsets are written by the device
             continue;
         std::vector<uint64_t> off(c->batch + 1, 0);
         for (uint64_t k = 0; k < c->batch; ++k)
@@ -1185,6 +1370,15 @@ int csgn_circuit_build(csgn_circuit *c)
             continue;
         }
         const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);
+        if (op.kind == 6) {
+            const csgn_circuit::Value &va = c->values[op.a], &vo = c->values[op.out];
+            e = va.total ? csgn::compact(c->n_bits, c->batch, va.total, va.max_terms, (const u64 *)A,
+                                         reinterpret_cast<const u64 *>(base + va.csr_offset),
+                                         reinterpret_cast<u64 *>(base + vo.offset),
+                                         reinterpret_cast<u64 *>(base + vo.csr_offset), base + op.scratch, s)
+                         : csgn::circuit_zero_words(reinterpret_cast<u64 *>(base + vo.csr_offset), c->batch + 1, s);
+            continue;
+        }
         if (op.kind == 2) {
             const csgn_circuit::Value &va = c->values[op.a];
             if (!va.per.empty())
@@ -1202,12 +1396,16 @@ int csgn_circuit_build(csgn_circuit *c)
             const u64 *oa = reinterpret_cast<const u64 *>(base + va.csr_offset);
             const u64 *ob = reinterpret_cast<const u64 *>(base + vb.csr_offset);
             u64 *oo = reinterpret_cast<u64 *>(base + vo.csr_offset);
-            if (op.kind)
+            if (op.kind && vo.dynamic)
+                // sizes known to the device only: plan kernels + CSR multiply back to back, the static bound sizes the launch
+                e = csgn::mul_ragged_async(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total,
+                                           reinterpret_cast<u64 *>(base + op.scratch), s);
+            else if (op.kind)
                 e = vo.total ? csgn::mul_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, va.max_terms,
-                                                vb.max_terms, vo.total, s, false, va.total + vb.total)
+                                                vb.max_terms, vo.total, s, nullptr, va.total + vb.total)
                              : hipSuccess;
             else
-                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s);
+                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s, vo.dynamic);
         } else if (op.kind == 3) {
             uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
             e = csgn::permute(c->n_bits, c->batch, c->values[op.a].terms, false, (const u64 *)A,

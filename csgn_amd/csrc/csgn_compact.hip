@@ -326,6 +326,7 @@ struct CompactArgs {
     u32 batch;
     u32 dL;
     u32 large_ready;         // the k_cl_* kernels ran: large ciphertexts have a keep decision
+    u32 nt;                  // non-temporal stores of the survivors
     u64 *stamps;             // dev only (CSGN_COMPACT_STAMPS)
 };
 
@@ -712,8 +713,12 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
                 const u32 j = js + (u32)i * kWave;
                 if (j < nunits) {
                     const u32 rk = s_rk[pos.t];
-                    if (rk & 1u)
-                        out[(prefix + (rk >> 1)) * U + pos.k] = reg[i];
+                    if (rk & 1u) {
+                        if (a.nt)
+                            __builtin_nontemporal_store(reg[i], out + (prefix + (rk >> 1)) * U + pos.k);
+                        else
+                            out[(prefix + (rk >> 1)) * U + pos.k] = reg[i];
+                    }
                 }
                 walk_next(walk, pos);
             }
@@ -875,7 +880,7 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     const Geom g = make_geom(U);
     const Layout l = make_layout(scratch, batch, total_terms, g);
     hipError_t e;
-    if ((e = hipMemsetAsync(l.ctrl, 0, l.head_bytes, s)) != hipSuccess)
+    if ((e = zero_words(l.ctrl, l.head_bytes / 8, s)) != hipSuccess)       // (a kernel: see zero_words)
         return e;
     const u32 cblocks = ceil_div_u64(batch, 256);
     k_cg_count<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial);
@@ -925,11 +930,13 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     a.batch = (u32)batch;
     a.dL = (u32)dL;
     a.large_ready = maybe_large ? 1u : 0u;
+    a.nt = tune(TUNE_COMPACT_NT) ? 1u : 0u;
     // dev only: just past the scratch block as csgn_compact_scratch_bytes sizes it
     a.stamps = reinterpret_cast<u64 *>(static_cast<char *>(scratch) +
                                        make_layout(nullptr, batch, total_terms, make_geom((u32)min(dL, (u64)kCapUnits / 2))).bytes);
     const size_t lds = main_lds_bytes(g.capT);
-    k_compact_main<Unit, kCR><<<(u32)min(ng, (u64)512), kCT, lds, s>>>(a);
+    const int grid = tune(TUNE_COMPACT_GRID) > 0 ? tune(TUNE_COMPACT_GRID) : 512;      // two workgroups per CU
+    k_compact_main<Unit, kCR><<<(u32)min(ng, (u64)grid), kCT, lds, s>>>(a);
     return hipGetLastError();
 }
 

@@ -139,6 +139,24 @@ __device__ inline void write_lane64(u64 uniform_value, int lane, u32 &lo, u32 &h
                  : "s"((u32)uniform_value), "s"((u32)(uniform_value >> 32)), "n"(lane));
 }
 
+// Zero-fill as a KERNEL.  Calls that may be captured into a hipGraph (csgn_circuit_*) do not use
+// hipMemsetAsync: with a memset node in the graph, launches on ROCm 7.2 were seen to start before copies
+// enqueued earlier on the same stream had landed (round 4: the inputs of a circuit with a compaction node
+// read as zeros); graphs of kernel nodes only never showed it.
+__global__ void __launch_bounds__(256) k_zero_words(u64 *__restrict__ p, u64 n)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u)
+        p[i] = 0ull;
+}
+inline hipError_t zero_words(u64 *p, u64 n, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const u32 blocks = (u32)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    k_zero_words<<<blocks, 256, 0, s>>>(p, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------- launch helpers
 template <typename T>
 inline bool aligned16(const T *p)

@@ -65,4 +65,6 @@ hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hip
     return hipGetLastError();
 }
 
+hipError_t circuit_zero_words(u64 *p, u64 n, hipStream_t s) { return zero_words(p, n, s); }
+
 } // namespace csgn

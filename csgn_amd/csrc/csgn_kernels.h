@@ -26,22 +26,40 @@ const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2);
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        u64 out_slots, hipStream_t s);
 u64 mul_ragged_plan_scratch_words(u64 batch);
-u64 mul_ragged_plan_head_words();       // [plan4][huge-pair count][records]: what the host copies back
-// remembers (per host thread) what a plan learned, for the csgn_mul_ragged that follows it
-void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch, const u64 *h_head);
+u64 mul_ragged_plan_head_words();       // [plan4][huge-pair count][records][operand terms][offsets checksum]: what the host copies back
+// What a plan learned beyond its four numbers; lives in the caller's csgn_mul_plan object.
+struct MulPlanNotes {
+    const u64 *offL = nullptr, *offR = nullptr, *offOut = nullptr;
+    u64 batch = 0, total = 0, max_t1 = 0, max_t2 = 0;
+    u64 operand_terms = 0;               // left + right terms of the whole batch
+    u64 checksum = 0;                    // of the three offset arrays as planned
+    u32 n = 0;                           // huge-pair records kept (sorted by pair)
+    u64 rec[32][6];                      // {pair, offL, offR, t1, t2, offOut}
+};
+void mul_plan_notes_from_head(MulPlanNotes &notes, const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch,
+                              const u64 *h_head);
+hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s);
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);
-// use_remembered_plan: consult what the calling thread's last mul_ragged_plan wrote down about huge
-// pairs and operand size (only the C entry point does: a circuit's offsets never came from that plan).
-// operand_terms: left + right terms of the whole batch when the caller knows them (a circuit does: its
-// shapes are static), 0 = unknown; sizes the output slices of a large product.
+// notes: what the plan of exactly these offset arrays learned about huge pairs and operand size (nullptr: nothing;
+// a circuit's offsets never came from a plan).  operand_terms: left + right terms of the whole batch when the
+// caller knows them (a circuit does: its shapes are static), 0 = unknown; sizes the output slices of a large product.
+// d_gate: csgn_mul_ragged_async -- {real output terms, ...} left on the DEVICE by the plan kernels; the grid is then
+// sized by total_out_terms (the caller's bound) and only the CSR kernel is used.
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan = false, u64 operand_terms = 0);
+                      u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes = nullptr, u64 operand_terms = 0,
+                      const u64 *d_gate = nullptr);
+// plan + multiply enqueued back to back, nothing read back (csgn_mul_ragged_async); d_plan: mul_ragged_async_plan_words(batch)
+u64 mul_ragged_async_plan_words(u64 batch);
+hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R, const u64 *offR,
+                            u64 *out, u64 *offOut, u64 capacity_terms, u64 *d_plan, hipStream_t s);
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        hipStream_t s);
+// device_end: total_terms_out is only an upper bound (sizes the launch); the real end is read from the offsets
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
-                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s);
+                      const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s,
+                      bool device_end = false);
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
                    const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s);
 // mod-2 compaction (csgn_compact.hip).  max_terms: an upper bound on the terms of any one ciphertext when
@@ -72,6 +90,7 @@ hipError_t decrypt_bitlen(u64 n_bits, u64 d, u64 len, const u64 *v, const u64 *b
                           uint8_t *bit, void *scratch, hipStream_t s);
 hipError_t permute_bitlen(u64 n_bits, u64 len, const u64 *v, const u64 *bitlen, const u32 *perm, u64 *out,
                           void *scratch, hipStream_t s);
+hipError_t circuit_zero_words(u64 *p, u64 n, hipStream_t s);   // zero-fill by a kernel (graph-safe, csgn_device.h)
 hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 

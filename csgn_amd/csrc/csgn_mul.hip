@@ -216,9 +216,14 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          Unit *__restrict__ out,
                                                          const u64 *__restrict__ offOut, u32 batch,
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU,
-                                                         u32 pf_pairs)
+                                                         u32 pf_pairs, const u64 *__restrict__ d_gate)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
+    // csgn_mul_ragged_async: the grid was sized for the caller's bound; the real end of the output is
+    // what the plan kernels left in d_gate[0] (0 when the 1x1 stream kernel takes the batch, or when
+    // the products do not fit)
+    if (d_gate)
+        total_units = min(total_units, d_gate[0] * U);
     __shared__ u64 w_out[kWin + 1], w_l[kWin + 1], w_r[kWin + 2];
     __shared__ u32 s_next;
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -351,8 +356,15 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
 }
 
 constexpr u64 kHugeTerms = 65536;        // a product of this many terms is recorded by the plan (10 MB at N=1247)
-constexpr u64 kHugeRecords = 32;
-constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 2;  // [plan4][huge count][records][left terms, right terms of the batch]
+constexpr u64 kHugeRecords = 32;            // = the rows of MulPlanNotes::rec
+constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 3;  // [plan4][huge count][records][left terms, right terms of the batch][offsets checksum]
+
+// one pair's share of the checksum of the offset arrays
+__device__ inline u64 offsets_mix(u64 b, u64 l, u64 r, u64 o)
+{
+    return csgn_splitmix64(l + CSGN_GOLDEN * (3 * b + 1)) + csgn_splitmix64(r + CSGN_GOLDEN * (3 * b + 2)) +
+           csgn_splitmix64(o + CSGN_GOLDEN * (3 * b + 3));
+}
 
 // Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
 // launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
@@ -454,9 +466,13 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
         huge[1 + kHugeRecords * 6] = offL[batch] - offL[0];
         huge[2 + kHugeRecords * 6] = offR[batch] - offR[0];
     }
+    u64 mix = 0;
+    if (b == batch)
+        mix = offsets_mix(b, offL[b], offR[b], offOut[b]);
     if (b < batch) {
         const u64 o = offOut[b] + partial[b >> 10];
         offOut[b] = o;
+        mix = offsets_mix(b, offL[b], offR[b], o);
         const u64 l0 = offL[b], r0 = offR[b], t1 = offL[b + 1] - l0, t2 = offR[b + 1] - r0;
         if (t1 * t2 >= kHugeTerms) {
             const u64 slot = atomicAdd(reinterpret_cast<unsigned long long *>(huge), 1ull);
@@ -466,6 +482,11 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
             }
         }
     }
+    // checksum of the three offset arrays as planned (csgn_mul_plan_validate recomputes it later)
+    for (int off = 32; off > 0; off >>= 1)
+        mix += (u64)__shfl_down(mix, off, 64);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mix)
+        atomicAdd(reinterpret_cast<unsigned long long *>(huge + 3 + kHugeRecords * 6), mix);
 }
 
 // Block size for the tiled kernel: a multiple of 64 that U divides (so every column a lane
@@ -896,7 +917,7 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
     // d_work: [plan4 (total, max t1, max t2, max t1*t2)][huge count][huge records][one partial per 1024-pair chunk]
     u64 *plan4 = d_work, *huge = d_work + 4, *partial = d_work + kPlanHeadWords;
     const u64 nchunks = (batch + 1023) / 1024;
-    hipError_t e = hipMemsetAsync(d_work, 0, mul_ragged_plan_scratch_words(batch) * 8, s);
+    hipError_t e = zero_words(d_work, mul_ragged_plan_scratch_words(batch), s);       // (a kernel: see zero_words)
     if (e != hipSuccess)
         return e;
     if (nchunks > kMaxBlocks256)
@@ -905,27 +926,16 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
         k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
     k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
     if (batch)
-        k_plan_fix<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge);
+        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge);
     return hipGetLastError();
 }
 
-// What the last csgn_mul_ragged_plan of this host thread learned about the huge pairs of a batch.
-// csgn_mul_ragged consults it when it is called with the SAME offset arrays, batch and plan numbers
-// (the documented sequence: plan, then multiply); with anything else it knows nothing and every pair
-// goes through the CSR kernel.  The offsets must not change between the two calls -- they are the
-// plan's own output.
-struct RememberedPlan {
-    const u64 *offL = nullptr, *offR = nullptr, *offOut = nullptr;
-    u64 batch = 0, total = 0, max_t1 = 0, max_t2 = 0;
-    u64 operand_terms = 0;                       // left + right terms of the whole batch
-    u32 n = 0;                                   // records kept (sorted by pair)
-    u64 rec[kHugeRecords][6];
-};
-static thread_local RememberedPlan t_plan;
-
-void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch, const u64 *h_head)
+// What a plan learned beyond its four numbers: the batch's huge pairs and operand size.  It belongs to
+// an explicit csgn_mul_plan object of the caller (round 4; round 3 kept it in hidden per-thread state
+// matched by array addresses, which a caller that rewrote offsets in place could fool -- ADVICE r3).
+void mul_plan_notes_from_head(MulPlanNotes &r, const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch,
+                              const u64 *h_head)
 {
-    RememberedPlan &r = t_plan;
     r.offL = offL;
     r.offR = offR;
     r.offOut = offOut;
@@ -934,6 +944,7 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
     r.max_t1 = h_head[1];
     r.max_t2 = h_head[2];
     r.operand_terms = h_head[5 + kHugeRecords * 6] + h_head[6 + kHugeRecords * 6];
+    r.checksum = h_head[7 + kHugeRecords * 6];
     const u64 count = h_head[4];
     r.n = (u32)std::min<u64>(count, kHugeRecords);
     for (u32 i = 0; i < r.n; ++i)
@@ -946,9 +957,34 @@ void mul_ragged_remember_plan(const u64 *offL, const u64 *offR, const u64 *offOu
                 std::swap(r.rec[j][k], r.rec[j - 1][k]);
 }
 
+// checksum of the three offset arrays as they are NOW (the same sum k_plan_fix accumulates): one word
+__global__ void __launch_bounds__(256) k_offsets_checksum(u64 batch, const u64 *__restrict__ offL,
+                                                          const u64 *__restrict__ offR,
+                                                          const u64 *__restrict__ offOut, u64 *__restrict__ sum)
+{
+    u64 mine = 0;
+    for (u64 b = (u64)blockIdx.x * 256u + threadIdx.x; b <= batch; b += (u64)gridDim.x * 256u)
+        mine += offsets_mix(b, offL[b], offR[b], offOut[b]);
+    for (int off = 32; off > 0; off >>= 1)
+        mine += (u64)__shfl_down(mine, off, 64);
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(sum), mine);
+}
+
+hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s)
+{
+    hipError_t e = zero_words(d_sum, 1, s);
+    if (e != hipSuccess)
+        return e;
+    const u32 blocks = (u32)std::min<u64>((batch + 256) / 256, 2048);
+    k_offsets_checksum<<<blocks, 256, 0, s>>>(batch, offL, offR, offOut, d_sum);
+    return hipGetLastError();
+}
+
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
-                      u64 total_out_terms, hipStream_t s, bool use_remembered_plan, u64 operand_terms)
+                      u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes, u64 operand_terms,
+                      const u64 *d_gate)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
@@ -959,20 +995,20 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // batch * max_t1 * max_t2): the CSR arrays describe a UNIFORM batch, so no lane has to look
     // anything up -- a million fresh 1x1 pairs given as a ragged batch run k_and_stream (6.2 TB/s
     // instead of 3.4 through the CSR kernel).
-    if (total_out_terms == batch * max_t1 * max_t2 && csgn::tune(TUNE_RAGGED_FLAT) == 0)
+    if (!d_gate && total_out_terms == batch * max_t1 * max_t2 && csgn::tune(TUNE_RAGGED_FLAT) == 0)
         return mul_uniform(n_bits, batch, max_t1, max_t2, L, R, out, 0, s);
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
     // Nearly uniform batches of large products keep the LDS-tiled kernel (one grid sized for the
     // largest shape); anything skewed or small goes through the flat ragged kernel, whose grid
     // is the real output.
-    const bool tiled = csgn::tune(TUNE_RAGGED_FLAT) == 0 && max_t1 * max_t2 * U > 8192 &&
+    const bool tiled = !d_gate && csgn::tune(TUNE_RAGGED_FLAT) == 0 && max_t1 * max_t2 * U > 8192 &&
                        batch * max_t1 * max_t2 <= 2 * total_out_terms;
     // Batches of small pairs with small MAXIMA (rows of at most 256 units, at most 16 rows, mean product at least a
     // quarter of the largest): the tiled kernel with ONE narrow workgroup per pair and 8-row tile -- the pair is the
     // block index, so there is no lookup of any kind, where the CSR kernel below pays the offset window in every turn.
     // A million pairs of 0-5 x 0-5 terms 4.50 -> 5.10 TB/s, 2^18 pairs of 4-12 x 4-12 3.46 -> 4.26 (end of round 3).
-    const bool small_tiled = csgn::tune(TUNE_RAGGED_FLAT) == 0 && wide && max_t2 * U <= 256 && max_t1 <= 16 &&
+    const bool small_tiled = !d_gate && csgn::tune(TUNE_RAGGED_FLAT) == 0 && wide && max_t2 * U <= 256 && max_t1 <= 16 &&
                              batch * max_t1 * max_t2 <= 4 * total_out_terms;
     if (small_tiled) {
         MulArgs a = {};
@@ -1018,8 +1054,9 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const int turn = csgn::tune(TUNE_RAGGED_M);                           // 4 KiB chunks that share one pair bet: 1, 2, 4
     // The plan this thread made for exactly these offset arrays, if any (the documented sequence
     // csgn_mul_ragged_plan -> csgn_mul_ragged): it knows the batch's operand size and its huge pairs.
-    const RememberedPlan &rp = t_plan;
-    const bool remembered = use_remembered_plan && rp.offL == offL && rp.offR == offR && rp.offOut == offOut &&
+    static const MulPlanNotes kNoNotes = MulPlanNotes();
+    const MulPlanNotes &rp = notes ? *notes : kNoNotes;
+    const bool remembered = notes && rp.offL == offL && rp.offR == offR && rp.offOut == offOut &&
                             rp.batch == batch && rp.total == total_out_terms && rp.max_t1 == max_t1 &&
                             rp.max_t2 == max_t2;
     // Large outputs go in slices, each preceded by a touch of the operands its pairs need
@@ -1051,7 +1088,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
         const u64 range_units = range_end - range_begin;
-        const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        const bool touch = !d_gate && wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
@@ -1066,11 +1103,12 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         if (wide)                                                                                   \
             k_mul_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                               \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
-                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs); \
+                reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs,  \
+                d_gate);                                                                            \
         else                                                                                        \
             k_mul_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
                                                                     (u32)batch, u0, u0 + nu, U, dU, \
-                                                                    pf_pairs);                      \
+                                                                    pf_pairs, d_gate);              \
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
@@ -1133,6 +1171,69 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     if (cursor < total_units)
         result = flat_range(cursor, total_units);
     return result;
+}
+
+
+// ------------------------------------------------------------------ csgn_mul_ragged_async
+// d_plan = [gate: real output terms for the CSR kernel | does not fit | all pairs 1x1][mul_ragged_plan's block]
+constexpr u64 kGateWords = 8;
+u64 mul_ragged_async_plan_words(u64 batch) { return kGateWords + mul_ragged_plan_scratch_words(batch); }
+
+__global__ void k_async_gate(const u64 *__restrict__ plan4, u64 batch, u64 capacity_terms, u32 can_stream,
+                             u64 *__restrict__ gate)
+{
+    const u64 total = plan4[0];
+    const bool fits = total <= capacity_terms;
+    const bool ones = can_stream && fits && total == batch && plan4[3] == 1ull;    // every pair 1 x 1: the plain AND stream
+    gate[0] = (fits && !ones) ? total : 0ull;
+    gate[1] = fits ? 0ull : 1ull;
+    gate[2] = ones ? total : 0ull;
+}
+
+// the 1x1 stream of k_and_stream, its length read from the gate (0: some other kernel has the batch)
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_and_stream_gated(const Unit *__restrict__ a, const Unit *__restrict__ b,
+                                                          Unit *__restrict__ o, u32 U, const u64 *__restrict__ gate)
+{
+    const u64 n_units = gate[2] * U;
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n_units)
+        unit_store<Unit, true>(o + i, a[i] & b[i]);
+}
+
+hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R, const u64 *offR,
+                            u64 *out, u64 *offOut, u64 capacity_terms, u64 *d_plan, hipStream_t s)
+{
+    const u64 dL = (n_bits + 63) / 64;
+    if (batch == 0)
+        return hipSuccess;
+    if (batch >= (1ull << 32))
+        return hipErrorInvalidValue;
+    u64 *gate = d_plan, *work = d_plan + kGateWords;
+    hipError_t e = mul_ragged_plan(batch, offL, offR, offOut, work, s);
+    if (e != hipSuccess)
+        return e;
+    // a batch of 1x1 pairs (fresh ciphertexts handed over as CSR): the stream kernel, if the gate says so
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const u32 U = (u32)(wide ? dL / 2 : dL);
+    const u64 stream_blocks = (batch * U + 255) / 256;
+    const bool can_stream = capacity_terms >= batch && stream_blocks <= kMaxBlocks256;
+    k_async_gate<<<1, 1, 0, s>>>(work, batch, capacity_terms, can_stream ? 1u : 0u, gate);
+    if (capacity_terms == 0)
+        return hipGetLastError();
+    if (can_stream) {
+        const u64 blocks = stream_blocks;
+        {
+            if (wide)
+                k_and_stream_gated<unit16><<<(u32)blocks, 256, 0, s>>>(reinterpret_cast<const unit16 *>(L),
+                                                                        reinterpret_cast<const unit16 *>(R),
+                                                                        reinterpret_cast<unit16 *>(out), U, gate);
+            else
+                k_and_stream_gated<unit8><<<(u32)blocks, 256, 0, s>>>(L, R, out, U, gate);
+        }
+    }
+    // everything else: the CSR kernel over the caller's bound, stopping at the real end
+    return mul_ragged(n_bits, batch, L, offL, R, offR, out, offOut, 1, 1, capacity_terms, s, nullptr, 0, gate);
 }
 
 } // namespace csgn

@@ -35,6 +35,8 @@ enum TuneKey {
     TUNE_ENC_COMPACT,    // keyed encrypt: compact LDS tables: -1 = auto (groups of 3+ passes), 0 / 1 forced
     TUNE_SHARED_GPU,     // 1 = other work streams through this GPU's HBM beside the caller: all-pairs multiplies take the LDS-tiled kernel instead of the operand-touch + flat pair, which depends on the memory-side cache (include/csgn_hip.h, "Sharing the GPU")
     TUNE_COMPACT_TAG_BITS, // compaction: hash-tag bits the tables keep, 0 = all (a test narrows them to force the collision path)
+    TUNE_COMPACT_NT,     // compaction: 1 = non-temporal stores of the surviving terms
+    TUNE_COMPACT_GRID,   // compaction: workgroups of the main kernel, 0 = 512 (two per CU)
     TUNE_COUNT
 };
 

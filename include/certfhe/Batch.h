@@ -1,11 +1,13 @@
-// certfhe/Batch.h -- EXTENSION (not in the reference): a uniform batch of ciphertexts that
-// stays in MI355X HBM, for the throughput the value-per-object API cannot reach.
+// certfhe/Batch.h -- EXTENSION (not in the reference): a batch of ciphertexts that stays in
+// MI355X HBM, for the throughput the value-per-object API cannot reach.
 //
-// A CiphertextBatch holds `count` independent ciphertexts of `terms` terms each, laid back to
-// back exactly as csgn_mul_uniform / csgn_add_uniform / csgn_decrypt_uniform expect
-// (include/csgn_hip.h).  Element i of `a * b` is `a[i] * b[i]` of the reference
-// (src/Ciphertext.cpp:231-247), element i of `a + b` is `a[i] + b[i]` (:204-229); one kernel
-// launch does the whole batch.
+// A CiphertextBatch holds `count` independent ciphertexts laid back to back.  UNIFORM (every
+// element `terms` terms): exactly what csgn_mul_uniform / csgn_add_uniform / csgn_decrypt_uniform
+// expect (include/csgn_hip.h).  RAGGED (element i has termsOf(i) terms; what compact() returns when
+// the elements end up with different sizes): CSR term offsets beside the words, the csgn_*_ragged
+// entry points.  Element i of `a * b` is `a[i] * b[i]` of the reference
+// (src/Ciphertext.cpp:231-247), element i of `a + b` is `a[i] + b[i]` (:204-229); one call does
+// the whole batch.
 #ifndef CERTFHE_BATCH_H
 #define CERTFHE_BATCH_H
 
@@ -26,12 +28,16 @@ class BatchCircuit;
 
 class CiphertextBatch {
     friend class BatchCircuit;
-    std::shared_ptr<detail::DevicePayload> payload;   // count * terms * dL words
+    std::shared_ptr<detail::DevicePayload> payload;   // total terms * dL words, element after element
     uint64_t count_;
-    uint64_t terms_;
+    uint64_t terms_;                                   // per element when uniform; 0 when ragged
     Context ctx;
+    std::vector<uint64_t> offsets_;                    // ragged: count+1 term offsets (host copy)
+    mutable std::shared_ptr<detail::DevicePayload> d_offsets_;   // the same in HBM (made on first use, also for a uniform batch)
 
     CiphertextBatch(const Context &c, uint64_t count, uint64_t terms);
+    const uint64_t *deviceOffsets() const;             // CSR offsets in HBM
+    uint64_t maxTerms() const;
 
   public:
     // Encrypts bits[i] under `key` on the device: same distribution as SecretKey::encrypt
@@ -53,15 +59,27 @@ class CiphertextBatch {
     // the permuted first term of each element).
     CiphertextBatch applyPermutation(const Permutation &permutation) const;
 
+    // EXTENSION beyond the reference's semantics (its add never reduces, src/Ciphertext.cpp:107-122):
+    // every element rewritten as its distinct terms of odd multiplicity, in order of first occurrence
+    // (csgn_compact_ragged).  Decryption XORs over terms (src/SecretKey.cpp:139), so identical terms
+    // cancel in pairs: Dec of every element is unchanged under ANY key, while e.g. (a+b)*(a+b) shrinks
+    // from 4 terms to 2 and a long add/multiply chain stops growing by its duplicates.  The words are
+    // no longer the reference's; never part of a parity comparison.  The result is uniform again when
+    // every element kept the same number of terms, ragged otherwise.
+    CiphertextBatch compact() const;
+
     // One plaintext bit per element.
     std::vector<unsigned char> decrypt(const SecretKey &key) const;
-    // Dec(this[i] * rhs[i]) / Dec(this[i] + rhs[i]) without materialising the results.
+    // Dec(this[i] * rhs[i]) / Dec(this[i] + rhs[i]) without materialising the results (uniform batches).
     std::vector<unsigned char> decryptProduct(const CiphertextBatch &rhs, const SecretKey &key) const;
     std::vector<unsigned char> decryptSum(const CiphertextBatch &rhs, const SecretKey &key) const;
 
     Ciphertext at(uint64_t i) const;          // copy of element i as an ordinary Ciphertext
     uint64_t size() const { return count_; }
-    uint64_t terms() const { return terms_; }
+    uint64_t terms() const { return terms_; }  // per element; 0 for a ragged batch (see termsOf)
+    bool uniform() const { return offsets_.empty(); }
+    uint64_t termsOf(uint64_t i) const;        // element i's term count
+    uint64_t totalTerms() const { return uniform() ? count_ * terms_ : offsets_.back(); }
     const Context &context() const { return ctx; }
     const uint64_t *deviceValues() const;
 };
@@ -107,6 +125,10 @@ class BatchCircuit {
     void setPlainPair(unsigned product, const std::vector<unsigned char> &a, const std::vector<unsigned char> &b);
     unsigned add(unsigned a, unsigned b);
     unsigned mul(unsigned a, unsigned b);
+    // EXTENSION (see CiphertextBatch::compact): every element reduced to its distinct terms of odd multiplicity.
+    // The result and everything computed from it have data-dependent sizes: value() returns them as a ragged
+    // batch; permute() does not accept them.
+    unsigned compact(unsigned a);
     unsigned permute(unsigned a, const Permutation &p);   // applyPermutation: ONE term, the permuted first term
     unsigned decrypt(unsigned a, const SecretKey &key);   // returns the id for bits()
     void build();

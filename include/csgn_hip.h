@@ -137,19 +137,54 @@ int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint6
  * small too (one narrow workgroup per pair); a batch whose pairs ALL have the largest shape runs
  * the uniform kernels; skewed or small ones a flat kernel whose grid is the real output (a workgroup
  * finds its first pair by a 64-ary search over d_off_out and stages the offsets it needs in LDS).
- * Called right after csgn_mul_ragged_plan on the same host thread with the same offset arrays -- the
- * documented sequence -- it also knows from the plan the batch's HUGE pairs (24 MB of output and more,
- * up to 32 of them), each of which gets a uniform launch of its own, and the batch's operand size,
- * which sets the size of the slices a product above 1 GiB is written in (each slice's operands are
- * read once ahead of it); the offsets must therefore not change between the two calls, and a thread
- * that writes NEW offsets into the same three arrays has to plan again before it multiplies (the match is
- * by array addresses, batch and the plan's four numbers).  Without a matching plan the same words come
- * out of the general kernel in 1 GiB slices. */
+ * A pure function of its arguments: it keeps no state from the plan call (round 3 did, per host thread;
+ * what a plan knows beyond its four numbers now lives in a csgn_mul_plan object, below).  Through this
+ * entry a skewed batch's huge pairs take the CSR kernel like everything else and a product above 1 GiB is
+ * written in 1 GiB slices. */
 int csgn_mul_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_left, const uint64_t *d_off_left,
                     const uint64_t *d_right, const uint64_t *d_off_right,
                     uint64_t *d_out, const uint64_t *d_off_out,
                     uint64_t max_t1, uint64_t max_t2, uint64_t total_out_terms, void *stream);
+
+/* The same two steps with the plan kept in an OBJECT of the caller's (round 4; supersedes the round-3 rule that
+ * csgn_mul_ragged found the last plan of the calling thread by array addresses).  csgn_mul_plan_ragged is
+ * csgn_mul_ragged_plan and additionally notes in *plan the batch's HUGE pairs (24 MB of output and more, up to
+ * 32 of them), its operand size and a checksum of the three offset arrays; csgn_mul_planned multiplies by that
+ * plan: a huge pair gets a uniform launch of its own when such pairs are most of the batch, a product above
+ * 1 GiB is written in slices sized from the operand size.  The offset arrays belong to the plan until the next
+ * csgn_mul_plan_ragged on it.  Because a huge pair's launch uses host copies of its offsets, csgn_mul_planned
+ * first CHECKS the offset arrays against the plan's checksum whenever it is about to use such records (one
+ * small kernel and a stream synchronise) and returns CSGN_ERR_INVALID if they changed;
+ * csgn_mul_plan_trust(plan, 1) turns that check off for a caller who guarantees it.
+ * csgn_mul_plan_validate does the check on demand.  A plan is used by one host thread at a time. */
+typedef struct csgn_mul_plan csgn_mul_plan;
+int csgn_mul_plan_create(csgn_mul_plan **plan);
+void csgn_mul_plan_destroy(csgn_mul_plan *plan);
+int csgn_mul_plan_ragged(csgn_mul_plan *plan, uint64_t batch, const uint64_t *d_off_left,
+                         const uint64_t *d_off_right, uint64_t *d_off_out, uint64_t h_plan[4], void *stream);
+int csgn_mul_planned(csgn_mul_plan *plan, uint64_t n_bits, const uint64_t *d_left, const uint64_t *d_right,
+                     uint64_t *d_out, void *stream);
+int csgn_mul_plan_validate(csgn_mul_plan *plan, void *stream);     /* CSGN_ERR_INVALID: offsets changed since the plan */
+int csgn_mul_plan_trust(csgn_mul_plan *plan, int trust);
+
+/* Ragged multiply with NO host round trip: the plan kernels and the multiply are enqueued back to back and
+ * nothing is read back.  d_off_out[batch+1] is written as by csgn_mul_ragged_plan.  The caller gives the room:
+ * out_capacity_terms = terms d_out can hold (an upper bound on the sum of t1_b*t2_b, e.g. from static shapes);
+ * the launch is sized for it and stops at the real end, which only the device knows.  If the products do
+ * not fit, NOTHING is written and the result's fifth word says so.  d_plan: device block of
+ * csgn_mul_ragged_async_plan_words(batch) words, valid until the stream has passed the call.
+ * Kernels: the CSR kernel, or -- decided on the device -- the plain AND stream when every pair is 1 x 1; the
+ * LDS-tiled and per-huge-pair forms need shapes on the host and belong to csgn_mul_planned.
+ * csgn_mul_ragged_async_result (optional, synchronises): h_result[0..3] as h_plan of csgn_mul_ragged_plan,
+ * h_result[4] = 1 if the products did not fit. */
+uint64_t csgn_mul_ragged_async_plan_words(uint64_t batch);
+int csgn_mul_ragged_async(uint64_t n_bits, uint64_t batch,
+                          const uint64_t *d_left, const uint64_t *d_off_left,
+                          const uint64_t *d_right, const uint64_t *d_off_right,
+                          uint64_t *d_out, uint64_t *d_off_out, uint64_t out_capacity_terms,
+                          uint64_t *d_plan, void *stream);
+int csgn_mul_ragged_async_result(const uint64_t *d_plan, uint64_t h_result[5], void *stream);
 
 /* ----------------------------------------------------------------------- add ---- */
 
@@ -365,6 +400,14 @@ int csgn_circuit_mul(csgn_circuit *circuit, uint32_t a, uint32_t b, uint32_t *va
 /* Decrypt value `a` under the key whose dL-word mask is d_mask (must stay valid); *bits_id
  * names a `batch`-byte result buffer. */
 int csgn_circuit_decrypt(csgn_circuit *circuit, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id);
+/* EXTENSION (as csgn_compact_ragged, never on a parity path): value = a with every element reduced to its
+ * distinct terms of odd multiplicity -- the one node that bounds the growth of a long add/multiply chain.
+ * Its sizes are data: the result (and everything computed from it) is a DYNAMIC ragged value -- the shapes the
+ * circuit knows for it are upper bounds (they size buffers and launches: csgn_circuit_value_total_terms), the
+ * real CSR offsets are written by the device in every run (csgn_circuit_value_offsets; element batch = the
+ * real total).  add / mul / decrypt / compact accept dynamic values (mul through the kernels of
+ * csgn_mul_ragged_async); permute does not. */
+int csgn_circuit_compact(csgn_circuit *circuit, uint32_t a, uint32_t *value);
 /* Ciphertext::applyPermutation on every element of value `a` (d_perm: N uint32 entries, must stay
  * valid): as in the reference the result is ONE term, the permuted first term. */
 int csgn_circuit_permute(csgn_circuit *circuit, uint32_t a, const uint32_t *d_perm, uint32_t *value);

@@ -535,6 +535,53 @@ static int cmd_batch(int count)
     std::vector<unsigned char> pb = packed.decrypt(sk);
     for (int i = 0; i < 5; ++i)
         EXPECT(pb[i] == bits[2][i]);
+    // compact() (extension): identical terms cancel in pairs, Dec is unchanged
+    {
+        CiphertextBatch s2 = in[3] + in[4];                       // 2 terms per element
+        CiphertextBatch sq = s2 * s2;                             // a*a + a*b + b*a + b*b
+        CiphertextBatch cq = sq.compact();                        // a*b and b*a cancel: 2 terms, uniform again
+        EXPECT(sq.terms() == 4 && cq.uniform() && cq.terms() == 2 && cq.totalTerms() == 2 * (uint64_t)count);
+        EXPECT(cq.decrypt(sk) == sq.decrypt(sk));
+        Ciphertext c0 = cq.at(0), a0 = in[3].at(0), b0 = in[4].at(0);
+        for (uint64_t w = 0; w < 20; ++w)                         // a & a = a first, then b & b = b
+            EXPECT(c0.getValues()[w] == a0.getValues()[w] && c0.getValues()[20 + w] == b0.getValues()[w]);
+        CiphertextBatch zero = (in[3] + in[3]).compact();         // x + x vanishes
+        EXPECT(zero.uniform() && zero.terms() == 0 && zero.totalTerms() == 0);
+        std::vector<unsigned char> zb = zero.decrypt(sk);
+        for (int i = 0; i < count; ++i)
+            EXPECT(zb[i] == 0);
+        // a ragged result: element i of `mix` is x + x (i even) or x + y (i odd)
+        std::vector<Ciphertext> mixed;
+        const int m = count < 9 ? count : 9;
+        for (int i = 0; i < m; ++i)
+            mixed.push_back(in[5].at(i) + (i % 2 ? in[6].at(i) : in[5].at(i)));
+        CiphertextBatch mix = CiphertextBatch::pack(mixed).compact();
+        if (m > 1) {
+            EXPECT(!mix.uniform() && mix.terms() == 0 && mix.size() == (uint64_t)m);
+            for (int i = 0; i < m; ++i)
+                EXPECT(mix.termsOf(i) == (i % 2 ? 2u : 0u));
+            std::vector<unsigned char> mb = mix.decrypt(sk);
+            for (int i = 0; i < m; ++i)
+                EXPECT(mb[i] == (i % 2 ? (bits[5][i] ^ bits[6][i]) : 0));
+            // ragged arithmetic: (mix + y) * z against the clear evaluation; compact() of a ragged batch
+            std::vector<Ciphertext> ys, zs;
+            for (int i = 0; i < m; ++i) {
+                ys.push_back(in[7].at(i));
+                zs.push_back(in[8].at(i) + in[9].at(i));
+            }
+            CiphertextBatch y = CiphertextBatch::pack(ys), z = CiphertextBatch::pack(zs);
+            CiphertextBatch r = (mix + y) * z;
+            EXPECT(!r.uniform());
+            std::vector<unsigned char> rb = r.decrypt(sk), rc = r.compact().decrypt(sk);
+            for (int i = 0; i < m; ++i) {
+                const unsigned char want = (unsigned char)(((i % 2 ? (bits[5][i] ^ bits[6][i]) : 0) ^ bits[7][i]) &
+                                                           (bits[8][i] ^ bits[9][i]));
+                EXPECT(r.termsOf(i) == (mix.termsOf(i) + 1) * 2);
+                EXPECT(rb[i] == want && rc[i] == want);
+                EXPECT(r.at(i).getLen() == r.termsOf(i) * 20);
+            }
+        }
+    }
     printf("batch ok count=%d\n", count);
     return 0;
 }

@@ -4,6 +4,7 @@ the committed golden vectors (tests/golden/, generated from the genuine referenc
 
 Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference.
 """
+import ctypes as C
 import json
 import os
 
@@ -1844,6 +1845,94 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 7), (129, 3, 33)])
+def test_circuit_with_compaction_bounds_growth(hip, oracle, n, d, batch):
+    """csgn_circuit_compact: x <- compact((x + a_k) * (x + a_k)) four times over, then + and Dec, as ONE
+    hipGraph.  Uncompacted the chain would square its size every level (2 -> 9 -> 100 -> ... terms); compacted,
+    (x + a)^2 = x^2 + a (the cross terms cancel, u & u = u) never grows past the distinct terms.  Every value
+    behind the first compaction is DYNAMIC: the device writes its CSR offsets, multiplies run through the
+    csgn_mul_ragged_async kernels with launches sized by static bounds.  Offsets, words and bits equal the same
+    chain done on the host with the oracle (mul / add / compact / decrypt), on two input sets."""
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 5)
+    dmask = hip.upload(hip.key_mask(n, key))
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    levels = 3
+    ins = [new(lib.csgn_circuit_input, 1) for _ in range(levels + 2)]
+    x = ins[0]
+    stages = []
+    for k in range(1, levels + 1):
+        s_ = new(lib.csgn_circuit_add, x, ins[k])
+        x = new(lib.csgn_circuit_compact, new(lib.csgn_circuit_mul, s_, s_))
+        stages.append(x)
+    y = new(lib.csgn_circuit_add, x, ins[levels + 1])
+    bits_x = new(lib.csgn_circuit_decrypt, x, dmask.data_ptr())
+    bits_y = new(lib.csgn_circuit_decrypt, y, dmask.data_ptr())
+    with pytest.raises(Exception):
+        new(lib.csgn_circuit_permute, x, dmask.data_ptr())        # no permutation of a ragged value
+    check(lib.csgn_circuit_build(c))
+    assert lib.csgn_circuit_value_terms(c, x) == 0                # ragged; the known sizes are bounds
+    for rnd in range(2):
+        plain = np.random.default_rng(rnd + batch).integers(0, 2, size=(levels + 2, batch)).astype(np.uint8)
+        fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), hip.upload(key), dmask, seed=rnd + 3)
+        hf = hip.download(fresh).reshape(levels + 2, batch, dl)
+        if rnd == 1:                                              # some equal inputs: a + a vanishes inside the chain
+            hf[1, ::3] = hf[0, ::3]
+            fresh = hip.upload(hf.reshape(-1))
+        for i in range(levels + 2):
+            check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, ins[i]), fresh[i * batch * dl:].data_ptr(), batch * dl * 8, hip.stream))
+        check(lib.csgn_circuit_run(c, hip.stream))
+        torch.cuda.synchronize()
+        # the same chain on the host
+        want = [hf[0, b].copy() for b in range(batch)]
+        for k in range(1, levels + 1):
+            for b in range(batch):
+                s_h, _ = oracle.add(want[b], hf[k, b])
+                p_h, _ = oracle.mul(n, s_h, s_h) if s_h.size else (s_h, None)
+                want[b] = oracle.compact(n, p_h)
+        def fetch(v):
+            bound = int(lib.csgn_circuit_value_total_terms(c, v))
+            off = hip.empty_words(batch + 1)
+            check(lib.csgn_memcpy_d2d(off.data_ptr(), lib.csgn_circuit_value_offsets(c, v), (batch + 1) * 8, hip.stream))
+            w = hip.empty_words(max(1, bound * dl))
+            check(lib.csgn_memcpy_d2d(w.data_ptr(), lib.csgn_circuit_value(c, v), bound * dl * 8, hip.stream))
+            return hip.download(off), hip.download(w), bound
+        off, words_, bound = fetch(x)
+        assert int(off[-1]) <= bound and int(off[-1]) == sum(w.size // dl for w in want)
+        for b in range(batch):
+            assert np.array_equal(words_[int(off[b]) * dl:int(off[b + 1]) * dl], want[b]), (rnd, b)
+            assert want[b].size // dl <= levels + 1               # the chain does not grow: at most the distinct inputs
+        offy, wy, _ = fetch(y)
+        for b in range(0, batch, max(1, batch // 7)):
+            wb, _ = oracle.add(want[b], hf[levels + 1, b])
+            assert np.array_equal(wy[int(offy[b]) * dl:int(offy[b + 1]) * dl], wb)
+        bx = hip.empty_words(1).new_empty(batch, dtype=torch.uint8)
+        check(lib.csgn_memcpy_d2d(bx.data_ptr(), lib.csgn_circuit_bits(c, bits_x), batch, hip.stream))
+        by = torch.empty_like(bx)
+        check(lib.csgn_memcpy_d2d(by.data_ptr(), lib.csgn_circuit_bits(c, bits_y), batch, hip.stream))
+        torch.cuda.synchronize()
+        clear = plain[0].copy()
+        hfb = plain.copy()
+        if rnd == 1:
+            hfb[1, ::3] = hfb[0, ::3]
+        clear = hfb[0].copy()
+        for k in range(1, levels + 1):
+            clear ^= hfb[k]                                       # Dec((x + a)^2) = Dec(x + a)
+        assert np.array_equal(bx.cpu().numpy(), clear)
+        assert np.array_equal(by.cpu().numpy(), clear ^ hfb[levels + 1])
+        for b in range(0, batch, max(1, batch // 5)):
+            assert oracle.decrypt_canonical(n, key, want[b]) == clear[b]
+    lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("n,d,batch", [(1247, 16, 65536), (1247, 16, 1000), (4096, 32, 77), (65, 3, 5000)])
 def test_circuit_graph_fresh_enc_mul_add_dec_as_one_graph(hip, oracle, n, d, batch):
     """BASELINE configs 2 / 4 end to end as ONE hipGraph: two encrypt nodes (keyed generator writing
@@ -2253,12 +2342,12 @@ def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
 
 
 def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
-    """csgn_mul_ragged right after csgn_mul_ragged_plan: pairs of 24 MB of output and more (written down by
+    """csgn_mul_planned by a csgn_mul_plan object: pairs of 24 MB of output and more (written down by
     the plan) get uniform launches of their own, the CSR kernel runs on the stretches between them.  Two
     huge pairs (400x400 and 512x330 terms, N=1247), one at the very start, among 3000 small and empty
     ones, and a third at the very end; identical to the CSR kernel alone (knob ragged_flat = 1), huge and
-    neighbouring pairs equal the oracle.  A multiply whose offsets were NOT planned on this thread (a
-    copy of the offset arrays) must give the same words through the CSR kernel."""
+    neighbouring pairs equal the oracle.  The plan-less csgn_mul_ragged (a pure function of its arguments)
+    must give the same words through the CSR kernel."""
     import torch
     n, dl = 1247, 20
     rng = np.random.default_rng(77)
@@ -2277,7 +2366,7 @@ def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)             # everything through the CSR kernel
     assert torch.equal(out, ref) and torch.equal(off, ref_off)
     knobs.unset("ragged_flat")
-    # unplanned offsets (copies): nothing is remembered for them, same words
+    # the plan-less entry: same words
     from csgn_amd.capi import check
     mo = hip.download(off)
     dOL2, dOR2, off2 = dOL.clone(), dOR.clone(), off.clone()
@@ -2290,6 +2379,100 @@ def test_ragged_huge_pairs_take_uniform_launches(hip, oracle, knobs):
         if t1s[b] and t2s[b]:
             want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
             assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
+def test_stale_plan_is_detected_not_multiplied(hip, oracle):
+    from csgn_amd.capi import check
+    """ADVICE r3 / VERDICT r3 #9: a plan remembers host copies of its huge pairs' offsets.  A caller that rewrites
+    the offset arrays IN PLACE with the same totals (pairs shuffled) and multiplies by the old plan used to get
+    silently wrong words; csgn_mul_planned now checks the arrays against the plan's checksum whenever it is
+    about to use such records and returns CSGN_ERR_INVALID.  Planning again gives the right products."""
+    import torch
+    from csgn_amd import capi
+    n, dl = 1247, 20
+    t1s = np.array([400, 3, 2, 512, 1, 4], dtype=np.int64)
+    t2s = np.array([400, 2, 5, 330, 1, 3], dtype=np.int64)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    L = hip.synth_fill(71, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(72, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    off_out = hip.empty_words(len(t1s) + 1)
+    plan = (C.c_uint64 * 4)()
+    handle = hip.mul_plan()
+    try:
+        check(hip.lib.csgn_mul_plan_ragged(handle, len(t1s), dOL.data_ptr(), dOR.data_ptr(), off_out.data_ptr(),
+                                           C.byref(plan), hip.stream))
+        total = int(plan[0])
+        out = hip.empty_words(total * dl)
+        assert hip.lib.csgn_mul_plan_validate(handle, hip.stream) == 0
+        check(hip.lib.csgn_mul_planned(handle, n, L.data_ptr(), R.data_ptr(), out.data_ptr(), hip.stream))
+        first = hip.download(out)
+        # shuffle the pairs in place: same multiset of shapes, same totals, same array addresses
+        perm = [3, 1, 2, 0, 4, 5]
+        dOL.copy_(hip.upload(csr(t1s[perm].tolist())))
+        dOR.copy_(hip.upload(csr(t2s[perm].tolist())))
+        torch.cuda.synchronize()
+        assert hip.lib.csgn_mul_plan_validate(handle, hip.stream) == capi.CSGN_ERR_INVALID
+        assert hip.lib.csgn_mul_planned(handle, n, L.data_ptr(), R.data_ptr(), out.data_ptr(), hip.stream) == capi.CSGN_ERR_INVALID
+        assert b"changed since" in hip.lib.csgn_last_error()
+        # plan again: right words for the shuffled batch
+        check(hip.lib.csgn_mul_plan_ragged(handle, len(t1s), dOL.data_ptr(), dOR.data_ptr(), off_out.data_ptr(),
+                                           C.byref(plan), hip.stream))
+        assert int(plan[0]) == total
+        check(hip.lib.csgn_mul_planned(handle, n, L.data_ptr(), R.data_ptr(), out.data_ptr(), hip.stream))
+        got, mo = hip.download(out), hip.download(off_out)
+        hl, hr = hip.download(L), hip.download(R)
+        ol, orr = csr(t1s[perm].tolist()), csr(t2s[perm].tolist())
+        for b in range(len(perm)):
+            want, _ = oracle.mul(n, hl[int(ol[b]) * dl:int(ol[b + 1]) * dl], hr[int(orr[b]) * dl:int(orr[b + 1]) * dl])
+            assert np.array_equal(got[int(mo[b]) * dl:int(mo[b + 1]) * dl], want), b
+        assert not np.array_equal(got, first)
+        # trust: the check is skipped (the caller's promise); a plan that was never made is refused
+        check(hip.lib.csgn_mul_plan_trust(handle, 1))
+        check(hip.lib.csgn_mul_planned(handle, n, L.data_ptr(), R.data_ptr(), out.data_ptr(), hip.stream))
+        fresh = hip.mul_plan()
+        assert hip.lib.csgn_mul_planned(fresh, n, L.data_ptr(), R.data_ptr(), out.data_ptr(), hip.stream) == capi.CSGN_ERR_INVALID
+        hip.lib.csgn_mul_plan_destroy(fresh)
+    finally:
+        hip.lib.csgn_mul_plan_destroy(handle)
+
+
+@pytest.mark.parametrize("n", [1247, 129])
+def test_mul_ragged_async_matches_the_planned_multiply(hip, oracle, n):
+    """csgn_mul_ragged_async: plan kernels + multiply enqueued back to back, nothing read back, the launch sized
+    by the caller's bound.  Same words and offsets as plan + multiply for skewed batches, empty pairs, a batch of
+    1x1 pairs (the device picks the AND stream) and a bound far above the real size; a bound that is too small
+    writes nothing and says so."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n)
+    cases = [
+        (rng.integers(0, 9, size=700), rng.integers(0, 9, size=700)),
+        (np.array([300] + [1] * 500 + [0, 0, 7]), np.array([250] + [1] * 500 + [3, 0, 2])),
+        (np.ones(5000, dtype=np.int64), np.ones(5000, dtype=np.int64)),
+        (np.array([0, 0, 0]), np.array([4, 0, 1])),
+    ]
+    for k, (t1s, t2s) in enumerate(cases):
+        offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+        L = hip.synth_fill(81 + k, n, 0, max(1, int(offL[-1])) * dl)
+        R = hip.synth_fill(91 + k, n, 0, max(1, int(offR[-1])) * dl)
+        dOL, dOR = hip.upload(offL), hip.upload(offR)
+        ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+        total = int((t1s * t2s).sum())
+        for cap in (total, total + 1, 3 * total + 1000):
+            out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, cap)
+            res = hip.mul_ragged_async_result(plan)
+            assert res[0] == total and res[4] == 0, (k, cap, res)
+            assert res[1] == int(t1s.max()) and res[2] == int(t2s.max())
+            assert torch.equal(off, ref_off)
+            assert torch.equal(out[:total * dl], ref[:total * dl]), (k, cap)
+        if total > 1:
+            guard = hip.empty_words(total * dl)
+            guard.fill_(0x5A5A5A5A)
+            out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total - 1, out=guard)
+            res = hip.mul_ragged_async_result(plan)
+            assert res[0] == total and res[4] == 1
+            assert bool((guard == 0x5A5A5A5A).all())          # nothing was written
 
 
 def test_ragged_forms_fuzz(hip, oracle, knobs):

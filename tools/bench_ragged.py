@@ -47,6 +47,17 @@ for name,t1s,t2s in [
     # offsets taken in turn (> 256 MB together for the skewed batches), per setting
     out, off_out = hip.mul_ragged(n,L,dL_,R,dR_)
     mt1, mt2, tot = int(max(t1s)), int(max(t2s)), outw // dl
+    # csgn_mul_ragged_async: plan kernels + multiply enqueued back to back, nothing read back (buffers preallocated,
+    # the bound = the real size); against the kernel-only figure below this is what the host round trip used to cost
+    aplan = hip.empty_words(int(hip.lib.csgn_mul_ragged_async_plan_words(len(t1s))))
+    t=timed(lambda: hip.mul_ragged_async(n,L,dL_,R,dR_,tot,out=out,off_out=off_out,plan=aplan))
+    assert hip.mul_ragged_async_result(aplan)[4] == 0
+    print(f"mul_ragged_async {name:<26} {t*1e3:8.3f} ms  {alg/t/1e9:8.1f} GB/s ({100*alg/t/8e12:4.1f}% of peak)  [plan kernels + multiply, no host round trip, warm operands]", flush=True)
+    # the plan object the kernel-only runs multiply by (trusted: the offsets do not change here)
+    import ctypes as C
+    handle = hip.mul_plan(); hplan = (C.c_uint64 * 4)()
+    check(hip.lib.csgn_mul_plan_ragged(handle, len(t1s), dL_.data_ptr(), dR_.data_ptr(), off_out.data_ptr(), C.byref(hplan), hip.stream))
+    check(hip.lib.csgn_mul_plan_trust(handle, 1))
     sets=[(L,R)]+[(hip.synth_fill(10+k,n,0,int(offL[-1])*dl), hip.synth_fill(20+k,n,0,int(offR[-1])*dl)) for k in range(2)]
     row=[]
     for label,env in VARIANTS:
@@ -57,8 +68,7 @@ for name,t1s,t2s in [
         turn=[0]
         def one():
             Lk,Rk=sets[turn[0]%NSETS[0]]; turn[0]+=1
-            check(hip.lib.csgn_mul_ragged(n,len(t1s),Lk.data_ptr(),dL_.data_ptr(),Rk.data_ptr(),dR_.data_ptr(),
-                                          out.data_ptr(),off_out.data_ptr(),mt1,mt2,tot,hip.stream))
+            check(hip.lib.csgn_mul_planned(handle,n,Lk.data_ptr(),Rk.data_ptr(),out.data_ptr(),hip.stream))
         if env.get("PRETOUCH"):
             ts=[]
             for _ in range(9):
@@ -72,6 +82,14 @@ for name,t1s,t2s in [
         row.append(f"{label}: {alg/t/1e9:6.0f}")
     capi.reset_tuning()
     print(f"   kernel only, GB/s   " + "  ".join(row), flush=True)
+    # the same through csgn_mul_ragged_async (cold operand sets in turn)
+    turn=[0]
+    def one_async():
+        Lk,Rk=sets[turn[0]%3]; turn[0]+=1
+        hip.mul_ragged_async(n,Lk,dL_,Rk,dR_,tot,out=out,off_out=off_out,plan=aplan)
+    t=timed(one_async, rounds=9)
+    print(f"   csgn_mul_ragged_async, cold operands: {alg/t/1e9:6.0f} GB/s ({t*1e6:7.1f} us)", flush=True)
+    hip.lib.csgn_mul_plan_destroy(handle)
     del out
     alg=2*8*dl*(int(offL[-1])+int(offR[-1]))
     tot=int(offL[-1]+offR[-1])
