@@ -200,6 +200,45 @@ def cpu_baseline_all_cores(terms: int, per_core_rate: float, budget_s: float):
     }
 
 
+def hbm_clock_info(device: int):
+    """What the box says about its memory clock, next to the 8.0 TB/s spec constant the roofline uses
+    (BASELINE.md section 3).  Best effort: torch's device properties, then the amdgpu sysfs DPM table."""
+    info = {"spec_peak_GBps": HBM_PEAK_BPS / 1e9}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        clk = getattr(p, "memory_clock_rate", None)          # kHz
+        bus = getattr(p, "memory_bus_width", None)           # bits
+        if clk and bus:
+            info["memory_clock_MHz"] = clk / 1e3
+            info["memory_bus_bits"] = bus
+            # HBM3E moves 4 bits per pin per reported clock on this part (2 x DDR): 8192 pins x 2 GHz x 4 = 8.2 TB/s
+            info["derived_peak_GBps"] = clk * 1e3 * bus / 8 * 4 / 1e9
+            info["derived_formula"] = "memory_clock x 4 transfers x bus_bits / 8"
+    except Exception as e:                                    # never let a diagnostic cost the contract line
+        info["torch_error"] = repr(e)
+    try:
+        import glob
+        import re
+        active = set()
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_mclk")):
+            with open(path) as f:
+                for ln in f:
+                    m = re.match(r"\s*\d+:\s*(\d+)\s*[Mm][Hh]z\s*\*", ln)
+                    if m:
+                        active.add(int(m.group(1)))
+        if active:
+            info["pp_dpm_mclk_active_MHz"] = sorted(active)      # the level every card of the node holds
+            if "derived_peak_GBps" not in info:
+                # 8 HBM3E stacks x 1024 pins (spec), 4 transfers per pin per reported clock: 2000 MHz -> 8.19 TB/s
+                info["memory_bus_bits"] = 8192
+                info["derived_peak_GBps"] = max(active) * 1e6 * 4 * 8192 / 8 / 1e9
+                info["derived_formula"] = "pp_dpm_mclk x 4 transfers x 8192 pins (spec bus width) / 8"
+    except Exception as e:
+        info["sysfs_error"] = repr(e)
+    return info
+
+
 def kernel_source_hash() -> str:
     """sha256 (first 16 hex digits) of the multiply kernels' source: ties a PMC capture to a build."""
     import hashlib
@@ -422,6 +461,13 @@ def main():
         if e_step:
             e_step[1].record()
 
+    # verification hooks (off the clock except the two mid-run digests above)
+    from csgn_amd.capi import check
+    mid_step = args.steps // 2
+    mid_slots = [0, slots - 1] if slots > 1 else [0]
+    mid_digests = None
+    if not args.no_verify and rank == 0 and args.steps >= 3:
+        mid_digests = torch.zeros(len(mid_slots), dtype=torch.int64, device=dev)
     mk = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev_mul = [mk() for _ in range(args.steps)]
     ev_step = [mk() for _ in range(args.steps)]
@@ -435,6 +481,12 @@ def main():
             t0 = time.perf_counter()
             for k in range(args.steps):
                 step(ev_mul[k], ev_step[k])
+                if k == mid_step and mid_digests is not None:
+                    # a launch that is NOT the run's last one: digest two arena slots right behind the middle
+                    # step (two reads of 168 MB, ~60 us inside a step of more than a second; checked after the loop)
+                    for slot in mid_slots:
+                        check(hip.lib.csgn_digest(arena[slot * words_per_product:].data_ptr(), words_per_product, 0,
+                                                  mid_digests[mid_slots.index(slot):].data_ptr(), hip.stream))
             torch.cuda.synchronize()
             host_barrier()
             elapsed = time.perf_counter() - t0
@@ -471,12 +523,46 @@ def main():
     # whole arena (first, last and evenly spaced ones) with the oracle ----
     verified = None
     verified_slots = []
+    oracle_slots = []
+    verify_notes = {}
     if not args.no_verify and rank == 0:
         from oracle.binding import Oracle
         orc = Oracle()
         ok = True
         first_of_last = (launches_per_step - 1) * slots
         live = batch - first_of_last                           # slots rewritten by the last launch
+        pair_of_slot = [first_of_last + sl if sl < live else first_of_last - slots + sl for sl in range(slots)]
+        # (a) EVERY slot, on the GPU: Dec(arena slot) under random keys against Dec(L_q) & Dec(R_q) of the pair
+        # that wrote the slot last, computed from the OPERANDS (csgn_decrypt_product_uniform never sees the
+        # arena).  Short keys (d = 2, 3) so that about one term in 4 / 8 hits and the parities are not trivially 0.
+        if min(pair_of_slot) >= 0:
+            idx = torch.tensor(pair_of_slot, dtype=torch.int64, device=dev)
+            lsel = left.view(batch, words_per_operand)[idx].reshape(-1)
+            rsel = right.view(batch, words_per_operand)[idx].reshape(-1)
+            krng = np.random.default_rng(SEED ^ 0x5EED)
+            mismatches, ones = 0, 0
+            for trial in range(6):
+                vkey = krng.permutation(N_BITS)[:2 + trial % 2].astype(np.uint64)
+                vmask = hip.upload(hip.key_mask(N_BITS, vkey))
+                got = hip.decrypt_uniform(N_BITS, slots, T * T, arena, vmask)
+                want = hip.decrypt_combined_uniform(N_BITS, slots, T, T, lsel, rsel, vmask, product=True)
+                mismatches += int((got != want).sum().item())
+                ones += int(want.sum().item())
+            ok = ok and mismatches == 0 and ones > 0
+            verified_slots = list(range(slots))
+            verify_notes["all_slots"] = (f"{slots} slots x 6 random keys (d=2,3): Dec(slot) == Dec(L)&Dec(R) from the operands; "
+                                         f"{mismatches} mismatches, {ones} one-bits among {6 * slots}")
+            del lsel, rsel
+        # (b) two slots of a MID-RUN launch (digests taken behind step `mid_step`) against the oracle
+        if mid_digests is not None:
+            md = hip.download(mid_digests)
+            for j, slot in enumerate(mid_slots):
+                p = lo + pair_of_slot[slot]
+                a = orc.synth(SEED + 1, N_BITS, p * words_per_operand, words_per_operand)
+                b = orc.synth(SEED + 2, N_BITS, p * words_per_operand, words_per_operand)
+                want, _ = orc.mul(N_BITS, a, b)
+                ok = ok and (int(md[j]) == orc.digest(want))
+            verify_notes["mid_run"] = f"slots {mid_slots} digested behind step {mid_step} of {args.steps}, equal to the oracle's products"
         want_n = max(1, min(args.verify_slots, slots))
         picks = sorted({int(round(i * (slots - 1) / max(1, want_n - 1))) for i in range(want_n)} | {0, slots - 1})
         for slot in picks:
@@ -490,7 +576,9 @@ def main():
             want, _ = orc.mul(N_BITS, a, b)
             got = hip.digest(arena[slot * words_per_product:(slot + 1) * words_per_product])
             ok = ok and (got == orc.digest(want))
-            verified_slots.append(slot)
+            oracle_slots.append(slot)
+            if slot not in verified_slots:
+                verified_slots.append(slot)
         if use_dist:
             ok = ok and bool((gathered == T * T).all().item()) and gathered.numel() == world * batch
         verified = bool(ok)
@@ -523,7 +611,10 @@ def main():
                 "bytes_per_mult": bytes_per_mul,
                 "collective": collective,
                 "verified_vs_oracle": verified,
-                "verified_slots": verified_slots,
+                "verified_slots": sorted(verified_slots),
+                "verified_slots_oracle_digest": oracle_slots,
+                "verification": verify_notes,
+                "hbm_clock": hbm_clock_info(local_rank),
                 "step_ms_rank0": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1],
                                   "n": len(step_ms)},
                 "value_from_median_step": world * batch / (step_ms[len(step_ms) // 2] / 1e3),

@@ -36,7 +36,8 @@ def ref():
     r = Ref(DRIVER_SO)
     maps = open("/proc/self/maps").read()
     assert "libcertFHE.so" in maps and "libcsgn_hip.so" in maps, "the drop-in library is not the one loaded"
-    assert "libcsgn_ref.so" not in maps or True   # the genuine reference may be loaded by other modules
+    # (the genuine reference, libcsgn_ref.so, may be mapped too when other test modules ran first in this
+    # process: what matters is the library THIS driver calls, checked by test_fixture_is_the_dropin with ldd)
     return r
 
 
