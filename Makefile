@@ -24,7 +24,7 @@ $(LIBDIR)/libcsgn_shard.so: $(CSRC)/csgn_shard.hip include/csgn_shard.h include/
 	mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared -Iinclude -o $@ $(CSRC)/csgn_shard.hip -L$(ROCM_LIB) -lrccl
 
-tools: tools/bin/shard_mul tools/bin/bench_mul
+tools: tools/bin/shard_mul tools/bin/bench_mul tools/bin/bench_native
 
 tools/bin/shard_mul: tools/shard_mul.cpp $(LIBDIR)/libcertFHE_shard.so
 	mkdir -p tools/bin
@@ -37,6 +37,12 @@ $(LIBDIR)/libcertFHE_shard.so: $(wildcard $(CSRC)/certfhe_shard/*.cpp) $(CLS_HDR
         $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcsgn_shard.so
 	$(CXX) -std=c++11 -O2 -fPIC -shared -pthread -Iinclude -Iinclude/certfhe -o $@ $(wildcard $(CSRC)/certfhe_shard/*.cpp) \
 	    -L$(LIBDIR) -lcertFHE -lcsgn_shard -lcsgn_hip '-Wl,-rpath,$$ORIGIN'
+
+# bench.py's measurement without torch: thread per GPU over the C ABI, strict RCCL (bench.py --native-ranks)
+tools/bin/bench_native: tools/bench_native.cpp $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so
+	mkdir -p tools/bin
+	$(CXX) -std=c++11 -O2 -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_shard -lcsgn_hip -lpthread \
+	    '-Wl,-rpath,$(abspath $(LIBDIR))' '-Wl,-rpath,$(abspath $(ROCM_LIB))'
 
 tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
 	mkdir -p tools/bin
@@ -55,4 +61,4 @@ check: all
 	python -m pytest tests -q -m "not gpu"
 
 clean:
-	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcertFHE_shard.so tools/bin/shard_mul tools/bin/bench_mul
+	rm -f $(LIBDIR)/libcsgn_hip.so $(LIBDIR)/libcsgn_shard.so $(LIBDIR)/libcertFHE.so $(LIBDIR)/libcertFHE_shard.so tools/bin/shard_mul tools/bin/bench_mul tools/bin/bench_native

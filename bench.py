@@ -77,6 +77,10 @@ def parse_args():
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="native: csgn_comm_gather_counts (libcsgn_shard.so, ncclAllGather called directly); "
                          "torch: torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--native-ranks", action="store_true",
+                    help="run the measurement in tools/bin/bench_native instead of torch rank processes: ONE process, "
+                         "one host thread per GPU over the C ABI, one HIP runtime and the RCCL libcsgn_shard.so was built "
+                         "against (strict version check).  Same workload, same JSON line; the CPU baseline is added here.")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes through torch.distributed.run even for --gpus 1")
     ap.add_argument("--verify-slots", type=int, default=8, help="arena slots compared with the oracle after timing")
@@ -111,6 +115,29 @@ def spawn_ranks(args) -> int:
     env.setdefault("OMP_NUM_THREADS", "4")
     print("# bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
     return subprocess.call(cmd, env=env)
+
+
+def native_ranks(args) -> int:
+    """--native-ranks: the torch-free driver does the GPU work; this process makes no GPU call at all."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "bin", "bench_native")
+    if not os.path.exists(tool):
+        from csgn_amd import build
+        build.build_bench_native(verbose=False)
+    cmd = [tool, "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
+           "--slots", str(args.slots), "--terms", str(args.terms), "--force-collective", "1" if args.force_collective else "0"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("# bench.py: " + " ".join(cmd), file=sys.stderr)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        return p.returncode
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]     # RCCL may print a banner before it
+    out = json.loads(line)
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.terms, args.cpu_seconds)
+    print(json.dumps(out))
+    return 0
 
 
 def cpu_baseline(terms: int, budget_s: float):
@@ -274,6 +301,8 @@ def main():
         return
     args = parse_args()
     in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.native_ranks and not in_rank:
+        sys.exit(native_ranks(args))
     if not in_rank and (args.gpus > 1 or args.spawn):
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

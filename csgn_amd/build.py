@@ -109,12 +109,32 @@ def build_certfhe_shard(force: bool = False, verbose: bool = False):
     return CERTFHE_SHARD_LIB
 
 
+BENCH_NATIVE = os.path.join(ROOT, "tools", "bin", "bench_native")
+
+
+def build_bench_native(force: bool = False, verbose: bool = False) -> str:
+    """tools/bin/bench_native: bench.py's measurement as a torch-free C++ program over the C ABI (thread per GPU,
+    strict RCCL); bench.py --native-ranks starts it."""
+    src = os.path.join(ROOT, "tools", "bench_native.cpp")
+    os.makedirs(os.path.dirname(BENCH_NATIVE), exist_ok=True)
+    deps = [src, HIP_LIB, SHARD_LIB, os.path.join(INCLUDE, "csgn_hip.h"), os.path.join(INCLUDE, "csgn_shard.h")]
+    if force or _stale(BENCH_NATIVE, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+        cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I" + INCLUDE, "-o", BENCH_NATIVE, src, "-L" + LIBDIR,
+               "-lcsgn_shard", "-lcsgn_hip", "-lpthread", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath," + rocm_lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return BENCH_NATIVE
+
+
 def build_all(force: bool = False, verbose: bool = False):
     out = [build_hip(force, verbose), build_shard(force, verbose)]
     c = build_certfhe(force, verbose)
     if c:
         out.append(c)
         out.append(build_certfhe_shard(force, verbose))
+    out.append(build_bench_native(force, verbose))
     return out
 
 

@@ -219,6 +219,63 @@ void downloadBytes(void *host, const void *dev, size_t bytes)
         check(csgn_memcpy_d2h(host, dev, bytes, stream()), "csgn_memcpy_d2h");
 }
 
+namespace {
+struct StagePair {
+    void *host[2] = {nullptr, nullptr};
+    void *dev[2] = {nullptr, nullptr};
+};
+thread_local StagePair g_stage[16];
+} // namespace
+
+void *stageBuffer(int which)
+{
+    ensureDevice();
+    static thread_local StagePair local;
+    StagePair &sp = (g_device >= 0 && g_device < 16) ? g_stage[g_device] : local;
+    if (!sp.host[which])
+        check(csgn_host_alloc(&sp.host[which], &sp.dev[which], kStageBytes), "csgn_host_alloc");
+    return sp.host[which];
+}
+
+void downloadStaged(const void *dev, size_t bytes, void (*consume)(void *, const void *, size_t), void *ctx)
+{
+    if (bytes == 0)
+        return;
+    void *buf[2] = {stageBuffer(0), stageBuffer(1)};
+    const char *src = static_cast<const char *>(dev);
+    size_t done = 0, inflight = bytes < kStageBytes ? bytes : kStageBytes;
+    check(csgn_memcpy_d2h(buf[0], src, inflight, stream()), "csgn_memcpy_d2h");
+    for (int cur = 0; done < bytes; cur ^= 1) {
+        check(csgn_stream_sync(stream()), "csgn_stream_sync");          // piece `cur` has landed
+        const size_t have = inflight;
+        const size_t next_at = done + have;
+        inflight = 0;
+        if (next_at < bytes) {                                          // start the next piece, then handle this one
+            inflight = bytes - next_at < kStageBytes ? bytes - next_at : kStageBytes;
+            check(csgn_memcpy_d2h(buf[cur ^ 1], src + next_at, inflight, stream()), "csgn_memcpy_d2h");
+        }
+        consume(ctx, buf[cur], have);
+        done = next_at;
+    }
+}
+
+void uploadStaged(void *dev, size_t bytes, void (*produce)(void *, void *, size_t), void *ctx)
+{
+    if (bytes == 0)
+        return;
+    void *buf[2] = {stageBuffer(0), stageBuffer(1)};
+    char *dst = static_cast<char *>(dev);
+    size_t done = 0;
+    for (int cur = 0; done < bytes; cur ^= 1) {
+        const size_t n = bytes - done < kStageBytes ? bytes - done : kStageBytes;
+        produce(ctx, buf[cur], n);                                      // while the previous piece is on the link
+        check(csgn_stream_sync(stream()), "csgn_stream_sync");          // the other buffer is free again after this
+        check(csgn_memcpy_h2d(dst + done, buf[cur], n, stream()), "csgn_memcpy_h2d");
+        done += n;
+    }
+    check(csgn_stream_sync(stream()), "csgn_stream_sync");
+}
+
 void syncDevice()
 {
     if (g_device >= 0)

@@ -41,6 +41,15 @@ std::shared_ptr<DevicePayload> allocWords(uint64_t words);
 std::shared_ptr<DevicePayload> uploadWords(const uint64_t *host, uint64_t words);
 void downloadBytes(void *host, const void *dev, size_t bytes);
 void syncDevice();
+// Two pinned host buffers per thread and device for staged transfers (kStageBytes each, made on first use):
+// a copy between HBM and one of them is a DMA at the link's rate and asynchronous to the host, so it
+// overlaps with whatever the host does with the other (stream I/O in Ciphertext::serialize/deserialize).
+const size_t kStageBytes = (size_t)8 << 20;
+void *stageBuffer(int which);
+// dev -> sink / source -> dev in kStageBytes pieces through the two buffers, the transfer of one piece
+// overlapping the host's handling of the previous one.  `consume(ptr, n)` / `produce(ptr, n)` see pinned memory.
+void downloadStaged(const void *dev, size_t bytes, void (*consume)(void *ctx, const void *piece, size_t n), void *ctx);
+void uploadStaged(void *dev, size_t bytes, void (*produce)(void *ctx, void *piece, size_t n), void *ctx);
 // Pinned host byte(s) a kernel can write directly (valid after syncDevice()); *dev_alias is the
 // address to hand to the kernel.  One slot per thread and device, reused by every call.
 volatile unsigned char *resultSlot(void **dev_alias);

@@ -10,14 +10,20 @@
 //   dropin_driver bitlen                  non-canonical Bitlen propagation (left-operand rule)
 //   dropin_driver api                     copy/assign/in-place operator semantics, printing
 #include <cassert>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <algorithm>
 #include <sstream>
 #include <stdexcept>
+#include <streambuf>
+#include <vector>
 
 #include "certFHE.h"
+#include "csgn_hip.h"      // wirebench only: csgn_stream_sync
 
 using namespace certFHE;
 
@@ -436,6 +442,100 @@ static int cmd_wire(int argc, char **argv)
     return 0;
 }
 
+// ---- wirebench: throughput of the wire format and of the host mirror ----
+namespace {
+// an in-memory sink / source: what the stream write costs is a memcpy, nothing else
+struct MemBuf : std::streambuf {
+    std::vector<char> store;
+    size_t wpos;
+    explicit MemBuf(size_t cap) : store(cap), wpos(0) {}
+    std::streamsize xsputn(const char *s, std::streamsize n)
+    {
+        if (wpos + (size_t)n > store.size())
+            return 0;
+        memcpy(store.data() + wpos, s, (size_t)n);
+        wpos += (size_t)n;
+        return n;
+    }
+    int_type overflow(int_type c)
+    {
+        if (c != traits_type::eof() && wpos < store.size())
+            store[wpos++] = (char)c;
+        return c;
+    }
+    void rewindForRead() { setg(store.data(), store.data(), store.data() + wpos); }
+    void rewindForWrite() { wpos = 0; }
+};
+double nowSeconds()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+} // namespace
+
+static int cmd_wirebench()
+{
+    Library::initializeLibrary();
+    Context ctx(1247, 16);
+    const uint64_t dl = ctx.getDefaultN();
+    // a 1024-term ciphertext of synthetic words, made by deserialising a hand-built stream
+    const uint64_t terms = 1024, words = terms * dl;
+    MemBuf small(64 + words * 8);
+    {
+        std::ostream o(&small);
+        const char head[8] = {'C', 'S', 'G', 'N', 1, 0, 0, 0};
+        o.write(head, 8);
+        uint64_t hdr[3] = {1247, 16, words};
+        o.write(reinterpret_cast<const char *>(hdr), 24);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (uint64_t i = 0; i < words; ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const uint64_t w = (i % dl == dl - 1) ? (x & 0xFFFFFFFE00000000ull) : x;
+            o.write(reinterpret_cast<const char *>(&w), 8);
+        }
+    }
+    small.rewindForRead();
+    std::istream is(&small);
+    Ciphertext c1k = Ciphertext::deserialize(is);
+    EXPECT(c1k.getLen() == words);
+    Ciphertext big = c1k * c1k;                                   // 2^20 terms, 168 MB, never mirrored on the host
+    EXPECT(big.getLen() == words * terms);
+    const double big_bytes = (double)big.getLen() * 8;
+    MemBuf bulk((size_t)big_bytes + 64);
+    auto best_of = [&](int reps, const std::function<void()> &fn) {
+        double best = 1e30;
+        for (int r = 0; r < reps; ++r) {
+            const double t0 = nowSeconds();
+            fn();
+            best = std::min(best, nowSeconds() - t0);
+        }
+        return best;
+    };
+    // serialize / deserialize, 168 MB
+    double t = best_of(4, [&] { bulk.rewindForWrite(); std::ostream o(&bulk); big.serialize(o); });
+    printf("wirebench serialize   2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s\n", big_bytes / 1e6, t * 1e3, big_bytes / t / 1e9);
+    Ciphertext back;
+    t = best_of(4, [&] { bulk.rewindForRead(); std::istream i(&bulk); back = Ciphertext::deserialize(i); });
+    printf("wirebench deserialize 2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s\n", big_bytes / 1e6, t * 1e3, big_bytes / t / 1e9);
+    EXPECT(back.getLen() == big.getLen());
+    // 160 KB ciphertexts, 200 in a row
+    MemBuf sb(64 + words * 8);
+    t = best_of(3, [&] { for (int k = 0; k < 200; ++k) { sb.rewindForWrite(); std::ostream o(&sb); c1k.serialize(o); } });
+    printf("wirebench serialize   1024 terms  %7.3f MB  %8.3f us  %6.2f GB/s\n", words * 8 / 1e6, t / 200 * 1e6, 200.0 * words * 8 / t / 1e9);
+    t = best_of(3, [&] { for (int k = 0; k < 200; ++k) { sb.rewindForRead(); std::istream i(&sb); Ciphertext x = Ciphertext::deserialize(i); } });
+    printf("wirebench deserialize 1024 terms  %7.3f MB  %8.3f us  %6.2f GB/s\n", words * 8 / 1e6, t / 200 * 1e6, 200.0 * words * 8 / t / 1e9);
+    // the host mirror of a fresh 1024 x 1024 product (getValues: pageable destination)
+    t = best_of(3, [&] { Ciphertext p = c1k * c1k; volatile uint64_t sink = p.getValues()[0]; (void)sink; });
+    const double tm = best_of(3, [&] { Ciphertext p = c1k * c1k; csgn_stream_sync(nullptr); });
+    printf("wirebench getValues   2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s  (product + mirror %0.3f ms, product alone %0.3f ms)\n",
+           big_bytes / 1e6, (t - tm) * 1e3, big_bytes / (t - tm) / 1e9, t * 1e3, tm * 1e3);
+    // words of the round trip equal the product's
+    const uint64_t *a = big.getValues(), *b = back.getValues();
+    for (uint64_t i = 0; i < big.getLen(); i += 4099)
+        EXPECT(a[i] == b[i]);
+    printf("wirebench ok\n");
+    return 0;
+}
+
 static int cmd_batch(int count)
 {
     // CiphertextBatch (extension): `count` independent depth-6 circuits in lock step, checked
@@ -783,6 +883,8 @@ int main(int argc, char **argv)
             return cmd_api();
         if (cmd == "wire")
             return cmd_wire(argc, argv);
+        if (cmd == "wirebench")
+            return cmd_wirebench();
         if (cmd == "batch")
             return cmd_batch(argc > 2 ? atoi(argv[2]) : 4096);
         if (cmd == "graph")

@@ -68,6 +68,35 @@ def test_bench_contract_line_on_the_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_native_ranks_mode_prints_the_same_contract_line():
+    """--native-ranks: the measurement runs in tools/bin/bench_native -- one process, one host
+    thread per GPU over the C ABI, no torch, the RCCL libcsgn_shard.so was built against under the STRICT version
+    check -- and prints bench.py's contract line.  With --force-collective the native all-gather of the term counts
+    is inside the timed region at world 1; every arena slot is verified on the GPU by the tool itself."""
+    p = run(["--native-ranks", "--force-collective", "--batch", "512", "--slots", "32", "--steps", "2", "--warmup", "1",
+             "--cpu-seconds", "1.5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[:500]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "mult/s" and d["dtype"] == "u64" and d["scaling"] == "weak"
+    assert "CSGN_COMM_STRICT" in d["config"]["collective"] and "ncclAllGather" in d["config"]["collective"]
+    assert "no torch" in d["config"]["collective"] and d["config"]["verified_slots"] == 32
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.3 < r["frac"] < 1.0
+    assert r["kernel"] == "k_touch+k_mul_flat"
+    assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3
+    # the tool is what it says: no torch, no python in its link map
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "bin", "bench_native")
+    ldd = subprocess.run(["ldd", tool], capture_output=True, text=True).stdout
+    assert "libcsgn_hip.so" in ldd and "libcsgn_shard.so" in ldd and "torch" not in ldd and "python" not in ldd
+
+
+@pytest.mark.gpu
 def test_bench_spawned_rank_with_the_rccl_gather():
     """--spawn: the parent starts one rank through torch.distributed.run; --force-collective puts the
     native RCCL all-gather of the term counts into the timed region."""

@@ -165,6 +165,17 @@ def test_wire_format_roundtrip(driver, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_wire_format_and_host_mirror_throughput(driver):
+    """Row f3's staging path: a 2^20-term ciphertext (168 MB) serialised from HBM through the pinned staging
+    pair, deserialised the same way, the host mirror of a fresh product -- round trip checked, rates printed
+    (tools/prof_r04.sh keeps the lines in profiles/r04/wirebench.log)."""
+    out = run(driver, "wirebench").stdout
+    assert "wirebench ok" in out
+    rates = [float(ln.split("GB/s")[0].split()[-1]) for ln in out.splitlines() if "GB/s" in ln]
+    assert len(rates) == 5 and min(rates) > 0.2, out      # the per-word loops of round 3 ran at ~0.1 GB/s
+
+
+@pytest.mark.gpu
 def test_batch_extension(driver):
     """certFHE::CiphertextBatch: 4096 depth-6 circuits in lock step vs the clear evaluation,
     the fused decryptProduct, and the per-object API."""
