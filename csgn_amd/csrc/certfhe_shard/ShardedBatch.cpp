@@ -317,6 +317,16 @@ void ShardGroup::setTimeoutMs(uint64_t ms)
 
 void ShardGroup::injectFailure(int rank) { impl->w.at(rank)->fail_next.store(true); }
 
+void ShardGroup::setTuning(const std::string &key, int value)
+{
+    // knobs are per host thread (csgn_hip.h): the group's kernels run on its worker threads, not on the caller's.
+    // The name is checked here first: a typo must not count as a rank failure (which aborts the communicators).
+    int unused = 0;
+    if (csgn_get_tuning(key.c_str(), &unused) != CSGN_OK)
+        throw std::invalid_argument("certFHE::ShardGroup::setTuning: no knob named '" + key + "'");
+    impl->runAll([&](ShardWorker &) { ck(csgn_set_tuning(key.c_str(), value), "csgn_set_tuning"); });
+}
+
 void ShardGroup::forceGroupedBroadcast(bool on)
 {
     for (auto &x : impl->w)
@@ -526,6 +536,9 @@ ShardedBatch ShardedBatch::applyPermutation(const Permutation &permutation) cons
         void *d_perm = me.take(tb);
         try {
             ck(csgn_memcpy_h2d(d_perm, table.data(), (size_t)n * 4, me.stream), "csgn_memcpy_h2d");
+            // `table` is a pageable local that dies when runAll returns: the copy must have left it by then
+            // (csgn_hip.h, csgn_memcpy_h2d: the host buffer belongs to the call until the stream has passed it)
+            ck(csgn_stream_sync(me.stream), "csgn_stream_sync");
             ck(csgn_permute_uniform(n, mine, a->terms, 0, a->words(me.rank), static_cast<const uint32_t *>(d_perm),
                                     o->words(me.rank), me.stream),
                "csgn_permute_uniform");

@@ -362,23 +362,26 @@ int csgn_mul_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint64_t t2,
 namespace {
 
 // the plan step behind csgn_mul_ragged_plan and csgn_mul_plan_ragged; h_head_out (optional): the whole head block
+struct PlanScratch {
+    u64 *p = nullptr;
+    size_t words = 0;
+};
+
+// owned: a csgn_mul_plan's own device block (it has to outlive the call: the class lists stay in it);
+// nullptr: the calling thread's grow-only block
 int plan_ragged(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
-                uint64_t *d_off_out, uint64_t h_plan[4], uint64_t *h_head_out, void *stream)
+                uint64_t *d_off_out, uint64_t h_plan[4], uint64_t *h_head_out, PlanScratch *owned, void *stream)
 {
     REQUIRE(d_off_left && d_off_right && d_off_out && h_plan, "null pointer");
     // The call returns host numbers, so it ends with a stream synchronise anyway; its small device
     // scratch is kept per host thread and device (grow-only) because hipMalloc + hipFree around
     // every plan cost more than the plan (hipFree synchronises the whole device).
-    struct PlanScratch {
-        u64 *p = nullptr;
-        size_t words = 0;
-    };
     static thread_local PlanScratch cache[16];
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const size_t need = csgn::mul_ragged_plan_scratch_words(batch);
     PlanScratch local;
-    PlanScratch &sc = (dev >= 0 && dev < 16) ? cache[dev] : local;
+    PlanScratch &sc = owned ? *owned : (dev >= 0 && dev < 16) ? cache[dev] : local;
     if (sc.words < need) {
         if (sc.p)
             (void)hipFree(sc.p);
@@ -416,7 +419,7 @@ extern "C" {
 int csgn_mul_ragged_plan(uint64_t batch, const uint64_t *d_off_left, const uint64_t *d_off_right,
                          uint64_t *d_off_out, uint64_t h_plan[4], void *stream)
 {
-    return plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, nullptr, stream);
+    return plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, nullptr, nullptr, stream);
 }
 
 /* ---- the plan as an object of the caller's ---- */
@@ -426,6 +429,8 @@ struct csgn_mul_plan {
     bool trust = false;
     u64 *d_sum = nullptr;        // one device word for the checksum check
     int device = -1;
+    PlanScratch work;            // the plan kernels' device block: the size-class lists live here
+    int work_device = -1;
 };
 
 int csgn_mul_plan_create(csgn_mul_plan **plan)
@@ -441,6 +446,8 @@ void csgn_mul_plan_destroy(csgn_mul_plan *plan)
         return;
     if (plan->d_sum)
         (void)hipFree(plan->d_sum);
+    if (plan->work.p)
+        (void)hipFree(plan->work.p);
     delete plan;
 }
 
@@ -456,11 +463,19 @@ int csgn_mul_plan_ragged(csgn_mul_plan *plan, uint64_t batch, const uint64_t *d_
 {
     REQUIRE(plan, "plan is null");
     plan->planned = false;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (plan->work.p && plan->work_device != dev) {          // the object moved to another GPU: start over there
+        (void)hipFree(plan->work.p);
+        plan->work = PlanScratch();
+    }
+    plan->work_device = dev;
     std::vector<u64> head(csgn::mul_ragged_plan_head_words(), 0);
-    if (int rc = plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, reinterpret_cast<uint64_t *>(head.data()), stream))
+    if (int rc = plan_ragged(batch, d_off_left, d_off_right, d_off_out, h_plan, reinterpret_cast<uint64_t *>(head.data()),
+                             &plan->work, stream))
         return rc;
     csgn::mul_plan_notes_from_head(plan->notes, (const u64 *)d_off_left, (const u64 *)d_off_right,
-                                   (const u64 *)d_off_out, batch, head.data());
+                                   (const u64 *)d_off_out, batch, head.data(), plan->work.p);
     plan->planned = true;
     return CSGN_OK;
 }

@@ -206,10 +206,15 @@ __device__ inline u32 wave_incl_scan(u32 v)
     return v;
 }
 
+// (also clears the call's control words and status granules: `head`, nothing of which is touched before
+// the next kernel of the call)
 __global__ void __launch_bounds__(256) k_cg_count(u32 batch, const u64 *__restrict__ off, Geom g,
-                                                  u32 *__restrict__ gpos, u64 *__restrict__ partial)
+                                                  u32 *__restrict__ gpos, u64 *__restrict__ partial,
+                                                  u64 *__restrict__ head, u64 head_words)
 {
     __shared__ u32 wsum[4];
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < head_words; i += (u64)gridDim.x * 256u)
+        head[i] = 0ull;
     const u32 c = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     bool large;
     const u32 n = c < batch ? group_count(off, c, g, large) : 0u;
@@ -271,14 +276,43 @@ struct GroupDesc {
 __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restrict__ off, Geom g,
                                                  const u32 *__restrict__ gpos, const u64 *__restrict__ partial,
                                                  GroupDesc *__restrict__ groups, u64 *__restrict__ chunks,
-                                                 u64 *__restrict__ ctrl)
+                                                 u64 *__restrict__ ctrl, u32 scanned)
 {
+    // the block's base: `partial` already scanned by k_cg_scan (scanned != 0), or -- up to 1024 blocks --
+    // summed here, which saves the scan kernel's launch; block 0 then also leaves the total for the main kernel
+    __shared__ u64 s_base, s_part[4];
+    u64 block_base = 0;
+    if (scanned) {
+        block_base = partial[blockIdx.x];
+    } else {
+        u64 mine = 0, all = 0;
+        for (u32 b = threadIdx.x; b < gridDim.x; b += 256u) {
+            const u64 v = partial[b];
+            all += v;
+            mine += b < blockIdx.x ? v : 0ull;
+        }
+        const bool want_total = blockIdx.x == 0;
+        u64 red = want_total ? all : mine;
+        for (int o = 32; o > 0; o >>= 1)
+            red += (u64)__shfl_down(red, o, 64);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            s_part[threadIdx.x >> 6] = red;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u64 sum = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            if (want_total)
+                ctrl[kCtrlGroups] = sum;
+            s_base = want_total ? 0ull : sum;
+        }
+        __syncthreads();
+        block_base = s_base;
+    }
     const u32 c = blockIdx.x * 256u + threadIdx.x;
     if (c >= batch)
         return;
     bool large, next_large;
     const u32 n = group_count(off, c, g, large);
-    const u64 before = partial[blockIdx.x] + gpos[c];             // groups started before c
+    const u64 before = block_base + gpos[c];                      // groups started before c
     const u64 o0 = off[c], o1 = off[c + 1];
     if (large) {
         const u64 at = atomicAdd(ull(ctrl + kCtrlChunks), (unsigned long long)n);
@@ -880,12 +914,16 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     const Geom g = make_geom(U);
     const Layout l = make_layout(scratch, batch, total_terms, g);
     hipError_t e;
-    if ((e = zero_words(l.ctrl, l.head_bytes / 8, s)) != hipSuccess)       // (a kernel: see zero_words)
-        return e;
+    // the call's head (control words + status granules) is cleared by the first kernel itself: no memset
+    // node (see zero_words), no launch of its own
     const u32 cblocks = ceil_div_u64(batch, 256);
-    k_cg_count<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial);
-    k_cg_scan<<<1, 1024, 0, s>>>(cblocks, l.partial, l.ctrl);
-    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.groups, l.chunks, l.ctrl);
+    k_cg_count<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.ctrl, l.head_bytes / 8);
+    const bool scan = cblocks > 1024u;
+    if (scan)
+        k_cg_scan<<<1, 1024, 0, s>>>(cblocks, l.partial, l.ctrl);
+    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.groups, l.chunks, l.ctrl, scan ? 1u : 0u);
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
 
     // tag bits kept by the tables: all of them, unless a test asks for collisions
     const int bits = tune(TUNE_COMPACT_TAG_BITS);

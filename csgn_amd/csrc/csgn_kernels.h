@@ -35,9 +35,15 @@ struct MulPlanNotes {
     u64 checksum = 0;                    // of the three offset arrays as planned
     u32 n = 0;                           // huge-pair records kept (sorted by pair)
     u64 rec[32][6];                      // {pair, offL, offR, t1, t2, offOut}
+    // size classes of small pairs (csgn_mul.hip, class_of): pairs and product terms per class, and the device
+    // list of every class's pairs (class c = lists[cls_base[c] .. cls_base[c + 1])); nullptr: no lists
+    u64 cls_pairs[28] = {0}, cls_terms[28] = {0}, cls_base[29] = {0};
+    const u32 *lists = nullptr;
 };
+// d_work: the plan's device block (mul_ragged_plan wrote the class lists there) when it stays alive with the
+// notes -- a csgn_mul_plan owns one --, nullptr otherwise
 void mul_plan_notes_from_head(MulPlanNotes &notes, const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch,
-                              const u64 *h_head);
+                              const u64 *h_head, const u64 *d_work);
 hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s);
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s);

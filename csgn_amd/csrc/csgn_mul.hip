@@ -105,6 +105,7 @@ struct MulArgs {
     u32 t1, t2, U, TI, col_tiles, row_tiles;
     u32 xcd_remap;
     u32 pair_base;      // ragged launches cut into chunks: first pair of this launch
+    const u32 *pair_list;   // ragged, size classes: the launch's pairs by index into this list (nullptr: consecutive pairs)
 };
 
 template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
     const u32 bid = a.xcd_remap ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const u32 pair_local = bid / tiles;
     const u32 tile = bid - pair_local * tiles;
-    const u32 pair = a.pair_base + pair_local;
+    const u32 pair = (RAGGED && a.pair_list) ? a.pair_list[a.pair_base + pair_local] : a.pair_base + pair_local;
     const u32 row_tile = tile / a.col_tiles;
     const u32 col_tile = tile - row_tile * a.col_tiles;
 
@@ -216,7 +217,8 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          Unit *__restrict__ out,
                                                          const u64 *__restrict__ offOut, u32 batch,
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU,
-                                                         u32 pf_pairs, const u64 *__restrict__ d_gate)
+                                                         u32 pf_pairs, const u64 *__restrict__ d_gate,
+                                                         u32 skip_t1, u32 skip_t2)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
     // csgn_mul_ragged_async: the grid was sized for the caller's bound; the real end of the output is
@@ -265,6 +267,17 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
         const bool whole = last_term < s_o1;
         const bool two = !whole && last_term < s_o2;            // a turn that crosses ONE pair boundary: no window
+        // pairs of the size classes (t1 <= skip_t1, t2 <= skip_t2) were written by their own launches
+        // (mul_ragged, "size classes"): a turn inside such pairs has nothing to do here
+        if (skip_t1 && (whole || two)) {
+            const bool b0 = (u32)(s_l1 - s_l0) <= skip_t1 && (u32)(s_r1 - s_r0) <= skip_t2;
+            const bool b1 = (u32)(offL[pw2] - s_l1) <= skip_t1 && (u32)(s_r2 - s_r1) <= skip_t2;
+            if (b0 && (whole || b1)) {
+                if (two)
+                    pw += 1u;
+                continue;
+            }
+        }
         if (!whole && !two) {
             const u32 i = threadIdx.x;
             const u32 pi = min(pw + i, batch);                   // the offset arrays have batch + 1 entries
@@ -297,13 +310,14 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             la[m] = ra[m] = 0;
             if (live[m]) {
                 u64 o0 = s_o0, l0 = s_l0, rr0 = s_r0;
-                u32 t2 = (u32)(s_r1 - s_r0);
+                u32 t2 = (u32)(s_r1 - s_r0), t1 = (u32)(s_l1 - s_l0);
                 if (two && term >= s_o1) {                      // the second pair of the bet
                     p[m] = pw + 1u;
                     o0 = s_o1;
                     l0 = s_l1;
                     rr0 = s_r1;
                     t2 = (u32)(s_r2 - s_r1);
+                    t1 = skip_t1 ? (u32)(offL[pw2] - s_l1) : 0u;
                 } else if (!whole && term >= s_o1) {            // past the end of pair pw: look in the window
                     // largest j in [0, kWin] with w_out[j] <= term (w_out[0] = s_o0 <= term)
                     u32 lo = 0, hi = kWin + 1u;
@@ -320,18 +334,24 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                         l0 = offL[p[m]];
                         rr0 = offR[p[m]];
                         t2 = (u32)(offR[p[m] + 1] - rr0);
+                        t1 = (u32)(offL[p[m] + 1] - l0);
                     } else {
                         p[m] = pw + lo;
                         o0 = w_out[lo];
                         l0 = w_l[lo];
                         rr0 = w_r[lo];
                         t2 = (u32)(w_r[lo + 1] - rr0);
+                        t1 = (u32)(w_l[lo + 1] - l0);           // lo < kWin here: w_l[kWin] is staged
                     }
                 }
                 const u32 q = (u32)(term - o0);                 // product term index inside the pair
                 const u32 i = q / t2, j = q - i * t2;
                 la[m] = (l0 + i) * U + k;
                 ra[m] = (rr0 + j) * U + k;
+                if (skip_t1 && t1 <= skip_t1 && t2 <= skip_t2) {   // a size-class launch wrote this pair
+                    live[m] = false;
+                    la[m] = ra[m] = 0;
+                }
             }
         }
         Unit lv[M], rv[M];
@@ -357,7 +377,27 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
 
 constexpr u64 kHugeTerms = 65536;        // a product of this many terms is recorded by the plan (10 MB at N=1247)
 constexpr u64 kHugeRecords = 32;            // = the rows of MulPlanNotes::rec
-constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 3;  // [plan4][huge count][records][left terms, right terms of the batch][offsets checksum]
+// Size classes of small pairs (round 4): t1 in (0, 8], (8, 16], (16, 32], (32, 64] x t2 in (0, 2], (2, 4], ... (64, 128]:
+// 28 classes; the plan counts each class's pairs and product terms and lists its pairs, so that the multiply can
+// give every class ONE launch of the LDS-tiled kernel shaped for it (pair = list[block / tiles]: no lookup of any
+// kind) and leave only pairs with a long side to the CSR kernel.
+constexpr u32 kClsRows = 4, kClsCols = 7, kNumClasses = kClsRows * kClsCols;
+constexpr u32 kClsMaxT1 = 64, kClsMaxT2 = 128;
+__host__ __device__ inline int class_of(u64 t1, u64 t2)
+{
+    if (t1 == 0 || t2 == 0 || t1 > kClsMaxT1 || t2 > kClsMaxT2)
+        return -1;
+    const int r = t1 <= 8 ? 0 : t1 <= 16 ? 1 : t1 <= 32 ? 2 : 3;
+    int c = 0;
+    while ((2ull << c) < t2)
+        ++c;                                         // t2 <= 2 << c
+    return r * (int)kClsCols + c;
+}
+inline u32 class_max_t1(int cls) { return 8u << (cls / (int)kClsCols); }
+inline u32 class_max_t2(int cls) { return 2u << (cls % (int)kClsCols); }
+
+constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 3 + 2 * kNumClasses;  // [plan4][huge count][records][left terms, right terms of the batch][offsets checksum][class pairs][class terms]
+constexpr u64 kClassAt = 4 + 1 + kHugeRecords * 6 + 3;      // first class word of the head
 
 // one pair's share of the checksum of the offset arrays
 __device__ inline u64 offsets_mix(u64 b, u64 l, u64 r, u64 o)
@@ -459,13 +499,20 @@ __global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 ba
 // all inside 99 % of a skewed batch's output) and runs the CSR kernel on the stretches between them.
 __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
                                                   const u64 *__restrict__ offL, const u64 *__restrict__ offR,
-                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge)
+                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge, u32 classes)
 {
     const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
     if (b == 0) {                                   // operand totals: what sizes the slices of a large product
         huge[1 + kHugeRecords * 6] = offL[batch] - offL[0];
         huge[2 + kHugeRecords * 6] = offR[batch] - offR[0];
     }
+    __shared__ u32 h_pairs[kNumClasses];
+    __shared__ u64 h_terms[kNumClasses];
+    if (threadIdx.x < kNumClasses) {
+        h_pairs[threadIdx.x] = 0u;
+        h_terms[threadIdx.x] = 0ull;
+    }
+    __syncthreads();
     u64 mix = 0;
     if (b == batch)
         mix = offsets_mix(b, offL[b], offR[b], offOut[b]);
@@ -474,6 +521,11 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
         offOut[b] = o;
         mix = offsets_mix(b, offL[b], offR[b], o);
         const u64 l0 = offL[b], r0 = offR[b], t1 = offL[b + 1] - l0, t2 = offR[b + 1] - r0;
+        const int cls = classes ? class_of(t1, t2) : -1;
+        if (cls >= 0) {
+            atomicAdd(h_pairs + cls, 1u);
+            atomicAdd(reinterpret_cast<unsigned long long *>(h_terms + cls), (unsigned long long)(t1 * t2));
+        }
         if (t1 * t2 >= kHugeTerms) {
             const u64 slot = atomicAdd(reinterpret_cast<unsigned long long *>(huge), 1ull);
             if (slot < kHugeRecords) {
@@ -487,6 +539,49 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
         mix += (u64)__shfl_down(mix, off, 64);
     if ((threadIdx.x & (kWave - 1)) == 0 && mix)
         atomicAdd(reinterpret_cast<unsigned long long *>(huge + 3 + kHugeRecords * 6), mix);
+    // the workgroup's class histogram: one global atomic per class it met
+    __syncthreads();
+    if (threadIdx.x < kNumClasses && h_pairs[threadIdx.x]) {
+        u64 *cls = huge - 4 + kClassAt;                          // `huge` = head + 4
+        atomicAdd(reinterpret_cast<unsigned long long *>(cls + threadIdx.x), (unsigned long long)h_pairs[threadIdx.x]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(cls + kNumClasses + threadIdx.x), (unsigned long long)h_terms[threadIdx.x]);
+    }
+}
+
+// class bases (exclusive scan of the class pair counts) and zeroed cursors, then the lists
+__global__ void k_class_bases(const u64 *__restrict__ head, u64 *__restrict__ bases)
+{
+    u64 run = 0;
+    for (u32 c = 0; c < kNumClasses; ++c) {
+        bases[c] = run;
+        bases[kNumClasses + 1 + c] = 0;                         // cursor
+        run += head[kClassAt + c];
+    }
+    bases[kNumClasses] = run;
+}
+
+__global__ void __launch_bounds__(256) k_class_lists(u64 batch, const u64 *__restrict__ offL, const u64 *__restrict__ offR,
+                                                     u64 *__restrict__ bases, u32 *__restrict__ list)
+{
+    __shared__ u32 h_count[kNumClasses], h_base[kNumClasses];
+    if (threadIdx.x < kNumClasses)
+        h_count[threadIdx.x] = 0u;
+    __syncthreads();
+    const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
+    int cls = -1;
+    u32 rank = 0;
+    if (b < batch) {
+        cls = class_of(offL[b + 1] - offL[b], offR[b + 1] - offR[b]);
+        if (cls >= 0)
+            rank = atomicAdd(h_count + cls, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumClasses && h_count[threadIdx.x])      // the workgroup's stretch of the class's list
+        h_base[threadIdx.x] = (u32)atomicAdd(reinterpret_cast<unsigned long long *>(bases + kNumClasses + 1 + threadIdx.x),
+                                             (unsigned long long)h_count[threadIdx.x]);
+    __syncthreads();
+    if (cls >= 0)
+        list[bases[cls] + h_base[cls] + rank] = (u32)b;
 }
 
 // Block size for the tiled kernel: a multiple of 64 that U divides (so every column a lane
@@ -908,7 +1003,10 @@ hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     return hipSuccess;
 }
 
-u64 mul_ragged_plan_scratch_words(u64 batch) { return kPlanHeadWords + (batch + 1023) / 1024 + 1; }
+// [head][one partial per 1024-pair chunk][class bases + cursors][class lists: one u32 per pair]
+static u64 plan_bases_at(u64 batch) { return kPlanHeadWords + (batch + 1023) / 1024 + 1; }
+static u64 plan_lists_at(u64 batch) { return plan_bases_at(batch) + 2 * kNumClasses + 2; }
+u64 mul_ragged_plan_scratch_words(u64 batch) { return plan_lists_at(batch) + (batch + 1) / 2 + 1; }
 u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
 
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
@@ -917,7 +1015,7 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
     // d_work: [plan4 (total, max t1, max t2, max t1*t2)][huge count][huge records][one partial per 1024-pair chunk]
     u64 *plan4 = d_work, *huge = d_work + 4, *partial = d_work + kPlanHeadWords;
     const u64 nchunks = (batch + 1023) / 1024;
-    hipError_t e = zero_words(d_work, mul_ragged_plan_scratch_words(batch), s);       // (a kernel: see zero_words)
+    hipError_t e = zero_words(d_work, plan_lists_at(batch), s);       // head, partials, class bases (a kernel: see zero_words)
     if (e != hipSuccess)
         return e;
     if (nchunks > kMaxBlocks256)
@@ -925,8 +1023,17 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
     if (batch)
         k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
     k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
-    if (batch)
-        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge);
+    if (batch) {
+        // the size-class lists (and the histogram's global atomics) only when the multiply is going to use them
+        const bool classes = csgn::tune(TUNE_RAGGED_CLASSES) == 1;
+        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge, classes ? 1u : 0u);
+        if (classes) {
+            u64 *bases = d_work + plan_bases_at(batch);
+            k_class_bases<<<1, 1, 0, s>>>(d_work, bases);
+            k_class_lists<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, offL, offR, bases,
+                                                                   reinterpret_cast<u32 *>(d_work + plan_lists_at(batch)));
+        }
+    }
     return hipGetLastError();
 }
 
@@ -934,8 +1041,16 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
 // an explicit csgn_mul_plan object of the caller (round 4; round 3 kept it in hidden per-thread state
 // matched by array addresses, which a caller that rewrote offsets in place could fool -- ADVICE r3).
 void mul_plan_notes_from_head(MulPlanNotes &r, const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch,
-                              const u64 *h_head)
+                              const u64 *h_head, const u64 *d_work)
 {
+    static_assert(kNumClasses == 28, "MulPlanNotes is sized for 28 classes");
+    r.lists = d_work ? reinterpret_cast<const u32 *>(d_work + plan_lists_at(batch)) : nullptr;
+    r.cls_base[0] = 0;
+    for (u32 c = 0; c < kNumClasses; ++c) {
+        r.cls_pairs[c] = h_head[kClassAt + c];
+        r.cls_terms[c] = h_head[kClassAt + kNumClasses + c];
+        r.cls_base[c + 1] = r.cls_base[c] + r.cls_pairs[c];
+    }
     r.offL = offL;
     r.offR = offR;
     r.offOut = offOut;
@@ -1036,6 +1151,54 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     const u64 total_units = total_out_terms * U;
     const FastDiv dU = csgn_fastdiv_make(U);
+    // Size classes (round 4; an experiment kept behind a knob): in a long-tailed batch of small pairs
+    // nearly every 16 KiB turn of the CSR kernel pays the offset window and a 9-step search (3.7 TB/s at a log-normal
+    // mean of 8 x 8 terms).  With the plan's lists at hand, every
+    // non-empty class gets ONE launch of the LDS-tiled kernel shaped for the class (pair = list[block / tiles]; a
+    // pair smaller than its class leaves early from the tiles it does not fill: at most 2x per side), and the CSR
+    // kernel below skips what they wrote.
+    u32 skip_t1 = 0, skip_t2 = 0;
+    bool only_classes = false;
+    {
+        static const MulPlanNotes kNone = MulPlanNotes();
+        const MulPlanNotes &cn = notes ? *notes : kNone;
+        const bool match = notes && cn.lists && cn.offL == offL && cn.offR == offR && cn.offOut == offOut &&
+                           cn.batch == batch && cn.total == total_out_terms;
+        u64 class_terms = 0;
+        for (u32 c = 0; c < kNumClasses; ++c)
+            class_terms += cn.cls_terms[c];
+        // MEASURED SLOWER (profiles/r04/ragged_size_classes.log: log-normal mean 8 x 8 2.6 TB/s against the CSR kernel's
+        // 3.6, mean 16 x 16 2.8 against 4.4, mean 32 x 32 3.6 against 5.4): every class launch writes a sparse subset
+        // of the output and a third to a half of its workgroups find nothing to do.  Off unless knob ragged_classes = 1
+        // (the plan only builds the lists then).
+        const bool want = csgn::tune(TUNE_RAGGED_CLASSES) == 1;
+        if (match && wide && !d_gate && want && class_terms && csgn::tune(TUNE_RAGGED_FLAT) == 0) {
+            for (u32 c = 0; c < kNumClasses; ++c) {
+                if (!cn.cls_pairs[c])
+                    continue;
+                MulArgs a = {};
+                a.L = L;
+                a.R = R;
+                a.out = out;
+                a.offL = offL;
+                a.offR = offR;
+                a.offOut = offOut;
+                a.t1 = class_max_t1((int)c);
+                a.t2 = class_max_t2((int)c);
+                a.pair_list = cn.lists + cn.cls_base[c];
+                const u32 cu = a.t2 * U;
+                const u32 bs = cu <= 64u ? 64u : cu <= 128u ? 128u : 256u;
+                const hipError_t e = launch_tiled<unit16, true>(a, cn.cls_pairs[c], U, s, bs, 8u);
+                if (e != hipSuccess)
+                    return e;
+            }
+            skip_t1 = kClsMaxT1;
+            skip_t2 = kClsMaxT2;
+            only_classes = class_terms == total_out_terms;
+        }
+    }
+    if (only_classes)
+        return hipSuccess;
     // 4 KiB chunks per workgroup: as many as 8 while the grid keeps >= 8192 workgroups (ragged_chunks).  Round 3,
     // cold, profiles/r03/bench_ragged.log: on the 2.8 GB log-normal batch C=4 and C=8 are within run-to-run noise
     // (5.1-5.5 TB/s each over three runs), C=16 4.85, C=2 5.2, C=1 3.9; the 178 MB skewed batch C=1 4.74, C=2 4.66,
@@ -1104,11 +1267,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             k_mul_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                               \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
                 reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs,  \
-                d_gate);                                                                            \
+                d_gate, skip_t1, skip_t2);                                                          \
         else                                                                                        \
             k_mul_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
                                                                     (u32)batch, u0, u0 + nu, U, dU, \
-                                                                    pf_pairs, d_gate);              \
+                                                                    pf_pairs, d_gate, skip_t1, skip_t2); \
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \

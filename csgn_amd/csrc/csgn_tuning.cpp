@@ -23,7 +23,7 @@ const Knob kKnobs[TUNE_COUNT] = {
     {"ragged_touch", 1}, {"ragged_m", 4},      {"perm_ballot", 0},   {"perm_narrow", 0},
     {"perm_waves", 0},   {"perm_persist", 1},  {"dec_loop", 0},
     {"enc_lds", 0},      {"enc_wave", 1},      {"enc_compact", -1},  {"shared_gpu", 0},
-    {"compact_tag_bits", 0}, {"compact_nt", 1}, {"compact_grid", 0},
+    {"compact_tag_bits", 0}, {"compact_nt", 1}, {"compact_grid", 0}, {"ragged_classes", 0},
 };
 
 // Knob values are PER HOST THREAD: a thread that sets a knob changes the dispatch of its own later

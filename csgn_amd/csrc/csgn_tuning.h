@@ -37,6 +37,7 @@ enum TuneKey {
     TUNE_COMPACT_TAG_BITS, // compaction: hash-tag bits the tables keep, 0 = all (a test narrows them to force the collision path)
     TUNE_COMPACT_NT,     // compaction: 1 = non-temporal stores of the surviving terms
     TUNE_COMPACT_GRID,   // compaction: workgroups of the main kernel, 0 = 512 (two per CU)
+    TUNE_RAGGED_CLASSES, // planned ragged multiply: 1 = the plan lists small pairs by size class and the multiply gives every class its own tiled launch (measured slower than the CSR kernel: off by default)
     TUNE_COUNT
 };
 

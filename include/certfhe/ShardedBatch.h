@@ -53,6 +53,11 @@ class ShardGroup {
     std::string collective() const;
     // Longest wait for peers in a collective, in milliseconds (default 120 000; 0 = for ever).
     void setTimeoutMs(uint64_t ms);
+    // csgn_set_tuning(key, value) on EVERY worker thread of the group.  The library's knobs are per host thread
+    // (include/csgn_hip.h, "tuning"), and a ShardedBatch's kernels are launched by the group's worker threads:
+    // csgn_set_tuning from the application thread -- e.g. "shared_gpu" = 1 on co-tenant GPUs -- does not reach
+    // them; this does.  (The CSGN_* environment snapshot reaches every thread either way.)
+    void setTuning(const std::string &key, int value);
     // TEST HOOK: the next task of `rank` throws before doing anything (exercises the failure path).
     void injectFailure(int rank);
     // TEST HOOK: gathers take the uneven-shard (grouped ncclBroadcast) form even for equal shards.

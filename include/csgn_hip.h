@@ -77,6 +77,10 @@ int csgn_free(void *d_ptr);
  * C++ classes for the one-byte answer of SecretKey::decrypt. */
 int csgn_host_alloc(void **h_ptr, void **d_alias, size_t bytes);
 int csgn_host_free(void *h_ptr);
+/* Host-buffer lifetime: h_src / h_dst belong to the call until `stream` has passed the copy.  From or to
+ * pageable memory the runtime happens to stage the copy before it returns, but that is not part of this
+ * contract: synchronise the stream (or use csgn_host_alloc memory that outlives it) before freeing or
+ * reusing the buffer. */
 int csgn_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int csgn_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int csgn_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);

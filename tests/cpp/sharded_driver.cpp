@@ -124,6 +124,22 @@ static int cmd_compare(uint64_t count, uint64_t n_bits, uint64_t d_key)
         ++sum;
     }
     CHECK(prev == count && sum == group.size(), "shards cover the batch");
+    // knobs are per host thread: setTuning reaches the worker threads (a knob that selects another kernel for the
+    // same words -- results must not move; an unknown knob is an exception from the worker, not silence)
+    {
+        group.setTuning("mul_flat", -1);
+        ShardedBatch x = ShardedBatch::synthetic(group, ctx, count, 3, 11) * ShardedBatch::synthetic(group, ctx, count, 5, 12);
+        group.setTuning("mul_flat", 0);
+        ShardedBatch y = ShardedBatch::synthetic(group, ctx, count, 3, 11) * ShardedBatch::synthetic(group, ctx, count, 5, 12);
+        CHECK(x.digest() == y.digest(), "setTuning on the workers: same words under another kernel");
+        bool threw = false;
+        try {
+            group.setTuning("no_such_knob", 1);
+        } catch (const std::exception &) {
+            threw = true;
+        }
+        CHECK(threw, "setTuning: an unknown knob is an exception");
+    }
     CHECK(group.healthy(), "group healthy at the end");
     return failures ? 1 : 0;
 }

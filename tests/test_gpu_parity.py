@@ -2309,6 +2309,56 @@ def test_ragged_long_tailed_small_pairs(hip, oracle, knobs, n, mu, batch):
         assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
 
 
+@pytest.mark.parametrize("n", [1247, 4096])
+def test_ragged_size_classes_match_the_csr_kernel(hip, oracle, knobs, n):
+    """Size classes (round 4; measured slower than the CSR kernel and therefore off unless knob ragged_classes = 1):
+    the plan lists the small pairs (t1 <= 64, t2 <= 128) by class, the multiply gives every class one LDS-tiled launch
+    shaped for it and the CSR kernel skips what they wrote.  A batch that visits every
+    class boundary (1, 8, 9, 16, 17, 32, 33, 64, 65 x 1, 2, 3, 4, 5, ... 128, 129 terms), empty pairs, runs of tiny
+    pairs and pairs with one long side: on (knob 1) and off (the default) give the same words;
+    samples of every kind equal the oracle.  A batch with small pairs ONLY never launches the CSR kernel."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n)
+    edge1 = [0, 1, 7, 8, 9, 16, 17, 32, 33, 64, 65, 100]
+    edge2 = [0, 1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 200]
+    pairs = [(a, b) for a in edge1 for b in edge2] * 2
+    pairs += [(int(a), int(b)) for a, b in zip(np.clip(rng.lognormal(2, 1, 3000), 1, 300).astype(int),
+                                                np.clip(rng.lognormal(2, 1, 3000), 1, 300).astype(int))]
+    pairs += [(1, 1)] * 700 + [(300, 2), (2, 300), (0, 5), (70, 70)]
+    order = rng.permutation(len(pairs))
+    t1s = np.array([pairs[i][0] for i in order]); t2s = np.array([pairs[i][1] for i in order])
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    L = hip.synth_fill(95, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(96, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    knobs.set("ragged_classes", 0)
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+    ref = ref.clone()
+    knobs.set("ragged_classes", 1)                          # the plan builds the lists, the multiply uses them
+    out, off = hip.mul_ragged(n, L, dOL, R, dOR)
+    assert torch.equal(off, ref_off) and torch.equal(out, ref)
+    mo = hip.download(ref_off)
+    hl, hr = hip.download(L), hip.download(R)
+    picks = set(rng.integers(0, len(pairs), 60).tolist()) | {0, len(pairs) - 1}
+    for b in sorted(picks):
+        if t1s[b] and t2s[b]:
+            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+            assert np.array_equal(hip.download(ref[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+    # small pairs only: class launches alone
+    small = (t1s <= 64) & (t2s <= 128)
+    t1b, t2b = t1s[small], t2s[small]
+    oL, oR = csr(t1b.tolist()), csr(t2b.tolist())
+    Lb = hip.synth_fill(97, n, 0, int(oL[-1]) * dl)
+    Rb = hip.synth_fill(98, n, 0, int(oR[-1]) * dl)
+    knobs.set("ragged_classes", 0)
+    ref2, ref2_off = hip.mul_ragged(n, Lb, hip.upload(oL), Rb, hip.upload(oR))
+    ref2 = ref2.clone()
+    knobs.set("ragged_classes", 1)
+    out2, off2 = hip.mul_ragged(n, Lb, hip.upload(oL), Rb, hip.upload(oR))
+    assert torch.equal(out2, ref2) and torch.equal(off2, ref2_off)
+
+
 @pytest.mark.parametrize("n,lo,hi,batch", [(1247, 0, 6, 300000), (1247, 4, 13, 60000), (4096, 1, 9, 40000), (128, 0, 6, 200000)])
 def test_ragged_batches_of_small_pairs(hip, oracle, knobs, n, lo, hi, batch):
     """Batches of SMALL pairs (0..5, 4..12, 1..8 terms; also N=128 with its one-unit terms): by default the tiled kernel

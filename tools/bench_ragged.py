@@ -11,6 +11,9 @@ VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_R
           ('cold C=1',{'CSGN_RAGGED_C':'1'}),('cold C=2',{'CSGN_RAGGED_C':'2'}),('cold C=4',{'CSGN_RAGGED_C':'4'}),('cold C=4 M=2',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'2'}),('cold C=4 M=1',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'1'}),
           ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('cold C=16',{'CSGN_RAGGED_C':'16'}),('cold C=8 M=2',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_M':'2'}),('cold C=8 no pf',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_PF':'0'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
           ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
+if os.environ.get('SHORT'):          # SHORT=1: the default dispatch, size classes off, CSR kernel alone
+    VARIANTS=[('cold',{}),('cold, size classes off',{'CSGN_RAGGED_CLASSES':'0'}),('same operands',{'NSETS':'1'}),
+              ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
@@ -30,7 +33,10 @@ def csr(c):
     o=np.zeros(len(c)+1,dtype=np.uint64); o[1:]=np.cumsum(np.asarray(c,dtype=np.uint64)); return o
 n=1247; dl=20
 rng=np.random.default_rng(0)
+lg=lambda mean,cnt,cap: np.clip(rng.lognormal(np.log(mean)-0.5,1,cnt),1,cap).astype(int)
 for name,t1s,t2s in [
+    ("lognormal mean~8 x262144 (long tail)", lg(8,1<<18,600), lg(8,1<<18,600)),
+    ("lognormal mean~16 x65536 (long tail)", lg(16,1<<16,1000), lg(16,1<<16,1000)),
     ("uniform 64x64 x4096", [64]*4096, [64]*4096),
     ("lognormal mean~32 x16384", np.clip(rng.lognormal(3,1,16384),1,2000).astype(int), np.clip(rng.lognormal(3,1,16384),1,2000).astype(int)),
     ("one 1024x1024 + 65535 1x1", [1024]+[1]*65535, [1024]+[1]*65535),
