@@ -89,13 +89,19 @@ class HipPath:
         dl = self.default_len(n_bits)
         off_out = self.empty_words(batch + 1)
         plan = (C.c_uint64 * 4)()
-        if getattr(self, "_plan", None) is None:           # one plan object per path: its device block is grow-only
-            self._plan = self.mul_plan()
-        check(self.lib.csgn_mul_plan_ragged(self._plan, batch, _ptr(off_left), _ptr(off_right), _ptr(off_out),
+        # one plan object per path AND host thread (a csgn_mul_plan is used by one thread at a time); its
+        # device block is grow-only, so the plan costs no allocation after the first call
+        import threading
+        if getattr(self, "_plans", None) is None:
+            self._plans = threading.local()
+        if getattr(self._plans, "handle", None) is None:
+            self._plans.handle = self.mul_plan()
+        handle = self._plans.handle
+        check(self.lib.csgn_mul_plan_ragged(handle, batch, _ptr(off_left), _ptr(off_right), _ptr(off_out),
                                             C.byref(plan), self.stream))
         total = int(plan[0])
         out = self.empty_words(max(total * dl, 1))
-        check(self.lib.csgn_mul_planned(self._plan, n_bits, _ptr(left), _ptr(right), _ptr(out), self.stream))
+        check(self.lib.csgn_mul_planned(handle, n_bits, _ptr(left), _ptr(right), _ptr(out), self.stream))
         return out[: total * dl], off_out
 
     def mul_plan(self) -> C.c_void_p:

@@ -489,15 +489,19 @@ int csgn_mul_plan_validate(csgn_mul_plan *plan, void *stream)
         (void)hipFree(plan->d_sum);
         plan->d_sum = nullptr;
     }
+    const u32 slots = csgn::offsets_checksum_words();
     if (!plan->d_sum) {
-        HIP_TRY(hipMalloc((void **)&plan->d_sum, 8));
+        HIP_TRY(hipMalloc((void **)&plan->d_sum, slots * 8));
         plan->device = dev;
     }
     const csgn::MulPlanNotes &n = plan->notes;
     HIP_TRY(csgn::offsets_checksum(n.batch, n.offL, n.offR, n.offOut, plan->d_sum, S(stream)));
-    u64 now = 0;
-    HIP_TRY(hipMemcpyAsync(&now, plan->d_sum, 8, hipMemcpyDeviceToHost, S(stream)));
+    std::vector<u64> part(slots, 0);
+    HIP_TRY(hipMemcpyAsync(part.data(), plan->d_sum, slots * 8, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
+    u64 now = 0;
+    for (u64 v : part)
+        now += v;
     if (now != n.checksum)
         return fail(CSGN_ERR_INVALID, "the offset arrays changed since csgn_mul_plan_ragged: plan again");
     return CSGN_OK;

@@ -44,9 +44,11 @@ struct MulPlanNotes {
 // notes -- a csgn_mul_plan owns one --, nullptr otherwise
 void mul_plan_notes_from_head(MulPlanNotes &notes, const u64 *offL, const u64 *offR, const u64 *offOut, u64 batch,
                               const u64 *h_head, const u64 *d_work);
+u32 offsets_checksum_words();          // d_sum of offsets_checksum: this many words, to be added up on the host
 hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s);
+// gate (csgn_mul_ragged_async only): three device words the last plan kernel fills for the kernels behind it
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
-                           hipStream_t s);
+                           hipStream_t s, u64 *gate = nullptr, u64 capacity_terms = 0, bool can_stream = false);
 // notes: what the plan of exactly these offset arrays learned about huge pairs and operand size (nullptr: nothing;
 // a circuit's offsets never came from a plan).  operand_terms: left + right terms of the whole batch when the
 // caller knows them (a circuit does: its shapes are static), 0 = unknown; sizes the output slices of a large product.

@@ -396,8 +396,12 @@ __host__ __device__ inline int class_of(u64 t1, u64 t2)
 inline u32 class_max_t1(int cls) { return 8u << (cls / (int)kClsCols); }
 inline u32 class_max_t2(int cls) { return 2u << (cls % (int)kClsCols); }
 
-constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 3 + 2 * kNumClasses;  // [plan4][huge count][records][left terms, right terms of the batch][offsets checksum][class pairs][class terms]
-constexpr u64 kClassAt = 4 + 1 + kHugeRecords * 6 + 3;      // first class word of the head
+// the checksum of the offset arrays is accumulated in kSumSlots words (workgroup b adds to slot b % kSumSlots: one
+// word would take every workgroup's atomic in turn, ~11 ns each) and summed on the host
+constexpr u32 kSumSlots = 64;
+constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 2 + kSumSlots + 2 * kNumClasses;  // [plan4][huge count][records][left terms, right terms of the batch][checksum slots][class pairs][class terms]
+constexpr u64 kSumAt = 4 + 1 + kHugeRecords * 6 + 2;       // first checksum slot of the head
+constexpr u64 kClassAt = kSumAt + kSumSlots;                // first class word of the head
 
 // one pair's share of the checksum of the offset arrays
 __device__ inline u64 offsets_mix(u64 b, u64 l, u64 r, u64 o)
@@ -449,16 +453,25 @@ __global__ void __launch_bounds__(256) k_plan_chunks(u64 batch, const u64 *__res
             offOut[b0 + j] = run;                      // chunk-local; k_plan_fix adds the chunk base
         run += c[j];
     }
-    // wave-level maxima, then one atomic per wave
+    // workgroup maxima, then an atomic only where the workgroup would RAISE the running maximum: atomics on one
+    // word complete at ~11 ns apiece chip-wide, and a wave's worth per chunk (48 K of them at a million pairs) was
+    // most of a plan's 200 us; nearly every workgroup now sees that it has nothing to add
+    __shared__ u64 wmax[3][4];
     for (int off = 32; off > 0; off >>= 1) {
         m1 = max(m1, (u64)__shfl_down(m1, off, 64));
         m2 = max(m2, (u64)__shfl_down(m2, off, 64));
         mp = max(mp, (u64)__shfl_down(mp, off, 64));
     }
     if ((tid & (kWave - 1)) == 0) {
-        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1), m1);
-        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 2), m2);
-        atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 3), mp);
+        wmax[0][tid >> 6] = m1;
+        wmax[1][tid >> 6] = m2;
+        wmax[2][tid >> 6] = mp;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const u64 m = max(max(wmax[tid][0], wmax[tid][1]), max(wmax[tid][2], wmax[tid][3]));
+        if (m > __hip_atomic_load(plan4 + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1 + tid), m);
     }
 }
 
@@ -472,17 +485,28 @@ __global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 ba
     u64 sum = 0;
     for (u64 c = c0; c < c1; ++c)
         sum += partial[c];
-    part[tid] = sum;
+    // exclusive scan of the 1024 per-thread sums: wave scans by shuffle, then the 16 wave totals (a serial loop
+    // over all 1024 in one thread was 12 of this kernel's 13 microseconds)
+    __shared__ u64 wtot[16];
+    const u32 lane = tid & (kWave - 1), wv = tid >> 6;
+    u64 incl = sum;
+    for (u32 d = 1; d < kWave; d <<= 1) {
+        const u64 nb = (u64)__shfl_up(incl, d, kWave);
+        if (lane >= d)
+            incl += nb;
+    }
+    if (lane == kWave - 1)
+        wtot[wv] = incl;
     __syncthreads();
+    u64 wbase = 0, all = 0;
+    for (u32 w = 0; w < 16; ++w) {
+        wbase += w < wv ? wtot[w] : 0ull;
+        all += wtot[w];
+    }
+    part[tid] = wbase + incl - sum;
     if (tid == 0) {
-        u64 run = 0;
-        for (u32 t = 0; t < 1024; ++t) {
-            const u64 v = part[t];
-            part[t] = run;
-            run += v;
-        }
-        offOut[batch] = run;
-        plan4[0] = run;
+        offOut[batch] = all;
+        plan4[0] = all;
     }
     __syncthreads();
     u64 run = part[tid];
@@ -499,7 +523,8 @@ __global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 ba
 // all inside 99 % of a skewed batch's output) and runs the CSR kernel on the stretches between them.
 __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
                                                   const u64 *__restrict__ offL, const u64 *__restrict__ offR,
-                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge, u32 classes)
+                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge, u32 classes,
+                                                  u64 *__restrict__ gate, u64 capacity_terms, u32 can_stream)
 {
     const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
     if (b == 0) {                                   // operand totals: what sizes the slices of a large product
@@ -514,8 +539,19 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
     }
     __syncthreads();
     u64 mix = 0;
-    if (b == batch)
+    if (b == batch) {
         mix = offsets_mix(b, offL[b], offR[b], offOut[b]);
+        if (gate) {
+            // csgn_mul_ragged_async: what the kernels behind this one may do (totals are final: k_plan_scan_partials ran)
+            const u64 *plan4 = huge - 4;
+            const u64 total = plan4[0];
+            const bool fits = total <= capacity_terms;
+            const bool ones = can_stream && fits && total == batch && plan4[3] == 1ull;   // every pair 1 x 1: the plain AND stream
+            gate[0] = (fits && !ones) ? total : 0ull;
+            gate[1] = fits ? 0ull : 1ull;
+            gate[2] = ones ? total : 0ull;
+        }
+    }
     if (b < batch) {
         const u64 o = offOut[b] + partial[b >> 10];
         offOut[b] = o;
@@ -535,12 +571,16 @@ __global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restri
         }
     }
     // checksum of the three offset arrays as planned (csgn_mul_plan_validate recomputes it later)
+    __shared__ u64 wsum[4];
     for (int off = 32; off > 0; off >>= 1)
         mix += (u64)__shfl_down(mix, off, 64);
-    if ((threadIdx.x & (kWave - 1)) == 0 && mix)
-        atomicAdd(reinterpret_cast<unsigned long long *>(huge + 3 + kHugeRecords * 6), mix);
-    // the workgroup's class histogram: one global atomic per class it met
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        wsum[threadIdx.x >> 6] = mix;
     __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(huge - 4 + kSumAt + (blockIdx.x % kSumSlots)),
+                  (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+    // the workgroup's class histogram: one global atomic per class it met
     if (threadIdx.x < kNumClasses && h_pairs[threadIdx.x]) {
         u64 *cls = huge - 4 + kClassAt;                          // `huge` = head + 4
         atomicAdd(reinterpret_cast<unsigned long long *>(cls + threadIdx.x), (unsigned long long)h_pairs[threadIdx.x]);
@@ -1010,7 +1050,7 @@ u64 mul_ragged_plan_scratch_words(u64 batch) { return plan_lists_at(batch) + (ba
 u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
 
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
-                           hipStream_t s)
+                           hipStream_t s, u64 *gate, u64 capacity_terms, bool can_stream)
 {
     // d_work: [plan4 (total, max t1, max t2, max t1*t2)][huge count][huge records][one partial per 1024-pair chunk]
     u64 *plan4 = d_work, *huge = d_work + 4, *partial = d_work + kPlanHeadWords;
@@ -1026,7 +1066,8 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
     if (batch) {
         // the size-class lists (and the histogram's global atomics) only when the multiply is going to use them
         const bool classes = csgn::tune(TUNE_RAGGED_CLASSES) == 1;
-        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge, classes ? 1u : 0u);
+        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge, classes ? 1u : 0u,
+                                                                gate, capacity_terms, can_stream ? 1u : 0u);
         if (classes) {
             u64 *bases = d_work + plan_bases_at(batch);
             k_class_bases<<<1, 1, 0, s>>>(d_work, bases);
@@ -1059,7 +1100,9 @@ void mul_plan_notes_from_head(MulPlanNotes &r, const u64 *offL, const u64 *offR,
     r.max_t1 = h_head[1];
     r.max_t2 = h_head[2];
     r.operand_terms = h_head[5 + kHugeRecords * 6] + h_head[6 + kHugeRecords * 6];
-    r.checksum = h_head[7 + kHugeRecords * 6];
+    r.checksum = 0;
+    for (u32 i = 0; i < kSumSlots; ++i)
+        r.checksum += h_head[kSumAt + i];
     const u64 count = h_head[4];
     r.n = (u32)std::min<u64>(count, kHugeRecords);
     for (u32 i = 0; i < r.n; ++i)
@@ -1080,15 +1123,22 @@ __global__ void __launch_bounds__(256) k_offsets_checksum(u64 batch, const u64 *
     u64 mine = 0;
     for (u64 b = (u64)blockIdx.x * 256u + threadIdx.x; b <= batch; b += (u64)gridDim.x * 256u)
         mine += offsets_mix(b, offL[b], offR[b], offOut[b]);
+    __shared__ u64 wsum[4];
     for (int off = 32; off > 0; off >>= 1)
         mine += (u64)__shfl_down(mine, off, 64);
     if ((threadIdx.x & (kWave - 1)) == 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(sum), mine);
+        wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(sum + (blockIdx.x % kSumSlots)),
+                  (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
 }
+
+u32 offsets_checksum_words() { return kSumSlots; }
 
 hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s)
 {
-    hipError_t e = zero_words(d_sum, 1, s);
+    hipError_t e = zero_words(d_sum, kSumSlots, s);
     if (e != hipSuccess)
         return e;
     const u32 blocks = (u32)std::min<u64>((batch + 256) / 256, 2048);
@@ -1342,17 +1392,6 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
 constexpr u64 kGateWords = 8;
 u64 mul_ragged_async_plan_words(u64 batch) { return kGateWords + mul_ragged_plan_scratch_words(batch); }
 
-__global__ void k_async_gate(const u64 *__restrict__ plan4, u64 batch, u64 capacity_terms, u32 can_stream,
-                             u64 *__restrict__ gate)
-{
-    const u64 total = plan4[0];
-    const bool fits = total <= capacity_terms;
-    const bool ones = can_stream && fits && total == batch && plan4[3] == 1ull;    // every pair 1 x 1: the plain AND stream
-    gate[0] = (fits && !ones) ? total : 0ull;
-    gate[1] = fits ? 0ull : 1ull;
-    gate[2] = ones ? total : 0ull;
-}
-
 // the 1x1 stream of k_and_stream, its length read from the gate (0: some other kernel has the batch)
 template <typename Unit>
 __global__ void __launch_bounds__(256) k_and_stream_gated(const Unit *__restrict__ a, const Unit *__restrict__ b,
@@ -1373,15 +1412,15 @@ hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL
     if (batch >= (1ull << 32))
         return hipErrorInvalidValue;
     u64 *gate = d_plan, *work = d_plan + kGateWords;
-    hipError_t e = mul_ragged_plan(batch, offL, offR, offOut, work, s);
-    if (e != hipSuccess)
-        return e;
     // a batch of 1x1 pairs (fresh ciphertexts handed over as CSR): the stream kernel, if the gate says so
     const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
     const u32 U = (u32)(wide ? dL / 2 : dL);
     const u64 stream_blocks = (batch * U + 255) / 256;
     const bool can_stream = capacity_terms >= batch && stream_blocks <= kMaxBlocks256;
-    k_async_gate<<<1, 1, 0, s>>>(work, batch, capacity_terms, can_stream ? 1u : 0u, gate);
+    // the plan kernels; the last of them also writes the gate (real output terms / does not fit / all pairs 1x1)
+    hipError_t e = mul_ragged_plan(batch, offL, offR, offOut, work, s, gate, capacity_terms, can_stream);
+    if (e != hipSuccess)
+        return e;
     if (capacity_terms == 0)
         return hipGetLastError();
     if (can_stream) {

@@ -1288,7 +1288,7 @@ def test_concurrent_host_threads_on_separate_streams(hip, oracle):
 
 def test_concurrent_host_threads_ragged_plans_encrypt_and_permute(hip, oracle):
     """Per-host-thread state of the library under concurrency: every thread plans its OWN skewed CSR batch (one
-    pair of >= 24 MB of output, so csgn_mul_ragged consults the plan its thread remembered), draws keyed
+    pair of >= 24 MB of output, multiplied by the thread's own csgn_mul_plan object), draws keyed
     ciphertexts and permutes them, each on its own stream, four threads at once.  A plan remembered by one
     thread must never steer another thread's multiply; all results equal the oracle's."""
     import threading
