@@ -65,6 +65,8 @@ python3 bench.py --native-ranks > $OUT/bench_native_ranks.json 2> $OUT/bench_nat
 python3 bench.py --native-ranks --force-collective --no-cpu-baseline > $OUT/bench_native_ranks_collective.json 2>> $OUT/bench_native_ranks.err; echo "native+collective rc=$?"
 python3 tools/bench_compact.py --json $OUT/compact.json > $OUT/compact.log 2>&1; echo "compact rc=$?"
 tests/cpp/dropin_driver wirebench > $OUT/wirebench.log 2>&1; echo "wirebench rc=$?"
+(python3 tools/prof_compact_phases.py 0.0; python3 tools/prof_compact_phases.py 0.5; python3 tools/prof_compact_phases.py 0.95) 2>&1 | grep -v amdgpu > $OUT/compact_phases.log; echo "phases rc=$?"
+SHORT=1 python3 tools/bench_ragged.py 2>&1 | grep -v amdgpu | grep -E "^mul_ragged|kernel only|async" > $OUT/bench_ragged_short.log; echo "ragged short rc=$?"
 if [ "$1" != "quick" ]; then
   python3 tools/bench_ragged.py > $OUT/bench_ragged.log 2>&1; echo "ragged rc=$?"
   python3 tools/bench_ops.py --json $OUT/ops.json > $OUT/ops.log 2>&1; echo "ops rc=$?"
