@@ -420,9 +420,10 @@ __host__ __device__ inline size_t main_lds_bytes(u32 capT)
     return (size_t)capT * (8 + 4 + 4 + 4 + 4) + 64 + (size_t)(kCT / kWave) * kSub * kWave * 8;
 }
 
-// Unit j of a group sits in wave w = j / (64 R), register row i = (j / 64) % R, lane j % 64: every wave
-// owns a contiguous span of 64 R units (coalesced 1 KiB wave loads all the same), so the hashes of a
-// term's units meet inside ONE wave.
+// Unit j of a group sits in wave w = j / (64 rows), register row i = (j / 64) % rows, lane j % 64, with
+// rows = the group's 64-unit rows dealt evenly over the eight waves (20 for a full group): every wave owns
+// a contiguous span of 64 rows units (coalesced 1 KiB wave loads all the same), so the hashes of a term's
+// units meet inside ONE wave.
 template <typename Unit, int R>
 __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs a)
 {
@@ -483,7 +484,11 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
         asm volatile("" : "+v"(tid));
         lane = tid & (kWave - 1);
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const u32 j0 = wave * (kWave * R) + lane;
+        // rows of 64 units per wave: the group's rows dealt evenly over the waves (a half-full group keeps every
+        // wave busy for half the rows instead of half the waves for all of them)
+        const u32 rows = min((u32)R, ((nunits + kWave - 1u) / kWave + kCT / kWave - 1u) / (kCT / kWave));
+        const u32 span = rows * kWave;                            // units per wave
+        const u32 j0 = wave * span + lane;
         CSGN_STAMP(1);
 
         // 1. the group's units -> registers
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const u32 j = j0 + (u32)i * kWave;
-            reg[i] = j < nunits ? terms[ub + j] : unit_zero<Unit>();
+            reg[i] = ((u32)i < rows && j < nunits) ? terms[ub + j] : unit_zero<Unit>();
         }
         for (u32 x = tid; x < nt; x += kCT) {
             s_node[x] = 0ull;
@@ -519,7 +524,9 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
                 UnitPos pos = walk_first(walk, jh);
 #pragma unroll
                 for (int r = 0; r < R / kSub; ++r) {
-                    const u32 w0 = wave * (kWave * R) + (u32)r * (kSub * kWave);      // first unit of the strip
+                    if ((u32)(r * kSub) >= rows)                  // wave-uniform: the wave's rows are done
+                        break;
+                    const u32 w0 = wave * span + (u32)r * (kSub * kWave);             // first unit of the strip
 #pragma unroll
                     for (int q = 0; q < kSub; ++q) {
                         part[q * (int)kWave + (int)lane] = unit_hash(reg[r * kSub + q], pos.k);
@@ -527,7 +534,7 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (w0 < nunits) {                            // wave-uniform
-                        const u32 w1 = min(w0 + kSub * kWave, nunits);
+                        const u32 w1 = min(min(w0 + kSub * kWave, (wave + 1u) * span), nunits);
                         const u32 tf = csgn_fastdiv(w0, a.dU), tl = csgn_fastdiv(w1 - 1u, a.dU);
                         for (u32 t = tf + lane; t <= tl; t += kWave) {
                             const u32 u0 = max(t * U, w0), u1 = min(t * U + U, w1);
@@ -615,15 +622,35 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
                 asm volatile("" : "+v"(jv));
                 UnitPos pos = walk_first(walk, jv);
                 bool bad = false;
+                constexpr int VB = 2;                              // rows whose loads travel together (4 spill a data register)
+                static_assert(R % VB == 0, "verify batches must tile the register rows");
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const u32 j = jv + (u32)i * kWave;
-                    if (j < nunits) {
-                        const u32 rep = s_rep[pos.t];
-                        if (rep != pos.t)
-                            bad |= !unit_same(terms[(tb + rep) * U + pos.k], reg[i]);
+                for (int r = 0; r < R / VB; ++r) {
+                    // every lane loads SOMETHING valid (its representative's unit, or its own unit again) so that the
+                    // VB loads of a batch are issued back to back instead of one per branch; a batch in which no lane
+                    // of the wave joined anybody is skipped (wave-uniform)
+                    u32 at[VB];                                    // unit index inside the group
+                    bool need[VB];
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < VB; ++q) {
+                        const u32 j = jv + (u32)(r * VB + q) * kWave;
+                        const bool in = (u32)(r * VB + q) < rows && j < nunits;
+                        const u32 rep = in ? s_rep[pos.t] : 0u;
+                        need[q] = in && rep != pos.t;
+                        at[q] = need[q] ? rep * U + pos.k : (in ? j : 0u);
+                        any = any || need[q];
+                        walk_next(walk, pos);
                     }
-                    walk_next(walk, pos);
+                    if (__ballot(any) != 0ull) {
+                        Unit other[VB];
+#pragma unroll
+                        for (int q = 0; q < VB; ++q)
+                            other[q] = terms[ub + at[q]];
+#pragma unroll
+                        for (int q = 0; q < VB; ++q)
+                            bad |= need[q] && !unit_same(other[q], reg[r * VB + q]);
+                    }
                 }
                 if (bad)
                     s_bad = 1u;
@@ -745,7 +772,7 @@ __global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const u32 j = js + (u32)i * kWave;
-                if (j < nunits) {
+                if ((u32)i < rows && j < nunits) {
                     const u32 rk = s_rk[pos.t];
                     if (rk & 1u) {
                         if (a.nt)
