@@ -37,9 +37,12 @@ namespace csgn {
 namespace {
 
 constexpr u32 kCT = 512;                  // threads of a group's workgroup: two workgroups share a CU
-constexpr int kCR = 20;                   // units per lane held in registers: 10 240 units = 1024 terms at N=1247
-constexpr u32 kCapUnits = kCT * kCR;
-constexpr u32 kMaxGroupTerms = 1024;      // two one-lane-per-term passes; LDS: 40 B per term
+// Two builds of the main kernel: 20 units per lane in registers (10 240 units = 1024 terms at N=1247; 122 VGPRs, two
+// workgroups per CU) and 48 (24 576 units = 1792 terms at N=1247, 768 at N=4096 -- BASELINE config 5's end size; one
+// workgroup per CU), the second taken when the caller's bound says the batch has ciphertexts between the two sizes.
+constexpr int kCR = 20, kCRWide = 48;
+constexpr u32 kCapUnits = kCT * kCR, kCapUnitsWide = kCT * kCRWide;
+constexpr u32 kMaxGroupTerms = 1024, kMaxGroupTermsWide = 1792;     // LDS: 24 B per term + the hash strips, under 64 KiB
 
 // control words (u64 each) at the head of the scratch block; zeroed, with the status granules, per call
 enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlWords = 32 };
@@ -51,11 +54,11 @@ struct Geom {
     u32 bigT;       // a ciphertext of more terms than this is a group by itself: capT - window
 };
 
-Geom make_geom(u32 U)
+Geom make_geom(u32 U, bool wide = false)
 {
     Geom g;
     g.U = U;
-    g.capT = min(kMaxGroupTerms, kCapUnits / U);
+    g.capT = wide ? min(kMaxGroupTermsWide, kCapUnitsWide / U) : min(kMaxGroupTerms, kCapUnits / U);
     g.wshift = 0;
     while ((2u << g.wshift) <= g.capT / 2)
         ++g.wshift;
@@ -410,14 +413,13 @@ __device__ inline u64 lookback(u64 *status, u32 gid, u64 count)
     return excl;
 }
 
-constexpr int kSub = 5;                                          // register rows hashed per staging round
-static_assert(kCR % kSub == 0, "hash staging rounds must tile the register rows");
-constexpr int kPasses = (int)((kMaxGroupTerms + kCT - 1) / kCT);  // term passes of the one-lane-per-term steps
+constexpr int sub_rows(int R) { return R % 5 == 0 ? 5 : 4; }      // register rows hashed per staging round
+constexpr int term_passes(int R) { return (int)(((R == kCR ? kMaxGroupTerms : kMaxGroupTermsWide) + kCT - 1) / kCT); }
 
 // dynamic LDS of the main kernel for groups of capT terms
-__host__ __device__ inline size_t main_lds_bytes(u32 capT)
+inline size_t main_lds_bytes(u32 capT, int R)
 {
-    return (size_t)capT * (8 + 4 + 4 + 4 + 4) + 64 + (size_t)(kCT / kWave) * kSub * kWave * 8;
+    return (size_t)capT * (8 + 4 + 4 + 4 + 4) + 64 + (size_t)(kCT / kWave) * sub_rows(R) * kWave * 8;
 }
 
 // Unit j of a group sits in wave w = j / (64 rows), register row i = (j / 64) % rows, lane j % 64, with
@@ -425,8 +427,10 @@ __host__ __device__ inline size_t main_lds_bytes(u32 capT)
 // a contiguous span of 64 rows units (coalesced 1 KiB wave loads all the same), so the hashes of a term's
 // units meet inside ONE wave.
 template <typename Unit, int R>
-__global__ void __launch_bounds__(kCT, 2 * kCT / 256) k_compact_main(CompactArgs a)
+__global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact_main(CompactArgs a)
 {
+    constexpr int kSub = sub_rows(R), kPasses = term_passes(R);
+    static_assert(R % kSub == 0, "hash staging rounds must tile the register rows");
     extern __shared__ u64 s_dyn[];
     const u32 capT = a.g.capT, U = a.g.U;
     u64 *s_node = s_dyn;                                          // [capT] hash sum, then {tag, next in bucket}
@@ -938,7 +942,10 @@ template <typename Unit>
 hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_terms, const u64 *terms,
                           const u64 *off, u64 *out, u64 *off_out, void *scratch, hipStream_t s)
 {
-    const Geom g = make_geom(U);
+    // the wide build only on the caller's word that some ciphertext needs it and none is larger still
+    const Geom narrow = make_geom(U), wide_g = make_geom(U, true);
+    const bool wide_groups = max_terms > narrow.capT && max_terms <= wide_g.capT;
+    const Geom g = wide_groups ? wide_g : narrow;
     const Layout l = make_layout(scratch, batch, total_terms, g);
     hipError_t e;
     // the call's head (control words + status granules) is cleared by the first kernel itself: no memset
@@ -999,9 +1006,12 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     // dev only: just past the scratch block as csgn_compact_scratch_bytes sizes it
     a.stamps = reinterpret_cast<u64 *>(static_cast<char *>(scratch) +
                                        make_layout(nullptr, batch, total_terms, make_geom((u32)min(dL, (u64)kCapUnits / 2))).bytes);
-    const size_t lds = main_lds_bytes(g.capT);
+    const size_t lds = main_lds_bytes(g.capT, wide_groups ? kCRWide : kCR);
     const int grid = tune(TUNE_COMPACT_GRID) > 0 ? tune(TUNE_COMPACT_GRID) : 512;      // two workgroups per CU
-    k_compact_main<Unit, kCR><<<(u32)min(ng, (u64)grid), kCT, lds, s>>>(a);
+    if (wide_groups)
+        k_compact_main<Unit, kCRWide><<<(u32)min(ng, (u64)grid / 2), kCT, lds, s>>>(a);       // one workgroup per CU
+    else
+        k_compact_main<Unit, kCR><<<(u32)min(ng, (u64)grid), kCT, lds, s>>>(a);
     return hipGetLastError();
 }
 

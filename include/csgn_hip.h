@@ -247,8 +247,10 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
  * csgn_compact_scratch_bytes(n_bits, batch, total_terms) bytes.
  * max_terms: an upper bound on the term count of any ONE ciphertext of the batch when the caller
  * knows it, 0 = unknown.  It is a launch hint only: a ciphertext up to one workgroup's group (1024
- * terms at N=1247) is read once and deduplicated in LDS, larger ones go through a hash table in
- * HBM whose kernels are skipped when the bound rules them out.  A ciphertext that exceeds a
+ * terms at N=1247, 320 at N=4096) is read once and deduplicated in LDS; with a bound of up to 1792 / 768
+ * terms a wide build of the same kernel (48 units per lane, one workgroup per CU) does the same for the
+ * whole batch; larger ciphertexts go through a hash table in HBM (terms read twice) whose kernels are
+ * skipped when the bound rules them out.  A ciphertext that exceeds a
  * non-zero bound it was promised to respect is copied through uncompacted (still a legal result).
  * Bit-exact for every input: terms are matched by a 48-bit hash tag first and then compared in
  * full; a tag collision between unequal terms only costs time.

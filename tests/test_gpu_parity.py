@@ -1475,6 +1475,19 @@ def test_compaction_large_ciphertexts(hip, oracle):
     assert int(off_out[6]) - int(off_out[5]) <= 100
 
 
+@pytest.mark.parametrize("n,sizes", [(1247, [1100, 1792, 3, 1500, 0, 1025, 700]), (4096, [766, 321, 768, 5, 500])])
+def test_compaction_wide_groups(hip, oracle, n, sizes):
+    """Ciphertexts between one workgroup's usual group (1024 terms at N=1247, 320 at N=4096) and the wide build's
+    (1792 / 768 -- BASELINE config 5 ends at 766 terms): with the caller's bound they are read once by the
+    48-units-per-lane build of the main kernel; without it they take the HBM-table path.  Same term lists as the
+    checker's either way, 0 % to 97 % duplicates."""
+    rng = np.random.default_rng(n + 3)
+    cts = [_dup_ciphertext(oracle, rng, n, 40 + i, max(1, int(t * f)), t) for i, (t, f) in
+           enumerate(zip(sizes, [1.5, 0.5, 1.0, 0.03, 1.0, 2.0, 0.3]))]
+    _check_compaction(hip, oracle, n, cts, max_terms=max(sizes))
+    _check_compaction(hip, oracle, n, cts)
+
+
 def test_compaction_one_million_single_terms_and_empties(hip, oracle):
     """A batch of 2^20 ciphertexts of 0, 1 or 2 terms: groups are runs of hundreds of ciphertexts whose
     offsets the workgroup stages in LDS; x + x vanishes."""

@@ -146,8 +146,13 @@ n, dl = 4096, 64
 for frac in (0.0, 0.5):
     case(f"compact 8192 x 256 terms, {int(frac*100)}% duplicates N={n}", n, (8192, 256),
          lambda frac=frac: [with_duplicates(n, dl, 8192, 256, frac, 14)], max_terms=256)
-case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates (HBM table) N={n}", n, (2048, 766),
+case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates, wide groups N={n}", n, (2048, 766),
+     lambda: [with_duplicates(n, dl, 2048, 766, 0.0, 15)], max_terms=766)
+case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates, bound unknown (HBM table) N={n}", n, (2048, 766),
      lambda: [with_duplicates(n, dl, 2048, 766, 0.0, 15)])
+n, dl = 1247, 20
+case(f"compact 2048 x 1792 terms, 0% duplicates, wide groups N={n}", n, (2048, 1792),
+     lambda: [with_duplicates(n, dl, 2048, 1792, 0.0, 16)], max_terms=1792)
 
 if args.json:
     with open(args.json, "w") as f:
