@@ -843,8 +843,13 @@ __global__ void __launch_bounds__(256) k_touch2(const u32 *__restrict__ a, u64 l
 __global__ void __launch_bounds__(256) k_touch_ragged(const u32 *__restrict__ L, const u64 *__restrict__ offL,
                                                       const u32 *__restrict__ R, const u64 *__restrict__ offR,
                                                       const u64 *__restrict__ offOut, u32 batch, u64 term_lo,
-                                                      u64 term_hi, u64 term_bytes)
+                                                      u64 term_hi, u64 term_bytes, const u64 *__restrict__ d_gate)
 {
+    if (d_gate) {                                    // csgn_mul_ragged_async: slices are cut from the caller's bound
+        term_hi = min(term_hi, d_gate[0]);
+        if (term_lo >= term_hi)
+            return;
+    }
     // the first and the last pair of the slice: two 64-ary wave searches side by side (waves 0 and 1), three or
     // four round trips in all -- the two binary searches that stood here were ~28 dependent loads, most of the
     // kernel's 20 us (PMC round 3: 60 VALU instructions per wave, parked 94 % of the time)
@@ -1301,7 +1306,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     }
     auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
         const u64 range_units = range_end - range_begin;
-        const bool touch = !d_gate && wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
@@ -1310,7 +1315,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             if (touch)
                 k_touch_ragged<<<2048, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
                                                    reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
-                                                   u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u);
+                                                   u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u, d_gate);
 #define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
     do {                                                                                            \
         if (wide)                                                                                   \
