@@ -375,43 +375,6 @@ struct CompactArgs {
 #define CSGN_STAMP(i) do { } while (0)
 #endif
 
-constexpr u64 kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
-
-// Decoupled look-back (one wave): publish this group's count, add up the counts of the groups before
-// it back to the nearest one whose inclusive prefix is known, publish the own inclusive prefix.  Every
-// granule is ONE 8-byte agent-scope store/load carrying flag and value together, so no ordering
-// between data and flag is needed.  Returns the exclusive prefix in every lane.
-__device__ inline u64 lookback(u64 *status, u32 gid, u64 count)
-{
-    const u32 lane = threadIdx.x & (kWave - 1);
-    if (lane == 0)
-        __hip_atomic_store(status + gid, kFlagAggregate | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u64 excl = 0;
-    long long base = (long long)gid - 1;
-    while (base >= 0) {
-        const long long idx = base - (long long)lane;
-        const u64 v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : kFlagPrefix;              // before group 0: prefix 0
-        const u32 flag = (u32)(v >> 62);
-        const u64 pending = __ballot(flag == 0u), known = __ballot(flag == 2u);
-        const u32 first = known ? (u32)__builtin_ctzll(known) : kWave;     // nearest lane holding a prefix
-        const u64 need = first < kWave - 1 ? (2ull << first) - 1ull : ~0ull;
-        if (pending & need) {
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        u64 mine = lane <= first ? (v & kValueMask) : 0ull;
-        for (u32 d = 32; d > 0; d >>= 1)
-            mine += __shfl_xor(mine, d, kWave);
-        excl += mine;
-        if (first < kWave)
-            break;
-        base -= kWave;
-    }
-    if (lane == 0)
-        __hip_atomic_store(status + gid, kFlagPrefix | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
 
 constexpr int sub_rows(int R) { return R % 5 == 0 ? 5 : 4; }      // register rows hashed per staging round
 constexpr int term_passes(int R) { return (int)(((R == kCR ? kMaxGroupTerms : kMaxGroupTermsWide) + kCT - 1) / kCT); }

@@ -139,6 +139,98 @@ __device__ inline void write_lane64(u64 uniform_value, int lane, u32 &lo, u32 &h
                  : "s"((u32)uniform_value), "s"((u32)(uniform_value >> 32)), "n"(lane));
 }
 
+// ---------------------------------------------------------------------- chained scan across workgroups
+constexpr u64 kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
+
+// Decoupled look-back (one wave): publish this group's count, add up the counts of the groups before
+// it back to the nearest one whose inclusive prefix is known, publish the own inclusive prefix.  Every
+// granule is ONE 8-byte agent-scope store/load carrying flag and value together, so no ordering
+// between data and flag is needed.  Returns the exclusive prefix in every lane.
+__device__ inline u64 lookback(u64 *status, u32 gid, u64 count)
+{
+    const u32 lane = threadIdx.x & (kWave - 1);
+    if (lane == 0)
+        __hip_atomic_store(status + gid, kFlagAggregate | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 excl = 0;
+    long long base = (long long)gid - 1;
+    while (base >= 0) {
+        const long long idx = base - (long long)lane;
+        const u64 v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : kFlagPrefix;              // before group 0: prefix 0
+        const u32 flag = (u32)(v >> 62);
+        const u64 pending = __ballot(flag == 0u), known = __ballot(flag == 2u);
+        const u32 first = known ? (u32)__builtin_ctzll(known) : kWave;     // nearest lane holding a prefix
+        const u64 need = first < kWave - 1 ? (2ull << first) - 1ull : ~0ull;
+        if (pending & need) {
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        u64 mine = lane <= first ? (v & kValueMask) : 0ull;
+        for (u32 d = 32; d > 0; d >>= 1)
+            mine += __shfl_xor(mine, d, kWave);
+        excl += mine;
+        if (first < kWave)
+            break;
+        base -= kWave;
+    }
+    if (lane == 0)
+        __hip_atomic_store(status + gid, kFlagPrefix | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// The same with one MARK bit riding along (value: 61 bits): a group may mark itself, and every group learns whether
+// any group before it did.  k_plan marks chunks that hold a pair of more than one product term, so the LAST chunk
+// knows from its look-back alone -- no counter of finished workgroups, no fence -- the batch total and whether every
+// pair of the batch is 1 x 1.
+constexpr u64 kMarkBit = 1ull << 61, kMarkedValueMask = kMarkBit - 1;
+__device__ inline u64 lookback_marked(u64 *status, u32 gid, u64 count, bool mark, bool &marked_before)
+{
+    const u32 lane = threadIdx.x & (kWave - 1);
+    const u64 own = mark ? kMarkBit : 0ull;
+    if (lane == 0)
+        __hip_atomic_store(status + gid, kFlagAggregate | own | (count & kMarkedValueMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    u64 excl = 0;
+    bool before = false;
+    long long base = (long long)gid - 1;
+    while (base >= 0) {
+        const long long idx = base - (long long)lane;
+        const u64 v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : kFlagPrefix;              // before group 0: prefix 0, no mark
+        const u32 flag = (u32)(v >> 62);
+        const u64 pending = __ballot(flag == 0u), known = __ballot(flag == 2u);
+        const u32 first = known ? (u32)__builtin_ctzll(known) : kWave;     // nearest lane holding a prefix
+        const u64 need = first < kWave - 1 ? (2ull << first) - 1ull : ~0ull;
+        if (pending & need) {
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        u64 mine = lane <= first ? (v & kMarkedValueMask) : 0ull;
+        before |= __ballot(lane <= first && (v & kMarkBit) != 0ull) != 0ull;
+        for (u32 d = 32; d > 0; d >>= 1)
+            mine += __shfl_xor(mine, d, kWave);
+        excl += mine;
+        if (first < kWave)
+            break;
+        base -= kWave;
+    }
+    if (lane == 0)
+        __hip_atomic_store(status + gid, kFlagPrefix | ((before || mark) ? kMarkBit : 0ull) | ((excl + count) & kMarkedValueMask),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    marked_before = before;
+    return excl;
+}
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load, store and
+// atomic the wave has in flight (s_waitcnt vmcnt(0)); where a wave has issued a global request whose result it wants
+// AFTER the barrier, this one lets it stay in flight.
+__device__ inline void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Zero-fill as a KERNEL.  Calls that may be captured into a hipGraph (csgn_circuit_*) do not use
 // hipMemsetAsync: with a memset node in the graph, launches on ROCm 7.2 were seen to start before copies
 // enqueued earlier on the same stream had landed (round 4: the inputs of a circuit with a compaction node

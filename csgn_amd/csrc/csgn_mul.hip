@@ -403,93 +403,99 @@ constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 2 + kSumSlots + 2 * kN
 constexpr u64 kSumAt = 4 + 1 + kHugeRecords * 6 + 2;       // first checksum slot of the head
 constexpr u64 kClassAt = kSumAt + kSumSlots;                // first class word of the head
 
-// one pair's share of the checksum of the offset arrays
+// one pair's share of the checksum of the offset arrays: one splitmix64 of the three entries folded together and
+// salted with the position (round 4; three splitmix64 per pair until then -- 64-bit multiplies run at a quarter of
+// the rate, and hashing four pairs a thread that way took the plan kernel 3.3 us of its 19)
 __device__ inline u64 offsets_mix(u64 b, u64 l, u64 r, u64 o)
 {
-    return csgn_splitmix64(l + CSGN_GOLDEN * (3 * b + 1)) + csgn_splitmix64(r + CSGN_GOLDEN * (3 * b + 2)) +
-           csgn_splitmix64(o + CSGN_GOLDEN * (3 * b + 3));
+    return csgn_splitmix64((l ^ ((r << 21) | (r >> 43)) ^ ((o << 42) | (o >> 22))) + CSGN_GOLDEN * (b + 1));
 }
 
-// Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus the shape maxima the
-// launcher needs.  Three small kernels: per-1024-pair chunk scans, a scan of the chunk totals,
-// and the fix-up -- 1M pairs plan in tens of microseconds.
-__global__ void __launch_bounds__(256) k_plan_chunks(u64 batch, const u64 *__restrict__ offL,
-                                                     const u64 *__restrict__ offR,
-                                                     u64 *__restrict__ offOut, u64 *__restrict__ partial,
-                                                     u64 *__restrict__ plan4)
-{
-    __shared__ u64 sums[256];
-    const u32 tid = threadIdx.x;
-    const u64 b0 = (u64)blockIdx.x * 1024u + (u64)tid * 4u;
-    u64 c[4], m1 = 0, m2 = 0, mp = 0, mine = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        c[j] = 0;
-        if (b0 + j < batch) {
-            const u64 t1 = offL[b0 + j + 1] - offL[b0 + j], t2 = offR[b0 + j + 1] - offR[b0 + j];
-            c[j] = t1 * t2;
-            m1 = max(m1, t1);
-            m2 = max(m2, t2);
-            mp = max(mp, c[j]);
-        }
-        mine += c[j];
-    }
-    sums[tid] = mine;
-    __syncthreads();
-    if (tid == 0) {
-        u64 run = 0;
-        for (u32 t = 0; t < 256; ++t) {
-            const u64 v = sums[t];
-            sums[t] = run;
-            run += v;
-        }
-        partial[blockIdx.x] = run;
-    }
-    __syncthreads();
-    u64 run = sums[tid];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (b0 + j < batch)
-            offOut[b0 + j] = run;                      // chunk-local; k_plan_fix adds the chunk base
-        run += c[j];
-    }
-    // workgroup maxima, then an atomic only where the workgroup would RAISE the running maximum: atomics on one
-    // word complete at ~11 ns apiece chip-wide, and a wave's worth per chunk (48 K of them at a million pairs) was
-    // most of a plan's 200 us; nearly every workgroup now sees that it has nothing to add
-    __shared__ u64 wmax[3][4];
-    for (int off = 32; off > 0; off >>= 1) {
-        m1 = max(m1, (u64)__shfl_down(m1, off, 64));
-        m2 = max(m2, (u64)__shfl_down(m2, off, 64));
-        mp = max(mp, (u64)__shfl_down(mp, off, 64));
-    }
-    if ((tid & (kWave - 1)) == 0) {
-        wmax[0][tid >> 6] = m1;
-        wmax[1][tid >> 6] = m2;
-        wmax[2][tid >> 6] = mp;
-    }
-    __syncthreads();
-    if (tid < 3) {
-        const u64 m = max(max(wmax[tid][0], wmax[tid][1]), max(wmax[tid][2], wmax[tid][3]));
-        if (m > __hip_atomic_load(plan4 + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1 + tid), m);
-    }
-}
+// Product term offsets = exclusive scan of t1_b*t2_b over the batch, plus what the launcher wants to know: shape
+// maxima, the HUGE pairs (products of kHugeTerms terms and more: {pair, offL, offR, t1, t2, offOut}, up to
+// kHugeRecords of them -- csgn_mul_planned gives such a pair a uniform launch of its own), operand totals, a
+// checksum of the three offset arrays, the size-class histogram, and for csgn_mul_ragged_async the gate.
+constexpr u32 kPlanThreads = 1024, kPlanChunk = kPlanThreads * 4;       // pairs per workgroup of k_plan
 
-__global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 batch, u64 *__restrict__ partial,
-                                                             u64 *__restrict__ offOut, u64 *__restrict__ plan4)
+#ifdef CSGN_PLAN_STAMPS     // dev (tools/prof_plan_phases.py): every 4th workgroup leaves 100 MHz wall-clock stamps behind the scan block
+#define CSGN_PSTAMP(k) do { if (tid == 0 && (chunk & 3u) == 0u) scan[nchunks + 3 + (chunk >> 2) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define CSGN_PSTAMP(k) do {} while (0)
+#endif
+
+// ONE kernel (round 4; three until then: chunk scans, a scan of the chunk totals, a fix-up pass that read every
+// offset a second time -- 27-45 us at a million pairs): a workgroup takes a ticket, scans its 4096 pairs,
+// gets the sum of all chunks before it by a decoupled look-back over one {flag, sum} granule per chunk (csgn_device.h),
+// and writes final offsets at once.  `scan` = [nchunks status granules][ticket],
+// zeroed by the caller.  One workgroup per CU (a 64-VGPR build for two spilled 270 bytes), so a million pairs are
+// exactly ONE wave of 256 workgroups: the closing entry of the arrays is written by the thread that owns the last
+// pair and gets no workgroup of its own (as a 257th it ran after the others, 9 us more).
+// `vec`: all three arrays 16-byte aligned -> 16-byte loads and stores.  `resident`: the CUs of the device = the
+// workgroups of this kernel it holds at once.
+__global__ void __launch_bounds__(kPlanThreads) k_plan(u64 batch, u32 nchunks, const u64 *__restrict__ offL,
+                                                          const u64 *__restrict__ offR, u64 *__restrict__ offOut,
+                                                          u64 *__restrict__ head, u64 *__restrict__ scan, u32 classes,
+                                                          u64 *__restrict__ gate, u64 capacity_terms, u32 can_stream, u32 vec,
+                                                          u32 resident)
 {
-    __shared__ u64 part[1024];
-    const u32 tid = threadIdx.x;
-    const u64 chunk = (nchunks + 1023) / 1024;
-    const u64 c0 = min(nchunks, (u64)tid * chunk), c1 = min(nchunks, c0 + chunk);
-    u64 sum = 0;
-    for (u64 c = c0; c < c1; ++c)
-        sum += partial[c];
-    // exclusive scan of the 1024 per-thread sums: wave scans by shuffle, then the 16 wave totals (a serial loop
-    // over all 1024 in one thread was 12 of this kernel's 13 microseconds)
-    __shared__ u64 wtot[16];
-    const u32 lane = tid & (kWave - 1), wv = tid >> 6;
-    u64 incl = sum;
+    constexpr u32 kWaves = kPlanThreads / kWave;
+    __shared__ u64 wtot[kWaves], wmax[3][kWaves], s_prefix;
+    __shared__ u32 s_chunk;
+    __shared__ u32 h_pairs[kNumClasses];
+    __shared__ u64 h_terms[kNumClasses];
+    u64 *plan4 = head, *huge = head + 4;
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+#ifdef CSGN_PLAN_STAMPS
+    const u64 st0 = wall_clock64();
+#endif
+    if (tid < kNumClasses) {
+        h_pairs[tid] = 0u;
+        h_terms[tid] = 0ull;
+    }
+    // A chunk waits for the chunks before it, so those must be running: in general a workgroup takes its chunk from a
+    // ticket counter (whoever holds an older ticket started earlier).  A grid that fits the chip at once needs no
+    // ticket -- every workgroup gets a CU without any other having to finish -- and 256 atomics on one word are 3-4 us
+    // for the last in line.
+    u32 chunk = blockIdx.x;
+    if (nchunks > resident) {
+        if (tid == 0)
+            s_chunk = atomicAdd(reinterpret_cast<u32 *>(scan + nchunks), 1u);
+        __syncthreads();
+        chunk = s_chunk;
+    }
+#ifdef CSGN_PLAN_STAMPS
+    if (tid == 0 && (chunk & 3u) == 0u)
+        scan[nchunks + 3 + (chunk >> 2) * 8] = st0;
+#endif
+    CSGN_PSTAMP(1);
+    const u64 b0 = (u64)chunk * kPlanChunk + (u64)tid * 4u;
+    // entries b0 .. b0+4 of both operand arrays (past the closing entry: the closing entry again, so such pairs are 0 x 0)
+    u64 l[5], r[5];
+    const bool whole = b0 + 4 <= batch;
+    if (vec && whole) {
+        const ulonglong2 la = *reinterpret_cast<const ulonglong2 *>(offL + b0), lb = *reinterpret_cast<const ulonglong2 *>(offL + b0 + 2);
+        const ulonglong2 ra = *reinterpret_cast<const ulonglong2 *>(offR + b0), rb = *reinterpret_cast<const ulonglong2 *>(offR + b0 + 2);
+        l[0] = la.x; l[1] = la.y; l[2] = lb.x; l[3] = lb.y; l[4] = offL[b0 + 4];
+        r[0] = ra.x; r[1] = ra.y; r[2] = rb.x; r[3] = rb.y; r[4] = offR[b0 + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const u64 at = b0 + j < batch ? b0 + j : batch;
+            l[j] = offL[at];
+            r[j] = offR[at];
+        }
+    }
+    u64 m1 = 0, m2 = 0, mp = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u64 t1 = l[j + 1] - l[j], t2 = r[j + 1] - r[j], c = t1 * t2;
+        m1 = max(m1, t1);
+        m2 = max(m2, t2);
+        mp = max(mp, c);
+        mine += c;
+    }
+    // exclusive scan of the per-thread sums
+    u64 incl = mine;
     for (u32 d = 1; d < kWave; d <<= 1) {
         const u64 nb = (u64)__shfl_up(incl, d, kWave);
         if (lane >= d)
@@ -497,95 +503,118 @@ __global__ void __launch_bounds__(1024) k_plan_scan_partials(u64 nchunks, u64 ba
     }
     if (lane == kWave - 1)
         wtot[wv] = incl;
+    for (int off = 32; off > 0; off >>= 1) {
+        m1 = max(m1, (u64)__shfl_down(m1, off, 64));
+        m2 = max(m2, (u64)__shfl_down(m2, off, 64));
+        mp = max(mp, (u64)__shfl_down(mp, off, 64));
+    }
+    if (lane == 0) {
+        wmax[0][wv] = m1;
+        wmax[1][wv] = m2;
+        wmax[2][wv] = mp;
+    }
     __syncthreads();
+    CSGN_PSTAMP(2);
     u64 wbase = 0, all = 0;
-    for (u32 w = 0; w < 16; ++w) {
+    for (u32 w = 0; w < kWaves; ++w) {
         wbase += w < wv ? wtot[w] : 0ull;
         all += wtot[w];
     }
-    part[tid] = wbase + incl - sum;
-    if (tid == 0) {
-        offOut[batch] = all;
-        plan4[0] = all;
-    }
-    __syncthreads();
-    u64 run = part[tid];
-    for (u64 c = c0; c < c1; ++c) {
-        const u64 v = partial[c];
-        partial[c] = run;
-        run += v;
-    }
-}
-
-// ... and, while every pair's final offset passes through a lane anyway, the HUGE pairs (products of
-// kHugeTerms terms and more) are written down for the host: {pair, offL, offR, t1, t2, offOut}, up to
-// kHugeRecords of them.  csgn_mul_ragged gives such a pair its own uniform launch (no lookups at
-// all inside 99 % of a skewed batch's output) and runs the CSR kernel on the stretches between them.
-__global__ void __launch_bounds__(256) k_plan_fix(u64 batch, const u64 *__restrict__ partial,
-                                                  const u64 *__restrict__ offL, const u64 *__restrict__ offR,
-                                                  u64 *__restrict__ offOut, u64 *__restrict__ huge, u32 classes,
-                                                  u64 *__restrict__ gate, u64 capacity_terms, u32 can_stream)
-{
-    const u64 b = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (b == 0) {                                   // operand totals: what sizes the slices of a large product
-        huge[1 + kHugeRecords * 6] = offL[batch] - offL[0];
-        huge[2 + kHugeRecords * 6] = offR[batch] - offR[0];
-    }
-    __shared__ u32 h_pairs[kNumClasses];
-    __shared__ u64 h_terms[kNumClasses];
-    if (threadIdx.x < kNumClasses) {
-        h_pairs[threadIdx.x] = 0u;
-        h_terms[threadIdx.x] = 0ull;
-    }
-    __syncthreads();
-    u64 mix = 0;
-    if (b == batch) {
-        mix = offsets_mix(b, offL[b], offR[b], offOut[b]);
-        if (gate) {
-            // csgn_mul_ragged_async: what the kernels behind this one may do (totals are final: k_plan_scan_partials ran)
-            const u64 *plan4 = huge - 4;
-            const u64 total = plan4[0];
-            const bool fits = total <= capacity_terms;
-            const bool ones = can_stream && fits && total == batch && plan4[3] == 1ull;   // every pair 1 x 1: the plain AND stream
-            gate[0] = (fits && !ones) ? total : 0ull;
-            gate[1] = fits ? 0ull : 1ull;
-            gate[2] = ones ? total : 0ull;
+    if (wv == 0) {
+        // a chunk with a pair of more than one product term marks itself: the LAST chunk then has, from its look-back
+        // alone, what csgn_mul_ragged_async's gate says to the kernels behind this one -- real output terms / does not
+        // fit / every pair 1 x 1 (the plain AND stream; total == batch with no pair above one term).  (Round-4 notes:
+        // a counter of finished workgroups cost 3 us of same-address atomics plus, with the release fence that makes
+        // the total visible, 5-8 us of L2 write-back with every workgroup's offsets in it.)
+        const bool mark = __ballot(lane < kWaves && wmax[2][lane < kWaves ? lane : 0] > 1ull) != 0ull;
+        bool marked_before;
+        const u64 excl = lookback_marked(scan, chunk, all, mark, marked_before);
+        if (lane == 0) {
+            s_prefix = excl;
+            if (gate && chunk == nchunks - 1u) {
+                const u64 total = excl + all;
+                const bool fits = total <= capacity_terms;
+                const bool ones = can_stream && fits && total == batch && !mark && !marked_before;
+                gate[0] = (fits && !ones) ? total : 0ull;
+                gate[1] = fits ? 0ull : 1ull;
+                gate[2] = ones ? total : 0ull;
+            }
         }
+    } else if (tid < kWave + 3u) {
+        // (wave 1) shape maxima: an atomic only where the workgroup would RAISE the running maximum -- atomics on one
+        // word complete at ~11 ns apiece chip-wide, and nearly every workgroup sees that it has nothing to add
+        const u32 k = tid - kWave;
+        u64 m = 0;
+        for (u32 w = 0; w < kWaves; ++w)
+            m = max(m, wmax[k][w]);
+        if (m > __hip_atomic_load(plan4 + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned long long *>(plan4 + 1 + k), (unsigned long long)m);
     }
-    if (b < batch) {
-        const u64 o = offOut[b] + partial[b >> 10];
-        offOut[b] = o;
-        mix = offsets_mix(b, offL[b], offR[b], o);
-        const u64 l0 = offL[b], r0 = offR[b], t1 = offL[b + 1] - l0, t2 = offR[b + 1] - r0;
+    __syncthreads();
+    CSGN_PSTAMP(3);
+    u64 run = s_prefix + wbase + incl - mine, mix = 0;
+    const bool wide = vec && whole;
+    if (wide) {
+        const u64 o1 = run + (l[1] - l[0]) * (r[1] - r[0]), o2 = o1 + (l[2] - l[1]) * (r[2] - r[1]);
+        const u64 o3 = o2 + (l[3] - l[2]) * (r[3] - r[2]);
+        *reinterpret_cast<ulonglong2 *>(offOut + b0) = make_ulonglong2(run, o1);
+        *reinterpret_cast<ulonglong2 *>(offOut + b0 + 2) = make_ulonglong2(o2, o3);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u64 b = b0 + j;
+        if (b >= batch)
+            break;
+        const u64 t1 = l[j + 1] - l[j], t2 = r[j + 1] - r[j], c = t1 * t2;
+        if (!wide)
+            offOut[b] = run;
+        mix += offsets_mix(b, l[j], r[j], run);
         const int cls = classes ? class_of(t1, t2) : -1;
         if (cls >= 0) {
             atomicAdd(h_pairs + cls, 1u);
-            atomicAdd(reinterpret_cast<unsigned long long *>(h_terms + cls), (unsigned long long)(t1 * t2));
+            atomicAdd(reinterpret_cast<unsigned long long *>(h_terms + cls), (unsigned long long)c);
         }
-        if (t1 * t2 >= kHugeTerms) {
+        if (c >= kHugeTerms) {
             const u64 slot = atomicAdd(reinterpret_cast<unsigned long long *>(huge), 1ull);
             if (slot < kHugeRecords) {
-                u64 *r = huge + 1 + slot * 6;
-                r[0] = b; r[1] = l0; r[2] = r0; r[3] = t1; r[4] = t2; r[5] = o;
+                u64 *rec = huge + 1 + slot * 6;
+                rec[0] = b; rec[1] = l[j]; rec[2] = r[j]; rec[3] = t1; rec[4] = t2; rec[5] = run;
             }
         }
+        run += c;
+        if (b + 1 == batch) {                       // the owner of the last pair: the closing entries of the three arrays
+            offOut[batch] = run;
+            plan4[0] = run;
+            mix += offsets_mix(batch, l[j + 1], r[j + 1], run);
+            huge[1 + kHugeRecords * 6] = l[j + 1] - offL[0];         // operand totals: what sizes the slices of a large product
+            huge[2 + kHugeRecords * 6] = r[j + 1] - offR[0];
+        }
     }
-    // checksum of the three offset arrays as planned (csgn_mul_plan_validate recomputes it later)
-    __shared__ u64 wsum[4];
+    if (batch == 0 && tid == 0) {                   // an empty batch has closing entries only
+        offOut[0] = 0;
+        plan4[0] = 0;
+        mix += offsets_mix(0, l[0], r[0], 0);
+    }
+    // checksum of the three offset arrays as planned (csgn_mul_plan_validate recomputes it later): every wave adds
+    // its share to one of the kSumSlots words
     for (int off = 32; off > 0; off >>= 1)
         mix += (u64)__shfl_down(mix, off, 64);
-    if ((threadIdx.x & (kWave - 1)) == 0)
-        wsum[threadIdx.x >> 6] = mix;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(huge - 4 + kSumAt + (blockIdx.x % kSumSlots)),
-                  (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
-    // the workgroup's class histogram: one global atomic per class it met
-    if (threadIdx.x < kNumClasses && h_pairs[threadIdx.x]) {
-        u64 *cls = huge - 4 + kClassAt;                          // `huge` = head + 4
-        atomicAdd(reinterpret_cast<unsigned long long *>(cls + threadIdx.x), (unsigned long long)h_pairs[threadIdx.x]);
-        atomicAdd(reinterpret_cast<unsigned long long *>(cls + kNumClasses + threadIdx.x), (unsigned long long)h_terms[threadIdx.x]);
+    if (lane == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(head + kSumAt + ((chunk * kWaves + wv) % kSumSlots)), (unsigned long long)mix);
+    CSGN_PSTAMP(4);
+    if (classes) {                                  // the workgroup's class histogram: one global atomic per class it met
+        __syncthreads();
+        if (tid < kNumClasses && h_pairs[tid]) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(head + kClassAt + tid), (unsigned long long)h_pairs[tid]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(head + kClassAt + kNumClasses + tid), (unsigned long long)h_terms[tid]);
+        }
     }
+    if (tid != kWave)
+        return;
+#ifdef CSGN_PLAN_STAMPS
+    if ((chunk & 3u) == 0u)
+        scan[nchunks + 3 + (chunk >> 2) * 8 + 5] = wall_clock64();
+#endif
 }
 
 // class bases (exclusive scan of the class pair counts) and zeroed cursors, then the lists
@@ -1048,8 +1077,8 @@ hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
     return hipSuccess;
 }
 
-// [head][one partial per 1024-pair chunk][class bases + cursors][class lists: one u32 per pair]
-static u64 plan_bases_at(u64 batch) { return kPlanHeadWords + (batch + 1023) / 1024 + 1; }
+// [head][scan block: one granule per chunk of pairs, ticket][class bases + cursors][class lists: one u32 per pair]
+static u64 plan_bases_at(u64 batch) { return kPlanHeadWords + (batch + 1 + 1023) / 1024 + 4; }   // (room for more granules than k_plan uses)
 static u64 plan_lists_at(u64 batch) { return plan_bases_at(batch) + 2 * kNumClasses + 2; }
 u64 mul_ragged_plan_scratch_words(u64 batch) { return plan_lists_at(batch) + (batch + 1) / 2 + 1; }
 u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
@@ -1057,28 +1086,28 @@ u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
                            hipStream_t s, u64 *gate, u64 capacity_terms, bool can_stream)
 {
-    // d_work: [plan4 (total, max t1, max t2, max t1*t2)][huge count][huge records][one partial per 1024-pair chunk]
-    u64 *plan4 = d_work, *huge = d_work + 4, *partial = d_work + kPlanHeadWords;
-    const u64 nchunks = (batch + 1023) / 1024;
-    hipError_t e = zero_words(d_work, plan_lists_at(batch), s);       // head, partials, class bases (a kernel: see zero_words)
+    // d_work: [head: plan4 (total, max t1, max t2, max t1*t2), huge count + records, operand totals, checksum slots,
+    //          class histogram][scan: one granule per 4096-pair chunk, ticket][class bases][class lists]
+    u64 *scan = d_work + kPlanHeadWords;
+    const u64 nchunks = batch ? (batch + kPlanChunk - 1) / kPlanChunk : 1;
+    hipError_t e = zero_words(d_work, plan_lists_at(batch), s);       // head, scan block, class bases (a kernel: see zero_words)
     if (e != hipSuccess)
         return e;
-    if (nchunks > kMaxBlocks256)
+    if (nchunks > kMaxBlocks1024)
         return hipErrorInvalidValue;
-    if (batch)
-        k_plan_chunks<<<(u32)nchunks, 256, 0, s>>>(batch, offL, offR, offOut, partial, plan4);
-    k_plan_scan_partials<<<1, 1024, 0, s>>>(nchunks, batch, partial, offOut, plan4);
-    if (batch) {
-        // the size-class lists (and the histogram's global atomics) only when the multiply is going to use them
-        const bool classes = csgn::tune(TUNE_RAGGED_CLASSES) == 1;
-        k_plan_fix<<<ceil_div_u64(batch + 1, 256), 256, 0, s>>>(batch, partial, offL, offR, offOut, huge, classes ? 1u : 0u,
-                                                                gate, capacity_terms, can_stream ? 1u : 0u);
-        if (classes) {
-            u64 *bases = d_work + plan_bases_at(batch);
-            k_class_bases<<<1, 1, 0, s>>>(d_work, bases);
-            k_class_lists<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, offL, offR, bases,
-                                                                   reinterpret_cast<u32 *>(d_work + plan_lists_at(batch)));
-        }
+    // the size-class lists (and the histogram's global atomics) only when the multiply is going to use them
+    const bool classes = csgn::tune(TUNE_RAGGED_CLASSES) == 1;
+    const u32 vec = ((reinterpret_cast<uintptr_t>(offL) | reinterpret_cast<uintptr_t>(offR) | reinterpret_cast<uintptr_t>(offOut)) & 15u) == 0u;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 0;                                                   // unknown: tickets always
+    k_plan<<<(u32)nchunks, kPlanThreads, 0, s>>>(batch, (u32)nchunks, offL, offR, offOut, d_work, scan, classes ? 1u : 0u, gate,
+                                                 capacity_terms, can_stream ? 1u : 0u, vec, (u32)cus);
+    if (classes && batch) {
+        u64 *bases = d_work + plan_bases_at(batch);
+        k_class_bases<<<1, 1, 0, s>>>(d_work, bases);
+        k_class_lists<<<ceil_div_u64(batch, 256), 256, 0, s>>>(batch, offL, offR, bases,
+                                                               reinterpret_cast<u32 *>(d_work + plan_lists_at(batch)));
     }
     return hipGetLastError();
 }

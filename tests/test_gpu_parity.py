@@ -2606,25 +2606,67 @@ def test_ragged_forms_fuzz(hip, oracle, knobs):
                 assert np.array_equal(ha[int(ao[b]) * dl:int(ao[b + 1]) * dl], want_s), (it, b)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 1023, 1024, 1025, 5000, 200000])
-def test_mul_ragged_plan_offsets(hip, batch):
-    """The chunked plan scan (1024-pair chunks, partial scan, fix-up) against numpy for batch
-    sizes around the chunk boundaries, with zeros mixed in."""
+@pytest.mark.parametrize("batch", [1, 2, 1023, 4095, 4096, 4097, 5000, 200000, 1300000])
+@pytest.mark.parametrize("misaligned", [False, True])
+def test_mul_ragged_plan_offsets(hip, batch, misaligned):
+    """The plan kernel (4096-pair chunks chained by a look-back; tickets once the chunks outnumber the CUs: the
+    1.3 M case) against numpy for batch sizes around the chunk boundaries, with zeros mixed in; 16-byte aligned
+    arrays (the vector path) and arrays 8 bytes off."""
     import ctypes as C
     rng = np.random.default_rng(batch)
     t1 = rng.integers(0, 7, size=batch).astype(np.uint64)
     t2 = rng.integers(0, 5, size=batch).astype(np.uint64)
     offL, offR = csr(t1), csr(t2)
-    off_out = hip.empty_words(batch + 1)
+    skew = 1 if misaligned else 0
+    off_out = hip.empty_words(batch + 1 + skew)[skew:]
     plan = (C.c_uint64 * 4)()
     from csgn_amd.capi import check
-    d_off_l, d_off_r = hip.upload(offL), hip.upload(offR)        # keep the tensors alive across the call
+    d_off_l = hip.upload(np.concatenate([np.zeros(skew, np.uint64), offL]))[skew:]    # keep the tensors alive across the call
+    d_off_r = hip.upload(np.concatenate([np.zeros(skew, np.uint64), offR]))[skew:]
+    assert (d_off_l.data_ptr() % 16 == 8) == misaligned
     check(hip.lib.csgn_mul_ragged_plan(batch, d_off_l.data_ptr(), d_off_r.data_ptr(),
                                        off_out.data_ptr(), C.byref(plan), hip.stream))
     want = csr(t1 * t2)
     assert np.array_equal(hip.download(off_out), want)
     assert int(plan[0]) == int(want[-1])
     assert (int(plan[1]), int(plan[2]), int(plan[3])) == (int(t1.max()), int(t2.max()), int((t1 * t2).max()))
+
+
+@pytest.mark.parametrize("batch", [4096, 300000, 1200000])
+@pytest.mark.parametrize("odd_at", [None, 0, -1, 70000])
+def test_mul_ragged_async_gate_across_chunks(hip, oracle, batch, odd_at):
+    """The all-1x1 decision of csgn_mul_ragged_async rides the plan kernel's look-back chain: a single pair that is
+    not 1 x 1 -- in the first chunk, the last, or in between -- must reach the last chunk across every window of the
+    chain (and across tickets at 1.2 M pairs), or the AND stream would run on a batch it is wrong for."""
+    import torch
+    n = 64
+    dl = oracle.default_len(n)
+    t1s = np.ones(batch, dtype=np.int64)
+    t2s = np.ones(batch, dtype=np.int64)
+    if odd_at is not None:
+        at = odd_at if odd_at >= 0 else batch - 1
+        if at >= batch:
+            pytest.skip("pair outside the batch")
+        t1s[at], t2s[at] = 2, 0 if odd_at == 70000 else 1        # 2 x 1 (one more term) or 2 x 0 (one fewer)
+    offL, offR = csr(t1s), csr(t2s)
+    L = hip.synth_fill(5, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(6, n, 0, max(1, int(offR[-1])) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    total = int((t1s * t2s).sum())
+    out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total + 3)
+    res = hip.mul_ragged_async_result(plan)
+    assert res[0] == total and res[4] == 0, res
+    want_off = csr(t1s * t2s)
+    assert np.array_equal(hip.download(off), want_off)
+    # every product term against torch: term j of pair b = L term (offL[b] + j / t2) & R term (offR[b] + j % t2)
+    pair = np.repeat(np.arange(batch), (t1s * t2s))
+    j = np.arange(total) - want_off[:-1].astype(np.int64)[pair]
+    li = offL[:-1].astype(np.int64)[pair] + j // np.maximum(t2s[pair], 1)
+    ri = offR[:-1].astype(np.int64)[pair] + j % np.maximum(t2s[pair], 1)
+    li_t = torch.from_numpy(li).to(hip.device)
+    ri_t = torch.from_numpy(ri).to(hip.device)
+    want = L.view(-1, dl)[li_t] & R.view(-1, dl)[ri_t]
+    assert torch.equal(out[:total * dl].view(-1, dl), want)
 
 
 def test_decrypt_ragged_skewed(hip, oracle):
