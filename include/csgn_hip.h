@@ -172,7 +172,7 @@ int csgn_mul_planned(csgn_mul_plan *plan, uint64_t n_bits, const uint64_t *d_lef
 int csgn_mul_plan_validate(csgn_mul_plan *plan, void *stream);     /* CSGN_ERR_INVALID: offsets changed since the plan */
 int csgn_mul_plan_trust(csgn_mul_plan *plan, int trust);
 
-/* Ragged multiply with NO host round trip: the plan kernels and the multiply are enqueued back to back and
+/* Ragged multiply with NO host round trip: the plan kernel and the multiply are enqueued back to back and
  * nothing is read back.  d_off_out[batch+1] is written as by csgn_mul_ragged_plan.  The caller gives the room:
  * out_capacity_terms = terms d_out can hold (an upper bound on the sum of t1_b*t2_b, e.g. from static shapes);
  * the launch is sized for it and stops at the real end, which only the device knows.  If the products do
