@@ -403,6 +403,174 @@ constexpr u64 kPlanHeadWords = 4 + 1 + kHugeRecords * 6 + 2 + kSumSlots + 2 * kN
 constexpr u64 kSumAt = 4 + 1 + kHugeRecords * 6 + 2;       // first checksum slot of the head
 constexpr u64 kClassAt = kSumAt + kSumSlots;                // first class word of the head
 
+// ---- ragged multiply, wave-cooperative form (round 4) -----------------------------------------------------------
+// The CSR kernel above gives every LANE a 16-byte unit of the flattened output and lets it find out on its own which
+// pair, row and column that is: a division by the unit count, a search of the offset window, a division by t2 and
+// 64-bit address arithmetic -- ~100 vector and ~70 scalar instructions per 64 units (rocprofv3 --pmc SQ_INSTS_VALU
+// on a log-normal batch of mean-8 pairs: 235 M wave instructions for 2.35 M blocks), which is what bounds it on small
+// pairs (3.7 TB/s where the same bytes stream at 6).  Here a WAVE owns a contiguous stretch of the output and walks
+// its pairs together: the offsets of the next 63 pairs sit in the lanes of three registers (one coalesced load each,
+// read back with v_readlane), every pair's stretch is written in blocks of 64 units, and a lane keeps (row, column,
+// unit in term) of its unit by ADDING per block -- one division per lane and pair, none per block; 32-bit offsets from
+// wave-uniform pair bases.  The price: the last block of a pair's stretch is partly idle (a 1 x 1 pair of 160-byte
+// terms uses 10 lanes of 64), ~5 % of the blocks on the batches this is for.
+__device__ inline u64 readlane64(u64 v, u32 j)
+{
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, (int)j);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)j);
+    return ((u64)hi << 32) | lo;
+}
+
+// The walk is ONE loop over blocks, kCoopBlocks of them in flight, whatever pairs they belong to: a block that finds its
+// pair used up moves the wave on to the next one (a wave-uniform branch), so a run of 1 x 1 pairs keeps as many loads
+// and stores in flight as the middle of a large pair does.  (The first form finished a pair before it started the
+// next: 0.5 TB/s on 65 535 singles.)
+// A wave's work is blocks, not bytes -- a single-term pair costs it a block as 64 units of a large pair do -- so the
+// output is dealt out along a VIRTUAL axis on which pair p starts at f(p) = offOut[p] * U + vw * p: its units plus vw
+// units of padding per pair before it (vw = 64 for a launch over the whole output; 0, the plain unit axis, for the
+// slices of a large output, whose ends the host knows in units only).  Stretches of equal virtual length hold at most
+// twice the blocks of one another, and nothing but offOut is needed to find them.
+constexpr int kCoopBlocks = 4;
+
+// largest p in [0, batch) with f(p) <= target (f(0) = 0 <= target), by a whole wave: wave_find on the virtual axis
+__device__ inline u32 wave_find_virtual(const u64 *__restrict__ offOut, u32 batch, u32 U, u32 vw, u64 target)
+{
+    const u32 lane = threadIdx.x & (kWave - 1);
+    u32 lo = 0, hi = batch;
+    while (hi - lo > 1) {
+        const u32 n = hi - lo, s = (n + kWave - 1) / kWave;
+        const u64 idx = (u64)lo + (u64)lane * s;
+        const bool ok = idx < hi && offOut[idx] * U + (u64)vw * idx <= target;
+        const u32 c = (u32)__popcll(__ballot(ok));             // >= 1: lane 0 holds by the invariant
+        lo += (c - 1u) * s;
+        hi = min(lo + s, hi);
+    }
+    return lo;
+}
+
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict__ L, const u64 *__restrict__ offL,
+                                                         const Unit *__restrict__ R, const u64 *__restrict__ offR,
+                                                         Unit *__restrict__ out, const u64 *__restrict__ offOut,
+                                                         u32 batch, u64 v_begin, u64 v_end, u32 U, FastDiv dU,
+                                                         u32 span, u32 vw, const u64 *__restrict__ d_gate)
+{
+    // csgn_mul_ragged_async: the grid was sized for the caller's bound, the real end is in the gate
+    if (d_gate)
+        v_end = min(v_end, d_gate[0] * U + (u64)vw * batch);
+    const u32 lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u64 v0 = v_begin + ((u64)bid * 4u + wv) * span;       // this wave's stretch of the virtual axis
+    if (v0 >= v_end)
+        return;
+    const u64 v1 = min(v0 + span, v_end);
+    u32 p = wave_find_virtual(offOut, batch, U, vw, v0);        // the pair v0 falls in (its units or its padding)
+    // From here on every place is a BYTE offset from a wave-uniform base, 32 bits wide (a pair's product stays under
+    // 4 GiB: the launcher's condition) -- an SGPR base plus one VGPR per address instead of a 64-bit VGPR pair each.
+    constexpr u32 kUB = (u32)sizeof(Unit), kBlockBytes = kWave * kUB;
+    const u32 termB = U * kUB;                                   // bytes of a term
+    const u32 kstepB = (kWave - csgn_fastdiv(kWave, dU) * U) * kUB;   // a block on, the place inside the term moves by 64 mod U units
+    // the window: offsets of pairs p .. p+62 (and the entry that closes the last of them) in the lanes
+    u64 wo = 0, wl = 0, wr = 0, todo = 0;
+    bool fresh = true;                                          // the window has to be loaded, p stays
+    // the pair in hand (wave-uniform) ...
+    const char *Lp = reinterpret_cast<const char *>(L), *Rp = reinterpret_cast<const char *>(R);
+    char *Op = reinterpret_cast<char *>(out);
+    u32 xeB = 0, xbB = 0, rowB = kUB, aB = 0, bB = kBlockBytes;   // xbB >= xeB: used up
+    // ... and this lane's place in it: its unit x, the place y inside the row (= inside the right operand), the start
+    // lu of its left term, the place k inside the term
+    u32 xB = 0, yB = 0, luB = 0, kB = 0;
+    bool done = false;
+    while (!done) {
+        u32 la[kCoopBlocks], ra[kCoopBlocks], oa[kCoopBlocks];
+        const char *lbase[kCoopBlocks], *rbase[kCoopBlocks];
+        char *obase[kCoopBlocks];
+        bool live[kCoopBlocks];
+#pragma unroll
+        for (int m = 0; m < kCoopBlocks; ++m) {
+            while (xbB >= xeB && !done) {                       // (wave-uniform) the next pair with product terms
+                if (todo == 0ull) {
+                    if (!fresh)
+                        p += kWave - 1u;
+                    if (p >= batch) {
+                        done = true;
+                        break;
+                    }
+                    const u32 pi = min(p + lane, batch);
+                    wo = offOut[pi];
+                    wl = offL[pi];
+                    wr = offR[pi];
+                    const u64 wo_next = (u64)__shfl_down(wo, 1, kWave);
+                    todo = __ballot(lane < kWave - 1u && p + lane < batch && wo_next > wo);
+                    fresh = false;
+                    continue;
+                }
+                const u32 j = (u32)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const u64 o0 = readlane64(wo, j), o1 = readlane64(wo, j + 1u);
+                const u64 fv = o0 * U + (u64)vw * (p + j);      // where the pair starts on the virtual axis
+                if (fv >= v1) {
+                    done = true;
+                    break;
+                }
+                const u64 pair_units = (o1 - o0) * U;
+                const u64 xs = v0 > fv ? min(v0 - fv, pair_units) : 0ull;
+                const u64 end = min(pair_units, v1 - fv);
+                if (xs >= end)
+                    continue;                                   // only the pair's padding is in this stretch
+                const u64 l0 = readlane64(wl, j), r0 = readlane64(wr, j), r1 = readlane64(wr, j + 1u);
+                Lp = reinterpret_cast<const char *>(L + l0 * U);
+                Rp = reinterpret_cast<const char *>(R + r0 * U);
+                Op = reinterpret_cast<char *>(out + o0 * U);
+                const u32 rowlen = (u32)(r1 - r0) * U;
+                const u32 x = (u32)xs + lane;
+                u32 row = 0, y = x;
+                if ((u32)end > rowlen) {                        // more than the first row: one division per lane
+                    row = x / rowlen;
+                    y = x - row * rowlen;
+                }
+                xbB = (u32)xs * kUB;
+                xeB = (u32)end * kUB;
+                rowB = rowlen * kUB;
+                xB = x * kUB;
+                yB = y * kUB;
+                luB = row * termB;
+                kB = (x - csgn_fastdiv(x, dU) * U) * kUB;       // rowlen is a multiple of U
+                const u32 a = rowlen <= kWave ? kWave / rowlen : 0u;     // one block on: a rows and bB bytes
+                bB = kBlockBytes - a * rowB;
+                aB = a * termB;
+            }
+            live[m] = !done && xB < xeB;
+            lbase[m] = Lp;
+            rbase[m] = Rp;
+            obase[m] = Op;
+            la[m] = live[m] ? luB + kB : 0u;
+            ra[m] = live[m] ? yB : 0u;
+            oa[m] = xB;
+            xbB += kBlockBytes;
+            xB += kBlockBytes;
+            yB += bB;
+            luB += aB;
+            if (yB >= rowB) {
+                yB -= rowB;
+                luB += termB;
+            }
+            kB += kstepB;
+            kB = kB >= termB ? kB - termB : kB;
+        }
+        Unit lv[kCoopBlocks], rv[kCoopBlocks];
+#pragma unroll
+        for (int m = 0; m < kCoopBlocks; ++m) {                 // unconditional (a pair's first unit for idle lanes)
+            lv[m] = *reinterpret_cast<const Unit *>(lbase[m] + la[m]);
+            rv[m] = *reinterpret_cast<const Unit *>(rbase[m] + ra[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < kCoopBlocks; ++m)
+            if (live[m])
+                unit_store<Unit, true>(reinterpret_cast<Unit *>(obase[m] + oa[m]), lv[m] & rv[m]);
+    }
+}
+
 // one pair's share of the checksum of the offset arrays: one splitmix64 of the three entries folded together and
 // salted with the position (round 4; three splitmix64 per pair until then -- 64-bit multiplies run at a quarter of
 // the rate, and hashing four pairs a thread that way took the plan kernel 3.3 us of its 19)
@@ -1333,8 +1501,18 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         if (too_much(slice_units))
             slice_touch = false;
     }
-    auto flat_range = [&](u64 range_begin, u64 range_end) -> hipError_t {
+    // The wave-cooperative kernel (k_mul_ragged_coop): a pair's stretch is addressed by 32-bit unit offsets from the
+    // pair's bases, so the largest product of the batch must stay under 2^28 units (4 GiB).
+    // (csgn_mul_ragged_async does not know the shapes: the caller's bound on the whole output stands in.)
+    const u64 pair_bound = d_gate ? total_out_terms : max_t1 * max_t2;
+    // It is for SMALL pairs, not tiny ones: a single-term pair costs a wave a block of its own, and a stretch of
+    // them leaves the wave with a sixth of its lanes at work (65 535 singles: 3.1 TB/s against the CSR kernel's 3.5, a
+    // million: 1.7 against 4.0).  Auto (-1): where the range averages 16 product terms a pair and more.
+    const int coop_mode = csgn::tune(TUNE_RAGGED_COOP);
+    const bool coop_ok = coop_mode != 0 && pair_bound * U < (1ull << 28) && skip_t1 == 0;
+    auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
         const u64 range_units = range_end - range_begin;
+        const bool coop = coop_ok && (coop_mode == 1 || range_units / U >= 16u * range_pairs);
         const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
@@ -1345,6 +1523,28 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                 k_touch_ragged<<<2048, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
                                                    reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
                                                    u0 / U, (u0 + nu + U - 1) / U, (u64)dL * 8u, d_gate);
+            if (coop) {
+                // the whole output in one launch: the virtual axis with 64 units of padding per pair, stretches sized for
+                // >= 16 K waves but 8 to 64 blocks each; a slice of a large output: the unit axis, 16 blocks a wave
+                const bool whole_output = u0 == 0 && nu == total_units;
+                const u32 vw = whole_output ? kWave : 0u;
+                const u64 v_begin = u0, v_end = u0 + nu + (u64)vw * batch;
+                u32 span = whole_output ? (u32)std::min<u64>(4096, std::max<u64>(512, ((v_end - v_begin) / 16384u) & ~63ull)) : 1024u;
+                if (csgn::tune(TUNE_RAGGED_COOP_SPAN) > 0)
+                    span = kWave * (u32)csgn::tune(TUNE_RAGGED_COOP_SPAN);
+                const u64 wgs = (v_end - v_begin + 4ull * span - 1) / (4ull * span);
+                if (wgs > kMaxBlocks256)
+                    return hipErrorInvalidValue;
+                if (wide)
+                    k_mul_ragged_coop<unit16><<<(u32)wgs, 256, 0, s>>>(
+                        reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
+                        reinterpret_cast<unit16 *>(out), offOut, (u32)batch, v_begin, v_end, U, dU, span, vw, d_gate);
+                else
+                    k_mul_ragged_coop<unit8><<<(u32)wgs, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, v_begin,
+                                                                     v_end, U, dU, span, vw, d_gate);
+                result = hipGetLastError();
+                continue;
+            }
 #define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
     do {                                                                                            \
         if (wide)                                                                                   \
@@ -1385,7 +1585,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // is worth a launch of its own (24 MB of output: ~3.5 us of HBM time against ~3 launches); the CSR
     // kernel runs on the stretches between them.  Knob ragged_flat = 1 keeps everything in the CSR kernel.
     const bool planned = remembered && csgn::tune(TUNE_RAGGED_FLAT) == 0 && rp.n != 0;
-    u64 cursor = 0;
+    u64 cursor = 0, cursor_pair = 0;
     // ... and only when those pairs are most of the batch: every split costs launches (a uniform one and the
     // CSR kernel's on either side, each with its own ramp and tail), which a few 30 MB pairs inside a 2.8 GB
     // log-normal batch do not repay (measured: 5.03 TB/s split, 5.35 unsplit)
@@ -1404,7 +1604,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             if (!split || pb >= batch || t1 * t2 * dL * 8u < (24ull << 20) || o0 + t1 * t2 > total_out_terms || o0 * U < cursor)
                 continue;
             if (o0 * U > cursor) {
-                const hipError_t e = flat_range(cursor, o0 * U);
+                const hipError_t e = flat_range(cursor, o0 * U, pb > cursor_pair ? pb - cursor_pair : 1);
                 if (e != hipSuccess)
                     return e;
             }
@@ -1412,11 +1612,12 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             if (e != hipSuccess)
                 return e;
             cursor = (o0 + t1 * t2) * U;
+            cursor_pair = pb + 1;
         }
     }
     hipError_t result = hipSuccess;
     if (cursor < total_units)
-        result = flat_range(cursor, total_units);
+        result = flat_range(cursor, total_units, batch > cursor_pair ? batch - cursor_pair : 1);
     return result;
 }
 

@@ -38,6 +38,8 @@ enum TuneKey {
     TUNE_COMPACT_NT,     // compaction: 1 = non-temporal stores of the surviving terms
     TUNE_COMPACT_GRID,   // compaction: workgroups of the main kernel, 0 = 512 (two per CU)
     TUNE_RAGGED_CLASSES, // planned ragged multiply: 1 = the plan lists small pairs by size class and the multiply gives every class its own tiled launch (measured slower than the CSR kernel: off by default)
+    TUNE_RAGGED_COOP,    // ragged multiply of small pairs: 1 = the wave-cooperative kernel (a wave walks its pairs together: no per-lane search or division), 0 = the CSR kernel, -1 = auto
+    TUNE_RAGGED_COOP_SPAN, // ... 64-unit blocks of output per wave (0 = 64)
     TUNE_COUNT
 };
 

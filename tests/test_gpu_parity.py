@@ -2322,6 +2322,50 @@ def test_ragged_long_tailed_small_pairs(hip, oracle, knobs, n, mu, batch):
         assert np.array_equal(hip.download(out[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
 
 
+@pytest.mark.parametrize("n", [63, 1247, 4096])
+def test_ragged_cooperative_kernel_matches_the_csr_kernel(hip, oracle, knobs, n):
+    """k_mul_ragged_coop (knob ragged_coop = 1): a wave walks the pairs of its stretch of the output together.  Same
+    words as the CSR kernel for a batch with empty pairs and runs of them longer than the 63-pair window, 1 x 1 pairs,
+    rows shorter and longer than a block, one pair far larger than a wave's stretch -- for stretches of 1, 3 and 64
+    blocks per wave (every stretch boundary inside a pair, inside a row, between pairs) -- and through
+    csgn_mul_ragged_async; a sample of pairs against the oracle."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n)
+    t1s = np.concatenate([[1, 0, 0, 90, 1], np.zeros(200, int), [2, 3], np.ones(70, int), [0, 7, 300],
+                          np.clip(rng.lognormal(1.4, 1, 3000), 1, 200).astype(int), [0, 0, 1]])
+    t2s = np.concatenate([[1, 5, 0, 70, 1], np.zeros(200, int), [3, 2], np.ones(70, int), [9, 0, 250],
+                          np.clip(rng.lognormal(1.4, 1, 3000), 1, 200).astype(int), [3, 0, 1]])
+    batch = len(t1s)
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    total = int(np.sum(t1s * t2s))
+    L = hip.synth_fill(95, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(96, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    knobs.set("ragged_flat", 1)                     # everything through the ragged kernels (no per-pair uniform launches)
+    knobs.set("ragged_coop", 0)
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+    ref = ref.clone()
+    knobs.set("ragged_coop", 1)
+    for span in (1, 3, 0):
+        knobs.set("ragged_coop_span", span)
+        got, off = hip.mul_ragged(n, L, dOL, R, dOR)
+        assert torch.equal(off, ref_off)
+        assert torch.equal(got, ref), span
+        guard = hip.empty_words((total + 7) * dl)
+        guard.fill_(0x5A5A5A5A)
+        out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total + 7, out=guard)
+        assert hip.mul_ragged_async_result(plan)[0] == total
+        assert torch.equal(out[:total * dl], ref[:total * dl]), span
+        assert bool((out[total * dl:] == 0x5A5A5A5A).all())        # nothing past the real end
+    mo = hip.download(ref_off)
+    hl, hr = hip.download(L), hip.download(R)
+    for b in [0, 3, 207, 208, 279, 280, 281, batch - 1] + rng.integers(282, batch - 3, 12).tolist():
+        if t1s[b] and t2s[b]:
+            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+            assert np.array_equal(hip.download(got[int(mo[b]) * dl:int(mo[b + 1]) * dl]), want), b
+
+
 @pytest.mark.parametrize("n", [1247, 4096])
 def test_ragged_size_classes_match_the_csr_kernel(hip, oracle, knobs, n):
     """Size classes (round 4; measured slower than the CSR kernel and therefore off unless knob ragged_classes = 1):

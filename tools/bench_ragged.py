@@ -12,8 +12,11 @@ VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_R
           ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('cold C=16',{'CSGN_RAGGED_C':'16'}),('cold C=8 M=2',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_M':'2'}),('cold C=8 no pf',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_PF':'0'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
           ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
 if os.environ.get('SHORT'):          # SHORT=1: the default dispatch, size classes off, CSR kernel alone
-    VARIANTS=[('cold',{}),('cold, size classes off',{'CSGN_RAGGED_CLASSES':'0'}),('same operands',{'NSETS':'1'}),
-              ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
+    VARIANTS=[('cold',{}),('same operands',{'NSETS':'1'}),
+              ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'}),
+              ('coop: cold',{'CSGN_RAGGED_COOP':'1'}),('coop span 16',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_SPAN':'16'}),
+              ('coop span 256',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_SPAN':'256'}),
+              ('coop, CSR forced',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_FLAT':'1'}),('coop auto',{'CSGN_RAGGED_COOP':'-1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
