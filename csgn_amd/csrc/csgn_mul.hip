@@ -430,7 +430,52 @@ __device__ inline u64 readlane64(u64 v, u32 j)
 // units of padding per pair before it (vw = 64 for a launch over the whole output; 0, the plain unit axis, for the
 // slices of a large output, whose ends the host knows in units only).  Stretches of equal virtual length hold at most
 // twice the blocks of one another, and nothing but offOut is needed to find them.
-constexpr int kCoopBlocks = 4;
+// Two things about waiting (round 4, second form; rocprofv3 --pmc on the first: waves parked 65 % of their cycles):
+//   * the offset window lives in registers across the loop; left alone, the compiler cannot tell that its three loads
+//     have landed and puts s_waitcnt vmcnt(0) in front of every v_readlane of them -- a full drain of the wave's
+//     loads and stores at EVERY pair.  The window is waited for once, where it is loaded (once per 63 pairs).
+//   * gfx9 counts loads AND stores in one in-order counter (vmcnt): a wave that waits for loads it issued after a
+//     batch of stores also waits for those stores to be acknowledged by L2, microseconds under write load.  The walk is
+//     therefore software-pipelined over two groups of K blocks -- the loads of group B are issued BEFORE group A is
+//     stored, so the wait in front of A's stores can count PAST B's loads and the stores before them: a wave never
+//     waits for a store.  The compiler's own counting cannot express this (a store it may skip when no lane is live
+//     makes it count the shorter path, and it waits for the stores after all; its register reuse put full drains in
+//     front of the loads besides), so in the PIPE form the operand loads and the waits are inline assembly and the
+//     counts are ours:
+//         fill(X) issues exactly 2K loads; put(X) of a group filled before the end of the stretch issues exactly K
+//         stores (every block generated before `done` has its first lane live, so no store is skipped);
+//         in front of put(A):  ... L(A) | S(B') L(B)  -> vmcnt(3K) leaves L(A) landed
+//     What the compiler adds for the loads it does know (the window, the start-up search) only waits for MORE.
+//     The one thing that must not happen is a copy of a loaded register between its load and its wait (the compiler
+//     thinks the value is there): tests/test_capi_symbols.py::test_coop_kernel_isa_keeps_loaded_registers_untouched
+//     disassembles the kernel and checks.
+// Everything the walk branches on is wave-uniform, and the wave index is read through readfirstlane so that the
+// compiler knows it too (scalar branches and SGPR bases instead of exec masks and VGPR copies).
+template <typename Unit, int K>
+struct CoopGroup {
+    Unit lv[K], rv[K];
+    char *obase[K];
+    u32 oa[K];
+    bool live[K];
+};
+
+// global_load of one unit outside the compiler's books.  The address is a VGPR pair: an SGPR base would have to be
+// five wait states old if a VALU instruction wrote it (v_readlane, a reload of a spilled SGPR), and the hazard
+// recogniser does not look inside inline assembly.  The stores stay the compiler's (it never waits for a store, and it
+// knows the wait state a 16-byte store's data registers need).
+__device__ inline void coop_load_asm(unit16 &d, const char *addr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(addr));
+}
+__device__ inline void coop_load_asm(unit8 &d, const char *addr)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(addr));
+}
+template <int N>
+__device__ inline void coop_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
 
 // largest p in [0, batch) with f(p) <= target (f(0) = 0 <= target), by a whole wave: wave_find on the virtual axis
 __device__ inline u32 wave_find_virtual(const u64 *__restrict__ offOut, u32 batch, u32 U, u32 vw, u64 target)
@@ -445,26 +490,39 @@ __device__ inline u32 wave_find_virtual(const u64 *__restrict__ offOut, u32 batc
         lo += (c - 1u) * s;
         hi = min(lo + s, hi);
     }
-    return lo;
+    return (u32)__builtin_amdgcn_readfirstlane((int)lo);
 }
 
-template <typename Unit>
+#ifdef CSGN_COOP_STAMPS     // dev (tools/coop_probe.hip): every wave leaves {cycles: whole, search, waits; blocks, pairs, windows} behind
+__device__ u64 *g_coop_stamps;
+#define CSGN_CSTAMP(...) __VA_ARGS__
+#else
+#define CSGN_CSTAMP(...)
+#endif
+
+template <typename Unit, int K, bool PIPE>
 __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict__ L, const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R, const u64 *__restrict__ offR,
                                                          Unit *__restrict__ out, const u64 *__restrict__ offOut,
                                                          u32 batch, u64 v_begin, u64 v_end, u32 U, FastDiv dU,
                                                          u32 span, u32 vw, const u64 *__restrict__ d_gate)
 {
-    // csgn_mul_ragged_async: the grid was sized for the caller's bound, the real end is in the gate
-    if (d_gate)
-        v_end = min(v_end, d_gate[0] * U + (u64)vw * batch);
-    const u32 lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    // csgn_mul_ragged_async: the grid was sized for the caller's bound, the real end is in the gate (0: nothing is to be
+    // written -- the products do not fit the bound, or the 1x1 stream kernel has the batch)
+    if (d_gate) {
+        const u64 real_terms = d_gate[0];
+        v_end = real_terms ? min(v_end, real_terms * U + (u64)vw * batch) : 0ull;
+    }
+    const u32 lane = threadIdx.x & (kWave - 1);
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const u64 v0 = v_begin + ((u64)bid * 4u + wv) * span;       // this wave's stretch of the virtual axis
     if (v0 >= v_end)
         return;
     const u64 v1 = min(v0 + span, v_end);
+    CSGN_CSTAMP(const u64 st_begin = __builtin_readcyclecounter(); u64 st_wait = 0; u32 st_blocks = 0, st_pairs = 0, st_windows = 0;)
     u32 p = wave_find_virtual(offOut, batch, U, vw, v0);        // the pair v0 falls in (its units or its padding)
+    CSGN_CSTAMP(const u64 st_found = __builtin_readcyclecounter();)
     // From here on every place is a BYTE offset from a wave-uniform base, 32 bits wide (a pair's product stays under
     // 4 GiB: the launcher's condition) -- an SGPR base plus one VGPR per address instead of a 64-bit VGPR pair each.
     constexpr u32 kUB = (u32)sizeof(Unit), kBlockBytes = kWave * kUB;
@@ -481,13 +539,12 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
     // lu of its left term, the place k inside the term
     u32 xB = 0, yB = 0, luB = 0, kB = 0;
     bool done = false;
-    while (!done) {
-        u32 la[kCoopBlocks], ra[kCoopBlocks], oa[kCoopBlocks];
-        const char *lbase[kCoopBlocks], *rbase[kCoopBlocks];
-        char *obase[kCoopBlocks];
-        bool live[kCoopBlocks];
+    // the places of the next K blocks, their operand loads issued
+    auto fill = [&](CoopGroup<Unit, K> &g) {
+        u32 la[K], ra[K];
+        const char *lbase[K], *rbase[K];
 #pragma unroll
-        for (int m = 0; m < kCoopBlocks; ++m) {
+        for (int m = 0; m < K; ++m) {
             while (xbB >= xeB && !done) {                       // (wave-uniform) the next pair with product terms
                 if (todo == 0ull) {
                     if (!fresh)
@@ -500,6 +557,8 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
                     wo = offOut[pi];
                     wl = offL[pi];
                     wr = offR[pi];
+                    asm volatile("" : "+v"(wo), "+v"(wl), "+v"(wr));   // all three landed HERE (see above)
+                    CSGN_CSTAMP(++st_windows;)
                     const u64 wo_next = (u64)__shfl_down(wo, 1, kWave);
                     todo = __ballot(lane < kWave - 1u && p + lane < batch && wo_next > wo);
                     fresh = false;
@@ -539,14 +598,16 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
                 const u32 a = rowlen <= kWave ? kWave / rowlen : 0u;     // one block on: a rows and bB bytes
                 bB = kBlockBytes - a * rowB;
                 aB = a * termB;
+                CSGN_CSTAMP(++st_pairs;)
             }
-            live[m] = !done && xB < xeB;
+            CSGN_CSTAMP(st_blocks += done ? 0u : 1u;)
+            g.live[m] = !done && xB < xeB;
             lbase[m] = Lp;
             rbase[m] = Rp;
-            obase[m] = Op;
-            la[m] = live[m] ? luB + kB : 0u;
-            ra[m] = live[m] ? yB : 0u;
-            oa[m] = xB;
+            g.obase[m] = Op;
+            la[m] = g.live[m] ? luB + kB : 0u;
+            ra[m] = g.live[m] ? yB : 0u;
+            g.oa[m] = xB;
             xbB += kBlockBytes;
             xB += kBlockBytes;
             yB += bB;
@@ -558,17 +619,101 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
             kB += kstepB;
             kB = kB >= termB ? kB - termB : kB;
         }
-        Unit lv[kCoopBlocks], rv[kCoopBlocks];
 #pragma unroll
-        for (int m = 0; m < kCoopBlocks; ++m) {                 // unconditional (a pair's first unit for idle lanes)
-            lv[m] = *reinterpret_cast<const Unit *>(lbase[m] + la[m]);
-            rv[m] = *reinterpret_cast<const Unit *>(rbase[m] + ra[m]);
+        for (int m = 0; m < K; ++m) {                           // unconditional (a pair's first unit for idle lanes)
+#if defined(CSGN_COOP_STAMPS) && defined(COOP_PROBE_NO_LOAD)       // tools/coop_probe.hip: the walk and the stores alone
+            g.lv[m] = g.rv[m] = Unit{} + (Unit)(la[m] + ra[m]);
+            continue;
+#endif
+            if (PIPE) {
+                coop_load_asm(g.lv[m], lbase[m] + la[m]);
+                coop_load_asm(g.rv[m], rbase[m] + ra[m]);
+            } else {
+                g.lv[m] = *reinterpret_cast<const Unit *>(lbase[m] + la[m]);
+                g.rv[m] = *reinterpret_cast<const Unit *>(rbase[m] + ra[m]);
+            }
         }
+    };
+    auto put = [&](CoopGroup<Unit, K> &g) {
+        // (not PIPE) every load of the group is waited for HERE, on all paths: a wait left inside `if (live)` leaves
+        // the loads of an idle block pending in the compiler's books, and the next fill's first write to those
+        // registers then costs a vmcnt(0).  (PIPE) the values pass through here on their way from the wait to the
+        // stores, so nothing that uses them can be scheduled in front of it.
 #pragma unroll
-        for (int m = 0; m < kCoopBlocks; ++m)
-            if (live[m])
-                unit_store<Unit, true>(reinterpret_cast<Unit *>(obase[m] + oa[m]), lv[m] & rv[m]);
+        for (int m = 0; m < K; ++m)
+            asm volatile("" : "+v"(g.lv[m]), "+v"(g.rv[m]));
+#if defined(CSGN_COOP_STAMPS) && defined(COOP_PROBE_NO_STORE)      // tools/coop_probe.hip: the walk and the loads alone
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            Unit v = g.lv[m] & g.rv[m];
+            asm volatile("" : : "v"(v));
+        }
+        return;
+#endif
+#pragma unroll
+        for (int m = 0; m < K; ++m)
+            if (g.live[m])
+                unit_store<Unit, true>(reinterpret_cast<Unit *>(g.obase[m] + g.oa[m]), g.lv[m] & g.rv[m]);
+    };
+    CoopGroup<Unit, K> A, B;
+#ifdef CSGN_COOP_STAMPS
+#define CSGN_COOP_WAIT(N) do { const u64 w0 = __builtin_readcyclecounter(); coop_wait<N>(); asm volatile("" ::: "memory"); st_wait += __builtin_readcyclecounter() - w0; } while (0)
+#define CSGN_COOP_LEAVE() do { if (lane == 0) { u64 *st = g_coop_stamps + ((u64)bid * 4u + wv) * 8u; st[0] = __builtin_readcyclecounter() - st_begin; st[1] = st_found - st_begin; st[2] = st_wait; st[3] = st_blocks; st[4] = st_pairs; st[5] = st_windows; st[6] = st_begin; } } while (0)
+#else
+#define CSGN_COOP_WAIT(N) coop_wait<N>()
+#define CSGN_COOP_LEAVE() do {} while (0)
+#endif
+    if (!PIPE) {                                                // loads, wait, stores; the compiler counts
+        do {
+            fill(A);
+            put(A);
+        } while (!done);
+        CSGN_COOP_LEAVE();
+        return;
     }
+    // Every wait in the loop is the same vmcnt(3K), on every path (no flag to follow in the generated code:
+    // tools/check_coop_isa.py walks it).  The first turn has no group A yet: put(A) stores nothing (no lane live), and K
+    // one-dword loads of nothing stand in for its K stores so that the count in front of put(B) holds.  Their
+    // destinations are kept alive (an empty asm per turn) until the wait at the top of the second turn has retired them:
+    // registers the compiler took for dead would be handed out while the loads are still in flight.
+#pragma unroll
+    for (int m = 0; m < K; ++m)
+        A.live[m] = false;
+    u32 stand_in[K];
+#pragma unroll
+    for (int m = 0; m < K; ++m)
+        stand_in[m] = 0;
+    bool first = true;
+    for (;;) {
+        fill(B);                                                // 2K loads
+        CSGN_COOP_WAIT(3 * K);                                  // ... L(A) | S(B') L(B): L(A) has landed
+#pragma unroll
+        for (int m = 0; m < K; ++m)
+            asm volatile("" : "+v"(stand_in[m]));
+        put(A);                                                 // K stores
+        if (first) {
+#pragma unroll
+            for (int m = 0; m < K; ++m)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(stand_in[m]) : "v"(L));
+            first = false;
+        }
+        if (done) {
+            CSGN_COOP_WAIT(0);
+            put(B);
+            break;
+        }
+        fill(A);
+        CSGN_COOP_WAIT(3 * K);                                  // L(B) | S(A) L(A'): L(B) has landed
+        put(B);
+        if (done) {
+            CSGN_COOP_WAIT(0);
+            put(A);
+            break;
+        }
+    }
+    CSGN_COOP_LEAVE();
+#undef CSGN_COOP_WAIT
+#undef CSGN_COOP_LEAVE
 }
 
 // one pair's share of the checksum of the offset arrays: one splitmix64 of the three entries folded together and
@@ -1535,13 +1680,31 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                 const u64 wgs = (v_end - v_begin + 4ull * span - 1) / (4ull * span);
                 if (wgs > kMaxBlocks256)
                     return hipErrorInvalidValue;
-                if (wide)
-                    k_mul_ragged_coop<unit16><<<(u32)wgs, 256, 0, s>>>(
-                        reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR,
-                        reinterpret_cast<unit16 *>(out), offOut, (u32)batch, v_begin, v_end, U, dU, span, vw, d_gate);
-                else
-                    k_mul_ragged_coop<unit8><<<(u32)wgs, 256, 0, s>>>(L, offL, R, offR, out, offOut, (u32)batch, v_begin,
-                                                                     v_end, U, dU, span, vw, d_gate);
+                const bool k2 = csgn::tune(TUNE_RAGGED_COOP_K) == 2, pipe = csgn::tune(TUNE_RAGGED_COOP_PIPE) != 0;
+#define CSGN_COOP(UNIT, KK)                                                                         \
+    if (pipe)                                                                                       \
+        CSGN_COOP_(UNIT, KK, true);                                                                 \
+    else                                                                                            \
+        CSGN_COOP_(UNIT, KK, false)
+#define CSGN_COOP_(UNIT, KK, PP)                                                                    \
+    k_mul_ragged_coop<UNIT, KK, PP><<<(u32)wgs, 256, 0, s>>>(                                           \
+        reinterpret_cast<const UNIT *>(L), offL, reinterpret_cast<const UNIT *>(R), offR,           \
+        reinterpret_cast<UNIT *>(out), offOut, (u32)batch, v_begin, v_end, U, dU, span, vw, d_gate)
+                if (wide) {
+                    if (k2) {
+                        CSGN_COOP(unit16, 2);
+                    } else {
+                        CSGN_COOP(unit16, 4);
+                    }
+                } else {
+                    if (k2) {
+                        CSGN_COOP(unit8, 2);
+                    } else {
+                        CSGN_COOP(unit8, 4);
+                    }
+                }
+#undef CSGN_COOP
+#undef CSGN_COOP_
                 result = hipGetLastError();
                 continue;
             }

@@ -38,8 +38,10 @@ enum TuneKey {
     TUNE_COMPACT_NT,     // compaction: 1 = non-temporal stores of the surviving terms
     TUNE_COMPACT_GRID,   // compaction: workgroups of the main kernel, 0 = 512 (two per CU)
     TUNE_RAGGED_CLASSES, // planned ragged multiply: 1 = the plan lists small pairs by size class and the multiply gives every class its own tiled launch (measured slower than the CSR kernel: off by default)
-    TUNE_RAGGED_COOP,    // ragged multiply of small pairs: 1 = the wave-cooperative kernel (a wave walks its pairs together: no per-lane search or division), 0 = the CSR kernel, -1 = auto
+    TUNE_RAGGED_COOP,    // ragged multiply of small pairs: 1 = the wave-cooperative kernel (a wave walks its pairs together: no per-lane search or division), 0 = the CSR kernel, -1 = auto (the default: ranges that average 16 product terms a pair and more)
     TUNE_RAGGED_COOP_SPAN, // ... 64-unit blocks of output per wave (0 = 64)
+    TUNE_RAGGED_COOP_K,  // ... blocks per group of the software pipeline: 2 or 4 (0 = 4)
+    TUNE_RAGGED_COOP_PIPE, // ... 1 = software-pipelined form (loads of the next group in front of the stores of this one; hand-counted waits), 0 = loads, wait, stores
     TUNE_COUNT
 };
 

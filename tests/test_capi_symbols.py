@@ -267,3 +267,20 @@ def test_size_guards_do_not_wrap(lib):
     assert lib.csgn_circuit_input(c, 1 << 30, C.byref(b)) == 0
     assert lib.csgn_circuit_mul(c, a, b, C.byref(o)) == -2
     lib.csgn_circuit_destroy(c)
+
+
+def test_coop_kernel_isa_keeps_loaded_registers_untouched():
+    """k_mul_ragged_coop's pipelined form issues its operand loads from inline assembly and retires them with
+    hand-counted `s_waitcnt vmcnt(N)`: the compiler believes the loaded registers hold their values at once, so a copy
+    of one (a live-range split, a phi) placed in front of the wait would read a register the load has not written yet.
+    tools/check_coop_isa.py compiles csgn_mul.hip to gfx950 assembly and walks the control-flow graph from every such
+    load to the wait that retires it; no instruction on the way may touch the destination."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this machine")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_coop_isa.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 findings") == 4, r.stdout           # unit16 / unit8 x 2 / 4 blocks per group

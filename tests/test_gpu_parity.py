@@ -2347,17 +2347,26 @@ def test_ragged_cooperative_kernel_matches_the_csr_kernel(hip, oracle, knobs, n)
     ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
     ref = ref.clone()
     knobs.set("ragged_coop", 1)
-    for span in (1, 3, 0):
+    # the software-pipelined form (hand-counted waits) and the plain one, 2 and 4 blocks per group
+    for span, k, pipe in [(1, 4, 1), (3, 4, 1), (0, 4, 1), (1, 2, 1), (3, 2, 1), (0, 2, 1), (2, 4, 1), (5, 2, 1), (7, 4, 1),
+                          (1, 4, 0), (3, 2, 0), (0, 4, 0)]:
         knobs.set("ragged_coop_span", span)
+        knobs.set("ragged_coop_k", k)
+        knobs.set("ragged_coop_pipe", pipe)
         got, off = hip.mul_ragged(n, L, dOL, R, dOR)
         assert torch.equal(off, ref_off)
-        assert torch.equal(got, ref), span
+        assert torch.equal(got, ref), (span, k, pipe)
         guard = hip.empty_words((total + 7) * dl)
         guard.fill_(0x5A5A5A5A)
         out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total + 7, out=guard)
         assert hip.mul_ragged_async_result(plan)[0] == total
-        assert torch.equal(out[:total * dl], ref[:total * dl]), span
+        assert torch.equal(out[:total * dl], ref[:total * dl]), (span, k, pipe)
         assert bool((out[total * dl:] == 0x5A5A5A5A).all())        # nothing past the real end
+        if span == 3:                                              # a bound that is too small: the gate is 0, nothing is written
+            guard.fill_(0x5A5A5A5A)
+            out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total - 1, out=guard)
+            assert hip.mul_ragged_async_result(plan)[4] == 1
+            assert bool((guard == 0x5A5A5A5A).all()), (span, k, pipe)
     mo = hip.download(ref_off)
     hl, hr = hip.download(L), hip.download(R)
     for b in [0, 3, 207, 208, 279, 280, 281, batch - 1] + rng.integers(282, batch - 3, 12).tolist():

@@ -14,9 +14,11 @@ VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_R
 if os.environ.get('SHORT'):          # SHORT=1: the default dispatch, size classes off, CSR kernel alone
     VARIANTS=[('cold',{}),('same operands',{'NSETS':'1'}),
               ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'}),
-              ('coop: cold',{'CSGN_RAGGED_COOP':'1'}),('coop span 16',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_SPAN':'16'}),
-              ('coop span 256',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_SPAN':'256'}),
-              ('coop, CSR forced',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_FLAT':'1'}),('coop auto',{'CSGN_RAGGED_COOP':'-1'})]
+              ('coop k4 pipe',{'CSGN_RAGGED_COOP':'1'}),('coop k2 pipe',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2'}),
+              ('coop k4 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_PIPE':'0'}),('coop k2 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2','CSGN_RAGGED_COOP_PIPE':'0'}),
+              ('coop k2 pipe span 16',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2','CSGN_RAGGED_COOP_SPAN':'16'}),
+              ('coop k2 pipe span 128',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2','CSGN_RAGGED_COOP_SPAN':'128'}),
+              ('coop auto',{'CSGN_RAGGED_COOP':'-1'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
