@@ -652,8 +652,13 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
 #endif
 #pragma unroll
         for (int m = 0; m < K; ++m)
-            if (g.live[m])
+            if (g.live[m]) {
+#if defined(CSGN_COOP_STAMPS) && defined(COOP_PROBE_PLAIN_STORE)   // tools/coop_probe.hip: ordinary stores instead of non-temporal ones
+                unit_store<Unit, false>(reinterpret_cast<Unit *>(g.obase[m] + g.oa[m]), g.lv[m] & g.rv[m]);
+#else
                 unit_store<Unit, true>(reinterpret_cast<Unit *>(g.obase[m] + g.oa[m]), g.lv[m] & g.rv[m]);
+#endif
+            }
     };
     CoopGroup<Unit, K> A, B;
 #ifdef CSGN_COOP_STAMPS
@@ -1645,6 +1650,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             slice_units >>= 1;
         if (too_much(slice_units))
             slice_touch = false;
+    }
+    if (csgn::tune(TUNE_RAGGED_SLICE_MB) > 0) {                  // (experiments: slices of this many MiB, touched)
+        slice_units = ((u64)csgn::tune(TUNE_RAGGED_SLICE_MB) << 20) / sizeof(unit16);
+        slice_touch = true;
     }
     // The wave-cooperative kernel (k_mul_ragged_coop): a pair's stretch is addressed by 32-bit unit offsets from the
     // pair's bases, so the largest product of the batch must stay under 2^28 units (4 GiB).
