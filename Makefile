@@ -44,6 +44,15 @@ tools/bin/bench_native: tools/bench_native.cpp $(LIBDIR)/libcsgn_hip.so $(LIBDIR
 	$(CXX) -std=c++11 -O2 -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_shard -lcsgn_hip -lpthread \
 	    '-Wl,-rpath,$(abspath $(LIBDIR))' '-Wl,-rpath,$(abspath $(ROCM_LIB))'
 
+# dev probes: per-wave cycle stamps of the wave-cooperative ragged multiply; scalar-path touch rate
+tools/bin/coop_probe: tools/coop_probe.hip $(HIP_SRC) $(HIP_HDR)
+	mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DCSGN_COOP_STAMPS $(COOP_PROBE_FLAGS) -Iinclude -I$(CSRC) -o $@ tools/coop_probe.hip $(CSRC)/csgn_tuning.cpp
+
+tools/bin/sprefetch_bench: tools/sprefetch_bench.hip
+	mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -o $@ $<
+
 tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
 	mkdir -p tools/bin
 	$(CXX) -std=c++11 -O2 -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_hip '-Wl,-rpath,$(abspath $(LIBDIR))'

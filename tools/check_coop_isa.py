@@ -30,7 +30,7 @@ def compile_asm():
 
 
 def kernels(path):
-    """{mangled name: [lines]} of the PIPE = true instantiations"""
+    """{mangled name: [lines]} of every instantiation (PIPE = true: ...Lb1E...)"""
     res, cur, name = {}, None, None
     for ln in open(path):
         m = re.match(r"^(_ZN4csgn\S*k_mul_ragged_coop\S*):", ln)
@@ -43,7 +43,7 @@ def kernels(path):
                 cur = None
             else:
                 cur.append(ln.rstrip("\n"))
-    return {k: v for k, v in res.items() if "Lb1E" in k}
+    return res
 
 
 def vregs(text):
@@ -168,7 +168,7 @@ def main():
         for x in f[:10]:
             print("   ", x)
         bad += len(f)
-        if n == 0:
+        if n == 0 and "Lb1E" in name:
             print("    no inline-assembly load found: the kernel changed, update this check")
             bad += 1
     return 1 if bad else 0
