@@ -47,7 +47,7 @@ tools/bin/bench_native: tools/bench_native.cpp $(LIBDIR)/libcsgn_hip.so $(LIBDIR
 # dev probes: per-wave cycle stamps of the wave-cooperative ragged multiply; scalar-path touch rate
 tools/bin/coop_probe: tools/coop_probe.hip $(HIP_SRC) $(HIP_HDR)
 	mkdir -p tools/bin
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -DCSGN_COOP_STAMPS $(COOP_PROBE_FLAGS) -Iinclude -I$(CSRC) -o $@ tools/coop_probe.hip $(CSRC)/csgn_tuning.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -Wno-inline-asm -DCSGN_COOP_STAMPS $(COOP_PROBE_FLAGS) -Iinclude -I$(CSRC) -o $@ tools/coop_probe.hip $(CSRC)/csgn_tuning.cpp
 
 tools/bin/sprefetch_bench: tools/sprefetch_bench.hip
 	mkdir -p tools/bin
@@ -59,7 +59,7 @@ tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
 
 $(LIBDIR)/libcsgn_hip.so: $(HIP_SRC) $(HIP_HDR)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Iinclude -I$(CSRC) -o $@ $(HIP_SRC)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wno-inline-asm -Iinclude -I$(CSRC) -o $@ $(HIP_SRC)
 
 $(LIBDIR)/libcertFHE.so: $(CLS_SRC) $(CLS_HDR) $(LIBDIR)/libcsgn_hip.so
 	$(CXX) -std=c++11 -O2 -fPIC -shared -Iinclude -Iinclude/certfhe -o $@ $(CLS_SRC) \

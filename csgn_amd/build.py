@@ -47,7 +47,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "csgn_hip.h")]
     if force or _stale(HIP_LIB, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-Wno-inline-asm",
                "-I" + INCLUDE, "-I" + CSRC, "-o", HIP_LIB] + srcs
         if verbose:
             print(" ".join(cmd))

@@ -500,12 +500,18 @@ __device__ u64 *g_coop_stamps;
 #define CSGN_CSTAMP(...)
 #endif
 
+// The operand touches' destination: v127.  The kernel is compiled for 127 vector registers (amdgpu_num_vgpr: v0 .. v126), so
+// the register allocator never hands v127 out -- a destination it took for dead would be given to another value while
+// touches that write it are still in flight, and a value carried in a variable gets copied between registers (the first
+// build did exactly that; tools/check_coop_isa.py found it) -- and every touch names it as clobbered, so the wave's
+// allocation covers it (128 registers: four waves a SIMD, what the pipelined form has anyway).
+#define CSGN_COOP_TOUCH(ptr) asm volatile("global_load_dword v127, %0, off" : : "v"(ptr) : "v127")
 template <typename Unit, int K, bool PIPE>
-__global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict__ L, const u64 *__restrict__ offL,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(127))) k_mul_ragged_coop(const Unit *__restrict__ L, const u64 *__restrict__ offL,
                                                          const Unit *__restrict__ R, const u64 *__restrict__ offR,
                                                          Unit *__restrict__ out, const u64 *__restrict__ offOut,
                                                          u32 batch, u64 v_begin, u64 v_end, u32 U, FastDiv dU,
-                                                         u32 span, u32 vw, const u64 *__restrict__ d_gate)
+                                                         u32 span, u32 vw, const u64 *__restrict__ d_gate, u32 touch_terms)
 {
     // csgn_mul_ragged_async: the grid was sized for the caller's bound, the real end is in the gate (0: nothing is to be
     // written -- the products do not fit the bound, or the 1x1 stream kernel has the batch)
@@ -539,6 +545,50 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
     // lu of its left term, the place k inside the term
     u32 xB = 0, yB = 0, luB = 0, kB = 0;
     bool done = false;
+    // The operand touch (touch_terms != 0).  Operands of a batch of small pairs are a quarter of its products and cold.  A
+    // line's first load is an HBM round trip, and every other load of that line issued meanwhile -- the next row's block
+    // re-reading the right operand, the next block of the row re-reading the left term -- waits for it inside the L1,
+    // whose pipe is in order: the stores of sixteen waves queue behind (the L1 stalled on its pending queue
+    // 69 % of the time; the same kernel on operands that sit in the memory-side cache needs half the cycles per block).
+    // So a wave that has just loaded an offset window reads ONE dword of every 128-byte line of the operands of the
+    // window's pairs that begin inside its stretch -- 64 lines per instruction, every line once, nothing re-read while it
+    // is on its way -- and only then walks them.  Loads return in order, so the first wait after a window waits for the
+    // touch as well: one HBM round trip per 63 pairs instead of one per cold line.  Left terms of the first pair: from the
+    // row the stretch starts in; of the last pair: to the row it ends in; the first pair's right operand only if the
+    // stretch starts in its first row (else the waves before this one have it in the L2); at most touch_terms terms a side.
+    // The loads are inline assembly and all write v127, which nothing else uses (CSGN_COOP_TOUCH, above the kernel).
+    auto touch_window = [&]() {
+        const u64 fl = wo * U + (u64)vw * (p + lane);
+        const u64 f0 = readlane64(fl, 0);
+        if (f0 >= v1)
+            return;                                             // the walk ends at this pair
+        const u64 inside = __ballot(lane == 0u || (lane < kWave - 1u && p + lane < batch && fl < v1));
+        const u32 last = 63u - (u32)__builtin_clzll(inside);     // pairs 0 .. last of the window begin in front of v1
+        const u64 o0 = readlane64(wo, 0), o1 = readlane64(wo, 1), l0 = readlane64(wl, 0), r0 = readlane64(wr, 0), r1 = readlane64(wr, 1);
+        u64 lo = l0, rlo = r0;
+        const u32 rowlen0 = (u32)(r1 - r0) * U;
+        if (v0 > f0 && rowlen0) {
+            const u32 row0 = (u32)__builtin_amdgcn_readfirstlane((int)((u32)min(v0 - f0, (o1 - o0) * U) / rowlen0));
+            lo += row0;
+            if (row0)
+                rlo = r1;
+        }
+        const u64 lL = readlane64(wl, last), rL = readlane64(wr, last), rL1 = readlane64(wr, last + 1u);
+        u64 hi = readlane64(wl, last + 1u);
+        const u32 rowlenL = (u32)(rL1 - rL) * U;
+        if (rowlenL) {
+            const u64 fL = readlane64(fl, last);
+            const u32 rows = (u32)__builtin_amdgcn_readfirstlane((int)((u32)min(v1 - fL, (u64)0xffffffffu) / rowlenL));
+            hi = min(hi, lL + rows + 1u);
+        }
+        hi = min(hi, lo + touch_terms);
+        const u64 rhi = min(rL1, rlo + touch_terms);
+        const char *Lb = reinterpret_cast<const char *>(L), *Rb = reinterpret_cast<const char *>(R);
+        for (size_t a = (size_t)lo * termB + lane * 128u, e = (size_t)hi * termB; a < e; a += kWave * 128u)
+            CSGN_COOP_TOUCH(Lb + a);
+        for (size_t a = (size_t)rlo * termB + lane * 128u, e = (size_t)rhi * termB; a < e; a += kWave * 128u)
+            CSGN_COOP_TOUCH(Rb + a);
+    };
     // the places of the next K blocks, their operand loads issued
     auto fill = [&](CoopGroup<Unit, K> &g) {
         u32 la[K], ra[K];
@@ -562,6 +612,8 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
                     const u64 wo_next = (u64)__shfl_down(wo, 1, kWave);
                     todo = __ballot(lane < kWave - 1u && p + lane < batch && wo_next > wo);
                     fresh = false;
+                    if (touch_terms)
+                        touch_window();
                     continue;
                 }
                 const u32 j = (u32)__builtin_ctzll(todo);
@@ -673,6 +725,7 @@ __global__ void __launch_bounds__(256) k_mul_ragged_coop(const Unit *__restrict_
             fill(A);
             put(A);
         } while (!done);
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");          // (the touches have landed before the wave ends)
         CSGN_COOP_LEAVE();
         return;
     }
@@ -1667,6 +1720,9 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
         const u64 range_units = range_end - range_begin;
         const bool coop = coop_ok && (coop_mode == 1 || range_units / U >= 16u * range_pairs);
+        // (slices behind k_touch_ragged where the operand share allows them: log-normal mean 16 x 16 / 32 x 32, cold, 5.1 /
+        // 5.75 TB/s against 4.9 / 5.0 in one launch whose waves touch their own operands -- which is what the batches of
+        // smaller pairs get, where slicing loses: mean 8 x 8 4.7-5.15 against 4.0-4.5 without any touch)
         const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
@@ -1690,6 +1746,8 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                 if (wgs > kMaxBlocks256)
                     return hipErrorInvalidValue;
                 const bool k2 = csgn::tune(TUNE_RAGGED_COOP_K) == 2, pipe = csgn::tune(TUNE_RAGGED_COOP_PIPE) != 0;
+                // the in-kernel operand touch (up to this many terms a side and window; knob in KiB): not behind a slice's own touch
+                const u32 touch_terms = touch ? 0u : (u32)(((u64)std::max(0, csgn::tune(TUNE_RAGGED_COOP_TOUCH)) << 10) / ((u64)dL * 8u));
 #define CSGN_COOP(UNIT, KK)                                                                         \
     if (pipe)                                                                                       \
         CSGN_COOP_(UNIT, KK, true);                                                                 \
@@ -1698,7 +1756,7 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
 #define CSGN_COOP_(UNIT, KK, PP)                                                                    \
     k_mul_ragged_coop<UNIT, KK, PP><<<(u32)wgs, 256, 0, s>>>(                                           \
         reinterpret_cast<const UNIT *>(L), offL, reinterpret_cast<const UNIT *>(R), offR,           \
-        reinterpret_cast<UNIT *>(out), offOut, (u32)batch, v_begin, v_end, U, dU, span, vw, d_gate)
+        reinterpret_cast<UNIT *>(out), offOut, (u32)batch, v_begin, v_end, U, dU, span, vw, d_gate, touch_terms)
                 if (wide) {
                     if (k2) {
                         CSGN_COOP(unit16, 2);

@@ -2348,14 +2348,17 @@ def test_ragged_cooperative_kernel_matches_the_csr_kernel(hip, oracle, knobs, n)
     ref = ref.clone()
     knobs.set("ragged_coop", 1)
     # the software-pipelined form (hand-counted waits) and the plain one, 2 and 4 blocks per group
-    for span, k, pipe in [(1, 4, 1), (3, 4, 1), (0, 4, 1), (1, 2, 1), (3, 2, 1), (0, 2, 1), (2, 4, 1), (5, 2, 1), (7, 4, 1),
-                          (1, 4, 0), (3, 2, 0), (0, 4, 0)]:
+    # ... with the in-kernel operand touch (the default, 128 KiB a side at most and window), capped at 1 KiB, and without
+    for span, k, pipe, touch in [(1, 4, 1, 128), (3, 4, 1, 128), (0, 4, 1, 128), (1, 2, 1, 128), (3, 2, 1, 1), (0, 2, 1, 128),
+                                 (2, 4, 1, 1), (5, 2, 1, 128), (7, 4, 1, 128), (1, 4, 0, 128), (3, 2, 0, 128), (0, 4, 0, 1),
+                                 (0, 4, 1, 0), (3, 4, 1, 0), (1, 2, 0, 0)]:
         knobs.set("ragged_coop_span", span)
         knobs.set("ragged_coop_k", k)
         knobs.set("ragged_coop_pipe", pipe)
+        knobs.set("ragged_coop_touch", touch)
         got, off = hip.mul_ragged(n, L, dOL, R, dOR)
         assert torch.equal(off, ref_off)
-        assert torch.equal(got, ref), (span, k, pipe)
+        assert torch.equal(got, ref), (span, k, pipe, touch)
         guard = hip.empty_words((total + 7) * dl)
         guard.fill_(0x5A5A5A5A)
         out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total + 7, out=guard)

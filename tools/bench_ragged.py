@@ -17,7 +17,7 @@ if os.environ.get('SHORT'):          # SHORT=1: the default dispatch, size class
               ('coop k4 pipe',{'CSGN_RAGGED_COOP':'1'}),('coop k2 pipe',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2'}),
               ('coop k4 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_PIPE':'0'}),('coop k2 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2','CSGN_RAGGED_COOP_PIPE':'0'}),
               ('CSR kernel (coop off)',{'CSGN_RAGGED_COOP':'0'}),
-              ('slices 512',{'CSGN_RAGGED_SLICE_MB':'512'})]
+              ('coop, no in-kernel touch',{'CSGN_RAGGED_COOP_TOUCH':'0'}),('unsliced, in-kernel touch',{'CSGN_RAGGED_TOUCH':'0'}),('touch 32 KiB',{'CSGN_RAGGED_COOP_TOUCH':'32'}),('touch 512 KiB',{'CSGN_RAGGED_COOP_TOUCH':'512'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls

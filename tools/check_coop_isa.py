@@ -10,7 +10,8 @@ must hold in the generated code, on every path from such a load:
 The compiler keeps the registers reserved (it believes the value is already there) but is free to COPY them -- live
 range splitting, a phi -- and a copy in front of the wait would read a register the load has not written yet.  This
 script compiles the file to gfx950 assembly, walks the control-flow graph from every inline-assembly load and fails if
-that happens.  The stores between the loads are taken as issued (a store is skipped only when no lane of its block is
+that happens.  It also checks that v127 -- the one destination of the kernel's operand touches (loads whose results
+nobody reads) -- appears nowhere else.  The stores between the loads are taken as issued (a store is skipped only when no lane of its block is
 live, which the kernel rules out for a group filled before the end of its stretch: see the kernel's comment).
 
 usage: check_coop_isa.py [file.s]     (without an argument: compiles csgn_mul.hip with hipcc; exit code 1 on a finding)
@@ -23,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def compile_asm():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(tempfile.mkdtemp(prefix="coop_isa_"), "mul.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-I" + ROOT + "/include",
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-inline-asm", "-I" + ROOT + "/include",
                     "-I" + ROOT + "/csgn_amd/csrc", "-S", "--cuda-device-only", "-o", out,
                     ROOT + "/csgn_amd/csrc/csgn_mul.hip"], check=True, stderr=subprocess.DEVNULL)
     return out
@@ -114,9 +115,14 @@ def check(name, lines):
         return [i + 1, tgt]
 
     findings, nloads = [], 0
+    # the operand touches (loads whose results nobody reads) all write v127, which the kernel keeps out of the register
+    # allocator's hands (amdgpu_num_vgpr): nothing else may mention it, or a touch still in flight would land in a live value
+    for t, in_asm in ins:
+        if 127 in vregs(t.split(None, 1)[1] if " " in t else "") and not (in_asm and t.startswith("global_load_dword v127,")):
+            findings.append("%s: `%s` uses v127, the destination of the operand touches" % (name[:60], t))
     for i0, (t0, asm0) in enumerate(ins):
         m = re.match(r"^global_load_dword(?:x[24])?\s+(v\[\d+:\d+\]|v\d+)", t0)
-        if not (asm0 and m):
+        if not (asm0 and m) or m.group(1) == "v127":
             continue
         nloads += 1
         dest = vregs(m.group(1))

@@ -23,7 +23,7 @@ static void launch(u32 wgs, const unit16 *L, const u64 *offL, const unit16 *R, c
                    u32 batch, u64 v_end, u32 U, u32 span)
 {
     k_mul_ragged_coop<unit16, K, PIPE><<<wgs, 256>>>(L, offL, R, offR, out, offOut, batch, 0, v_end, U, csgn_fastdiv_make(U), span,
-                                                    kWave, nullptr);
+                                                    kWave, nullptr, (getenv("PROBE_TOUCH") ? (u32)atoi(getenv("PROBE_TOUCH")) : 128u) * 1024u / (U * 16u));
 }
 
 int main(int argc, char **argv)
