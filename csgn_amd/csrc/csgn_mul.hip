@@ -1703,6 +1703,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             slice_units >>= 1;
         if (too_much(slice_units))
             slice_touch = false;
+    } else if (total_out_terms / batch < 512u) {
+        // operand size unknown (no plan at hand: csgn_mul_ragged, csgn_mul_ragged_async, whose total is the caller's bound):
+        // a batch that averages under 512 product terms a pair is taken for one of small pairs with a large operand share
+        slice_units >>= 1;
     }
     if (csgn::tune(TUNE_RAGGED_SLICE_MB) > 0) {                  // (experiments: slices of this many MiB, touched)
         slice_units = ((u64)csgn::tune(TUNE_RAGGED_SLICE_MB) << 20) / sizeof(unit16);
@@ -1720,10 +1724,12 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
         const u64 range_units = range_end - range_begin;
         const bool coop = coop_ok && (coop_mode == 1 || range_units / U >= 16u * range_pairs);
-        // (slices behind k_touch_ragged where the operand share allows them: log-normal mean 16 x 16 / 32 x 32, cold, 5.1 /
-        // 5.75 TB/s against 4.9 / 5.0 in one launch whose waves touch their own operands -- which is what the batches of
-        // smaller pairs get, where slicing loses: mean 8 x 8 4.7-5.15 against 4.0-4.5 without any touch)
-        const bool touch = wide && slice_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
+        // Slices behind k_touch_ragged where 1 GiB slices do (log-normal mean 32 x 32, cold: 5.7 TB/s sliced, 5.2-5.3 in one
+        // launch).  Where the operand share asks for 512 MiB slices, a range the wave-cooperative kernel takes goes in ONE
+        // launch whose waves touch their own operands (mean 16 x 16: 5.2 against 4.9-5.0 sliced), as do the batches of
+        // smaller pairs that are never sliced (mean 8 x 8: 4.8-5.3 against 4.0-4.5 without any touch).
+        const bool own_touch = coop && slice_units < (1ull << 26) && csgn::tune(TUNE_RAGGED_COOP_TOUCH) > 0 && csgn::tune(TUNE_RAGGED_SLICE_MB) <= 0;
+        const bool touch = wide && slice_touch && !own_touch && range_units > slice_units && csgn::tune(TUNE_RAGGED_TOUCH) != 0;
         const u64 per_launch = touch ? slice_units : kMaxBlocks256 * 256u;   // units
         hipError_t result = hipSuccess;
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {

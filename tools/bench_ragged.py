@@ -11,13 +11,13 @@ VARIANTS=[('same operands',{'NSETS':'1'}),('cold',{}),('cold, no touch',{'CSGN_R
           ('cold C=1',{'CSGN_RAGGED_C':'1'}),('cold C=2',{'CSGN_RAGGED_C':'2'}),('cold C=4',{'CSGN_RAGGED_C':'4'}),('cold C=4 M=2',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'2'}),('cold C=4 M=1',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_M':'1'}),
           ('cold C=4 no touch',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_TOUCH':'0'}),('cold C=4 no pf',{'CSGN_RAGGED_C':'4','CSGN_RAGGED_PF':'0'}),('cold C=8',{'CSGN_RAGGED_C':'8'}),('cold C=16',{'CSGN_RAGGED_C':'16'}),('cold C=8 M=2',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_M':'2'}),('cold C=8 no pf',{'CSGN_RAGGED_C':'8','CSGN_RAGGED_PF':'0'}),('same C=4',{'NSETS':'1','CSGN_RAGGED_C':'4'}),
           ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'})]
-if os.environ.get('SHORT'):          # SHORT=1: the default dispatch, size classes off, CSR kernel alone
+if os.environ.get('SHORT'):          # SHORT=1: the default dispatch and the wave-cooperative kernel's choices
     VARIANTS=[('cold',{}),('same operands',{'NSETS':'1'}),
-              ('CSR kernel forced: cold',{'CSGN_RAGGED_FLAT':'1'}),
-              ('coop k4 pipe',{'CSGN_RAGGED_COOP':'1'}),('coop k2 pipe',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2'}),
-              ('coop k4 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_PIPE':'0'}),('coop k2 plain',{'CSGN_RAGGED_COOP':'1','CSGN_RAGGED_COOP_K':'2','CSGN_RAGGED_COOP_PIPE':'0'}),
               ('CSR kernel (coop off)',{'CSGN_RAGGED_COOP':'0'}),
-              ('coop, no in-kernel touch',{'CSGN_RAGGED_COOP_TOUCH':'0'}),('unsliced, in-kernel touch',{'CSGN_RAGGED_TOUCH':'0'}),('touch 32 KiB',{'CSGN_RAGGED_COOP_TOUCH':'32'}),('touch 512 KiB',{'CSGN_RAGGED_COOP_TOUCH':'512'})]
+              ('one launch, in-kernel touch',{'CSGN_RAGGED_TOUCH':'0'}),
+              ('one launch, no touch',{'CSGN_RAGGED_TOUCH':'0','CSGN_RAGGED_COOP_TOUCH':'0'}),
+              ('slices behind k_touch_ragged',{'CSGN_RAGGED_COOP_TOUCH':'0'}),
+              ('coop forced',{'CSGN_RAGGED_COOP':'1'}),('coop k2',{'CSGN_RAGGED_COOP_K':'2'}),('coop plain',{'CSGN_RAGGED_COOP_PIPE':'0'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
