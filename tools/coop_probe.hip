@@ -22,7 +22,8 @@ template <int K, bool PIPE>
 static void launch(u32 wgs, const unit16 *L, const u64 *offL, const unit16 *R, const u64 *offR, unit16 *out, const u64 *offOut,
                    u32 batch, u64 v_end, u32 U, u32 span)
 {
-    k_mul_ragged_coop<unit16, K, PIPE><<<wgs, 256>>>(L, offL, R, offR, out, offOut, batch, 0, v_end, U, csgn_fastdiv_make(U), span,
+    // PROBE_LDS: bytes of (unused) dynamic LDS per workgroup, to hold fewer workgroups on a CU: 81920 -> 2 (8 waves), 54000 -> 3
+    k_mul_ragged_coop<unit16, K, PIPE><<<wgs, 256, getenv("PROBE_LDS") ? (size_t)atoi(getenv("PROBE_LDS")) : 0>>>(L, offL, R, offR, out, offOut, batch, 0, v_end, U, csgn_fastdiv_make(U), span,
                                                     kWave, nullptr, (getenv("PROBE_TOUCH") ? (u32)atoi(getenv("PROBE_TOUCH")) : 128u) * 1024u / (U * 16u));
 }
 
