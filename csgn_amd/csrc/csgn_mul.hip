@@ -1718,12 +1718,18 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     const u64 pair_bound = d_gate ? total_out_terms : max_t1 * max_t2;
     // It is for SMALL pairs, not tiny ones: a single-term pair costs a wave a block of its own, and a stretch of
     // them leaves the wave with a sixth of its lanes at work (65 535 singles: 3.1 TB/s against the CSR kernel's 3.5, a
-    // million: 1.7 against 4.0).  Auto (-1): where the range averages 16 product terms a pair and more.
+    // million: 1.7 against 4.0).  Auto (-1): where the range averages 16 product terms a pair and more (below).
     const int coop_mode = csgn::tune(TUNE_RAGGED_COOP);
     const bool coop_ok = coop_mode != 0 && pair_bound * U < (1ull << 28) && skip_t1 == 0;
     auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
         const u64 range_units = range_end - range_begin;
-        const bool coop = coop_ok && (coop_mode == 1 || range_units / U >= 16u * range_pairs);
+        // (the average is taken WITHOUT the largest product the shapes allow: one 1024 x 1024 pair among 65 535 singles
+        // averages 17 terms a pair and is no batch of small pairs; where the shapes are unknown -- the async call -- the
+        // bar is 32: that batch runs at 2.0 TB/s here and 2.8-3.5 in the CSR kernel)
+        const u64 range_terms = range_units / U;
+        const bool small_pairs = d_gate ? range_terms >= 32u * range_pairs
+                                        : range_terms - std::min(range_terms, max_t1 * max_t2) >= 16u * range_pairs;
+        const bool coop = coop_ok && (coop_mode == 1 || small_pairs);
         // Slices behind k_touch_ragged where 1 GiB slices do (log-normal mean 32 x 32, cold: 5.7 TB/s sliced, 5.2-5.3 in one
         // launch).  Where the operand share asks for 512 MiB slices, a range the wave-cooperative kernel takes goes in ONE
         // launch whose waves touch their own operands (mean 16 x 16: 5.2 against 4.9-5.0 sliced), as do the batches of
