@@ -117,10 +117,19 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
                 src[m] = from_l[m] ? (l0 + q) * U + k : (rr0 + (q - t1)) * U + k;
             }
         }
+        // ONE unconditional load per unit from a selected base: `from_l ? L[i] : R[i]` compiles to a branch around each
+        // of two loads with a full vmcnt(0) wait per element -- the M loads of a lane one after the other
         Unit v[M];
 #pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const Unit *base = from_l[m] ? L : R;
+            v[m] = base[src[m]];
+        }
+        // (all M loads are issued HERE: left to itself the compiler sinks a load into the `if (live)` of its store,
+        // behind the other stores, with a vmcnt(0) of its own)
+#pragma unroll
         for (int m = 0; m < M; ++m)
-            v[m] = from_l[m] ? L[src[m]] : R[src[m]];
+            asm volatile("" : "+v"(v[m]));
 #pragma unroll
         for (int m = 0; m < M; ++m)
             if (live[m])

@@ -360,6 +360,11 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
             lv[m] = L[la[m]];
             rv[m] = R[ra[m]];
         }
+        // (... and issued HERE, all 2M of them: left to itself the compiler sinks the loads of one unit into the `if (live)`
+        // of its store, behind the other stores, with a vmcnt(0) of their own)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            asm volatile("" : "+v"(lv[m]), "+v"(rv[m]));
 #pragma unroll
         for (int m = 0; m < M; ++m)
             if (live[m])

@@ -17,7 +17,7 @@ if os.environ.get('SHORT'):          # SHORT=1: the default dispatch and the wav
               ('one launch, in-kernel touch',{'CSGN_RAGGED_TOUCH':'0'}),
               ('one launch, no touch',{'CSGN_RAGGED_TOUCH':'0','CSGN_RAGGED_COOP_TOUCH':'0'}),
               ('slices behind k_touch_ragged',{'CSGN_RAGGED_COOP_TOUCH':'0'}),
-              ('coop forced',{'CSGN_RAGGED_COOP':'1'}),('coop k2',{'CSGN_RAGGED_COOP_K':'2'}),('coop pipelined',{'CSGN_RAGGED_COOP_PIPE':'1'}),('coop pipelined k2',{'CSGN_RAGGED_COOP_PIPE':'1','CSGN_RAGGED_COOP_K':'2'})]
+              ('coop forced',{'CSGN_RAGGED_COOP':'1'}),('coop k2',{'CSGN_RAGGED_COOP_K':'2'}),('coop pipelined',{'CSGN_RAGGED_COOP_PIPE':'1'}),('span 32',{'CSGN_RAGGED_COOP_SPAN':'32'}),('span 128',{'CSGN_RAGGED_COOP_SPAN':'128'}),('touch 32 KiB',{'CSGN_RAGGED_COOP_TOUCH':'32'})]
 hip = HipPath(0)
 def timed(fn, rounds=7):
     """Steady-state time per call (as tools/bench_ops.py): >= 30 ms of back-to-back warm-up, then runs of K calls
