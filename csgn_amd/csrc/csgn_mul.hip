@@ -163,8 +163,9 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
     for (int m = 0; m < M; ++m) {
         const u32 c = c0 + (u32)m * BS + tid;
         valid[m] = c < cu;
-        if (valid[m])
-            r[m] = Rp[c];
+        // unconditional, of a clamped column (c0 < cu here): `if (valid) r = Rp[c]` compiles to a branch, a load and a
+        // vmcnt(0) per column -- the M loads of a lane one round trip after the other (tools/isa_waits.py)
+        r[m] = Rp[min(c, cu - 1u)];
         k[m] = c % U;
     }
     __syncthreads();

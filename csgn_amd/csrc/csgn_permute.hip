@@ -229,12 +229,10 @@ __global__ void __launch_bounds__(MAXT, 1024 / MAXT) k_permute_planes3(u32 n_bit
         for (int u = 0; u < UW; ++u) {
             const u32 i = wave + (u32)k * W;
             const u32 j = (i * UW + (u32)u) * 64u + 63u - lane;
-            u32 p = none;
-            if (i < NI && j < n_bits) {
-                p = perm[j];
-                if (p >= n_bits)
-                    p = none;
-            }
+            // an unconditional load of a clamped entry: `if (in range) p = perm[j]` compiles to a branch, a load and a full
+            // wait per entry -- MAXI * UW dependent round trips (10 us and more) in front of every workgroup's first group
+            const u32 pv = perm[min(j, n_bits - 1u)];
+            const u32 p = (i < NI && j < n_bits && pv < n_bits) ? pv : none;
             const int e = k * UW + u;
             srcpk[e / 2] |= p << (16 * (e & 1));
         }
