@@ -1757,7 +1757,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
                 const bool whole_output = u0 == 0 && nu == total_units;
                 const u32 vw = whole_output ? kWave : 0u;
                 const u64 v_begin = u0, v_end = u0 + nu + (u64)vw * batch;
-                u32 span = whole_output ? (u32)std::min<u64>(4096, std::max<u64>(512, ((v_end - v_begin) / 16384u) & ~63ull)) : 1024u;
+                // (at most 64 blocks a wave; 32 where the range averages under 128 product terms a pair -- log-normal mean 8 x 8:
+                // +4 % on two boxes, mean 16 x 16 +-0, mean 32 x 32 -4 % with 32)
+                const u64 span_cap = range_terms < 128u * range_pairs ? 2048u : 4096u;
+                u32 span = whole_output ? (u32)std::min<u64>(span_cap, std::max<u64>(512, ((v_end - v_begin) / 16384u) & ~63ull)) : 1024u;
                 if (csgn::tune(TUNE_RAGGED_COOP_SPAN) > 0)
                     span = kWave * (u32)csgn::tune(TUNE_RAGGED_COOP_SPAN);
                 const u64 wgs = (v_end - v_begin + 4ull * span - 1) / (4ull * span);
