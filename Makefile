@@ -53,6 +53,10 @@ tools/bin/sprefetch_bench: tools/sprefetch_bench.hip
 	mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -o $@ $<
 
+tools/bin/wpattern_bench: tools/wpattern_bench.hip
+	mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -o $@ $<
+
 tools/bin/bench_mul: tools/bench_mul.cpp $(LIBDIR)/libcsgn_hip.so
 	mkdir -p tools/bin
 	$(CXX) -std=c++11 -O2 -Iinclude -o $@ $< -L$(LIBDIR) -lcsgn_hip '-Wl,-rpath,$(abspath $(LIBDIR))'
