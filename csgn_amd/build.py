@@ -23,9 +23,10 @@ CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
 SHARD_LIB = os.path.join(LIBDIR, "libcsgn_shard.so")
 CERTFHE_SHARD_LIB = os.path.join(LIBDIR, "libcertFHE_shard.so")
 
-HIP_SOURCES = ["csgn_capi.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
+HIP_SOURCES = ["csgn_capi.hip", "csgn_circuit.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
                "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip", "csgn_bitlen.hip", "csgn_tuning.cpp"]
-HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h", "csgn_tuning.h"]
+HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h", "csgn_tuning.h", "csgn_capi_util.h"]
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def _hipcc() -> str:
@@ -42,13 +43,47 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def check_coop_isa(asm_path=None) -> None:
+    """The wave-cooperative ragged multiply keeps loads outside the compiler's books (inline-assembly loads into a
+    reserved v127, hand-counted s_waitcnt): tools/check_coop_isa.py reads the generated code and fails on any
+    instruction that touches a loaded register before its wait.  Run wherever the library is compiled:
+    a toolchain that breaks the invariant must break the build, not the products."""
+    tool = os.path.join(ROOT, "tools", "check_coop_isa.py")
+    subprocess.check_call([sys.executable, tool] + ([asm_path] if asm_path else []))
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "csgn_hip.h")]
-    if force or _stale(HIP_LIB, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-Wno-inline-asm",
-               "-I" + INCLUDE, "-I" + CSRC, "-o", HIP_LIB] + srcs
+    """One object per translation unit (compiled in parallel, rebuilt only when it or a header changed), then the
+    link; csgn_mul.hip is also compiled to assembly for the ISA check of the wave-cooperative kernel."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "csgn_hip.h")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",
+             "-I" + INCLUDE, "-I" + CSRC]
+    jobs, objs = [], []
+    for name in HIP_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, os.path.splitext(name)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [_hipcc()] + flags + (["-x", "hip"] if name.endswith(".cpp") else []) + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    mul_asm = os.path.join(OBJDIR, "csgn_mul.s")
+    mul_src = os.path.join(CSRC, "csgn_mul.hip")
+    checked = os.path.join(OBJDIR, "coop_isa.ok")
+    asm_job = None
+    if force or _stale(mul_asm, [mul_src] + hdrs):
+        cmd = [_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", mul_asm, mul_src]
+        asm_job = (cmd, subprocess.Popen(cmd, stderr=subprocess.DEVNULL))
+    for cmd, proc in jobs + ([asm_job] if asm_job else []):
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    if force or _stale(checked, [mul_asm, os.path.join(ROOT, "tools", "check_coop_isa.py")]):
+        check_coop_isa(mul_asm)
+        open(checked, "w").write("ok\n")
+    if force or _stale(HIP_LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -98,6 +98,11 @@ SIGNATURES = {
     "csgn_circuit_encrypt_mul": (C.c_int, [vp, u64, vp, vp, vp, vp, vp, vp, u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "csgn_circuit_epoch": (u64, [vp]),
     "csgn_circuit_node_key": (C.c_int, [vp, vp]),
+    "csgn_circuit_optimize": (C.c_int, [vp, C.c_uint32]),
+    "csgn_circuit_output": (C.c_int, [vp, C.c_uint32]),
+    "csgn_circuit_block_bytes": (u64, [vp]),
+    "csgn_circuit_stats": (C.c_int, [vp, vp]),
+    "csgn_circuit_plan_json": (C.c_int, [vp, vp, C.c_size_t]),
     "csgn_circuit_build": (C.c_int, [vp]),
     "csgn_circuit_value": (vp, [vp, C.c_uint32]),
     "csgn_circuit_value_terms": (u64, [vp, C.c_uint32]),

@@ -502,6 +502,15 @@ unsigned BatchCircuit::decrypt(unsigned a, const SecretKey &key)
     return id;
 }
 
+void BatchCircuit::optimize(unsigned passes)
+{
+    detail::check(csgn_circuit_optimize(handle, passes), "csgn_circuit_optimize");
+}
+
+void BatchCircuit::keep(unsigned value) { detail::check(csgn_circuit_output(handle, value), "csgn_circuit_output"); }
+
+uint64_t BatchCircuit::blockBytes() const { return csgn_circuit_block_bytes(handle); }
+
 void BatchCircuit::build() { detail::check(csgn_circuit_build(handle), "csgn_circuit_build"); }
 
 void BatchCircuit::set(unsigned input, const CiphertextBatch &batch)
@@ -522,10 +531,10 @@ CiphertextBatch BatchCircuit::value(unsigned id) const
     const uint64_t terms = csgn_circuit_value_terms(handle, id);
     const uint64_t *src = csgn_circuit_value(handle, id);
     if (!src)
-        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value or circuit not built");
+        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value, circuit not built, or a value a compiled circuit did not keep()");
     const uint64_t *d_off = csgn_circuit_value_offsets(handle, id);
     if (terms == 0 && !d_off)
-        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value or circuit not built");
+        throw std::invalid_argument("certFHE::BatchCircuit::value: no such value, circuit not built, or a value a compiled circuit did not keep()");
     if (d_off) {                                    // ragged (static shapes, or data-dependent ones behind compact())
         CiphertextBatch out(ctx, count_, 0);
         out.offsets_.resize(count_ + 1);

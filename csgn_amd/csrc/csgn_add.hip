@@ -148,11 +148,14 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
 // ---------------------------------------------------------------------------------------
 // add = concatenation (src/Ciphertext.cpp:107-122).  Flat map over output units.
 // ---------------------------------------------------------------------------------------
-template <typename Unit, bool NT>
+// PITCH (circuit placement, csgn_circuit.hip): element p's LU + RU units go to out + p * opitch -- a slice of a larger
+// sum; with LU or RU zero this is the strided copy of ONE operand into its slice (the other was written there by its
+// producer).
+template <typename Unit, bool NT, bool PITCH = false>
 __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
                                                   Unit *__restrict__ out, u32 total_units, u32 LU,
-                                                  u32 RU, FastDiv dOU, u32 xcd)
+                                                  u32 RU, FastDiv dOU, u32 xcd, u32 opitch = 0)
 {
     // one unit per lane, < 2^32 units per launch (see k_and_stream for why)
     const u32 OU = LU + RU;
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
         const u32 pair = csgn_fastdiv(g, dOU);
         const u32 r = g - pair * OU;
         const Unit v = (r < LU) ? L[(u64)pair * LU + r] : R[(u64)pair * RU + (r - LU)];
-        unit_store<Unit, NT>(out + g, v);
+        unit_store<Unit, NT>(out + (PITCH ? (u64)pair * opitch + r : (u64)g), v);
     }
 }
 
@@ -179,13 +182,16 @@ __global__ void __launch_bounds__(256) k_off_sum(u64 n, const u64 *__restrict__ 
 // ------------------------------------------------------------------------------ public
 
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
-                       hipStream_t s)
+                       hipStream_t s, u64 out_pitch_words)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || t1 + t2 == 0)
         return hipSuccess;
-    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    if (out_pitch_words && (out_pitch_words < (t1 + t2) * dL || out_pitch_words >= (1ull << 32)))
+        return hipErrorInvalidValue;
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out) && out_pitch_words % 2 == 0;
     const u32 U = (u32)(wide ? dL / 2 : dL);
+    const u32 opitch = (u32)(wide ? out_pitch_words / 2 : out_pitch_words);
     const u64 OU = (t1 + t2) * U;
     const u64 pairs_per = (0xFFFFFF00ull / OU) ? (0xFFFFFF00ull / OU) : 1;       // units (= threads) per launch < 2^32
     const FastDiv d = csgn_fastdiv_make((u32)OU);
@@ -194,7 +200,16 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
         const u64 np = (batch - p0 < pairs_per) ? batch - p0 : pairs_per;
         const u32 tot = (u32)(np * OU);
         const u32 blocks = ceil_div_u64(tot, 256u);
-        if (wide)
+        if (opitch && wide)
+            k_add_flat<unit16, true, true><<<blocks, 256, 0, s>>>(
+                reinterpret_cast<const unit16 *>(L) + p0 * t1 * U,
+                reinterpret_cast<const unit16 *>(R) + p0 * t2 * U,
+                reinterpret_cast<unit16 *>(out) + p0 * opitch, tot, (u32)(t1 * U), (u32)(t2 * U), d, sxcd, opitch);
+        else if (opitch)
+            k_add_flat<unit8, true, true><<<blocks, 256, 0, s>>>(L + p0 * t1 * U, R + p0 * t2 * U,
+                                                                 out + p0 * opitch, tot, (u32)(t1 * U),
+                                                                 (u32)(t2 * U), d, sxcd, opitch);
+        else if (wide)
             k_add_flat<unit16, true><<<blocks, 256, 0, s>>>(
                 reinterpret_cast<const unit16 *>(L) + p0 * t1 * U,
                 reinterpret_cast<const unit16 *>(R) + p0 * t2 * U,

@@ -1,8 +1,7 @@
 // csgn_capi.hip -- the extern "C" surface of libcsgn_hip.so (declared in include/csgn_hip.h).
 // Argument validation, error reporting and stream plumbing only; the kernels live in
 // csgn_{mul,add,decrypt,encrypt,permute,compact,harness}.hip.  There is deliberately no CPU fallback anywhere in this library.
-#include "csgn_hip.h"
-#include "csgn_kernels.h"
+#include "csgn_capi_util.h"
 #include "csgn_tuning.h"
 
 #include <sys/random.h>
@@ -13,7 +12,8 @@
 #include <cstdio>
 #include <cstring>
 
-namespace {
+namespace csgn {
+namespace capi {
 
 thread_local char g_err[512] = "";
 
@@ -33,21 +33,6 @@ int hip_fail(hipError_t e, const char *what)
                     what, hipGetErrorString(e));
     return fail(CSGN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
-
-#define HIP_TRY(expr)                          \
-    do {                                       \
-        hipError_t e_ = (expr);                \
-        if (e_ != hipSuccess)                  \
-            return hip_fail(e_, #expr);        \
-    } while (0)
-
-#define REQUIRE(cond, ...)                               \
-    do {                                                 \
-        if (!(cond))                                     \
-            return fail(CSGN_ERR_INVALID, __VA_ARGS__);  \
-    } while (0)
-
-inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 // a*b*c < limit, evaluated without wrapping (operands may be anything up to 2^64-1)
 bool product_below(uint64_t a, uint64_t b, uint64_t c, uint64_t limit)
@@ -112,7 +97,10 @@ int check_n(uint64_t n_bits)
     return CSGN_OK;
 }
 
-} // namespace
+} // namespace capi
+} // namespace csgn
+
+using namespace csgn::capi;
 
 extern "C" {
 
@@ -932,566 +920,6 @@ int csgn_digest(const uint64_t *d_words, uint64_t n_words, uint64_t first_index,
 const char *csgn_mul_uniform_kernel(uint64_t n_bits, uint64_t pairs, uint64_t t1, uint64_t t2)
 {
     return csgn::mul_uniform_kernel_name(n_bits, pairs, t1, t2);
-}
-
-/* ---------------------------------------------------------------- circuits ---- */
-/* A fixed add/multiply/decrypt circuit over uniform batches, all values in one HBM block, the
- * launches captured once into a hipGraph: a launch-bound circuit (BASELINE config 5: 24
- * operations of a few microseconds each) is replayed with one hipGraphLaunch. */
-struct csgn_circuit {
-    struct Value {
-        uint64_t terms;       // uniform: terms per element; ragged: 0
-        size_t offset;        // bytes into block
-        // ragged values (static shapes: the per-element term counts are fixed when the circuit is
-        // described, so every size downstream is known on the host and the graph needs no plan step)
-        std::vector<uint64_t> per;   // batch entries, empty for a uniform value
-        size_t csr_offset;           // bytes into block of the batch+1 CSR term offsets (0 = none yet)
-        uint64_t total;              // terms over the whole batch
-        uint64_t max_terms;
-        // a value behind a compaction: `per`, `total`, `max_terms` are static UPPER BOUNDS (they size the
-        // buffers and the launches), the real CSR offsets are written by the device in every run
-        bool dynamic = false;
-    };
-    struct Op {
-        int kind;             // 0 add, 1 mul, 2 decrypt, 3 permute, 4 encrypt (keyed generator), 5 fused Enc*Enc (+Dec), 6 compact
-        uint32_t a, b, out;
-        const void *mask;     // decrypt / encrypt: key mask (u64 words); permute: permutation (u32 entries)
-        size_t scratch, bits; // byte offsets (decrypt)
-        // encrypt only
-        const uint8_t *plain;
-        const uint64_t *key;
-        uint64_t d, first;
-        csgn_rng rng;
-        // fused Enc*Enc only
-        const uint8_t *plain_b;
-        csgn_rng rng_b;
-        bool want_bits;
-    };
-    uint64_t n_bits = 0, batch = 0;
-    std::vector<Value> values;
-    std::vector<Op> ops;
-    std::vector<size_t> bits_offsets;
-    size_t bytes = 0;
-    size_t epoch_offset = 0;  // u64 run counter in the block, bumped by the graph's first node
-    bool has_encrypt = false;
-    uint64_t runs = 0;
-    void *block = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-};
-
-namespace {
-size_t circuit_reserve(csgn_circuit *c, size_t n)
-{
-    const size_t at = (c->bytes + 255) & ~(size_t)255;
-    c->bytes = at + n;
-    return at;
-}
-}
-
-extern "C++" {
-namespace {
-csgn_circuit::Value make_uniform(csgn_circuit *c, uint64_t terms, size_t offset)
-{
-    csgn_circuit::Value v;
-    v.terms = terms;
-    v.offset = offset;
-    v.csr_offset = 0;
-    v.total = c->batch * terms;
-    v.max_terms = terms;
-    return v;
-}
-uint64_t terms_of(const csgn_circuit::Value &v, uint64_t i) { return v.per.empty() ? v.terms : v.per[i]; }
-// CSR offsets of a value inside the block (created on first need, also for uniform values that meet
-// a ragged one)
-size_t ensure_csr(csgn_circuit *c, uint32_t id)
-{
-    csgn_circuit::Value &v = c->values[id];
-    if (!v.csr_offset)
-        v.csr_offset = circuit_reserve(c, (size_t)(c->batch + 1) * 8);
-    return v.csr_offset;
-}
-} // namespace
-} // extern "C++"
-
-int csgn_circuit_create(uint64_t n_bits, uint64_t batch, csgn_circuit **circuit)
-{
-    REQUIRE(circuit, "circuit is null");
-    *circuit = nullptr;
-    if (int rc = check_n(n_bits))
-        return rc;
-    REQUIRE(batch > 0, "batch must be > 0");
-    csgn_circuit *c = new csgn_circuit();
-    c->n_bits = n_bits;
-    c->batch = batch;
-    *circuit = c;
-    return CSGN_OK;
-}
-
-void csgn_circuit_destroy(csgn_circuit *c)
-{
-    if (!c)
-        return;
-    if (c->exec)
-        (void)hipGraphExecDestroy(c->exec);
-    if (c->graph)
-        (void)hipGraphDestroy(c->graph);
-    if (c->block)
-        (void)hipFree(c->block);
-    for (auto &op : c->ops) {                 // the encrypt nodes' generator keys: not left in freed host memory
-        volatile uint32_t *a = op.rng.key, *b = op.rng_b.key;
-        for (int i = 0; i < 8; ++i)
-            a[i] = b[i] = 0;
-    }
-    delete c;
-}
-
-int csgn_circuit_input(csgn_circuit *c, uint64_t terms, uint32_t *value)
-{
-    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
-    REQUIRE(terms > 0, "an input needs at least one term");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    if (!product_below(c->batch, terms, dl, 1ull << 57))
-        return fail(CSGN_ERR_UNSUPPORTED, "input of %llu x %llu terms: size overflows",
-                    (unsigned long long)c->batch, (unsigned long long)terms);
-    c->values.push_back(make_uniform(c, terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))));
-    *value = (uint32_t)(c->values.size() - 1);
-    return CSGN_OK;
-}
-
-int csgn_circuit_input_ragged(csgn_circuit *c, const uint64_t *h_terms, uint32_t *value)
-{
-    REQUIRE(c && value && h_terms && !c->exec, "null argument, or the circuit is already built");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    csgn_circuit::Value v;
-    v.terms = 0;
-    v.csr_offset = 0;
-    v.total = 0;
-    v.max_terms = 0;
-    v.per.assign(h_terms, h_terms + c->batch);
-    for (uint64_t i = 0; i < c->batch; ++i) {
-        REQUIRE(h_terms[i] < (1ull << 31), "element %llu has too many terms", (unsigned long long)i);
-        v.total += h_terms[i];
-        v.max_terms = h_terms[i] > v.max_terms ? h_terms[i] : v.max_terms;
-    }
-    if (!product_below(v.total ? v.total : 1, 1, dl, 1ull << 57))
-        return fail(CSGN_ERR_UNSUPPORTED, "ragged input of %llu terms: size overflows", (unsigned long long)v.total);
-    v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
-    c->values.push_back(v);
-    const uint32_t id = (uint32_t)(c->values.size() - 1);
-    (void)ensure_csr(c, id);
-    *value = id;
-    return CSGN_OK;
-}
-
-static int circuit_binary(csgn_circuit *c, int kind, uint32_t a, uint32_t b, uint32_t *value)
-{
-    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
-    REQUIRE(a < c->values.size() && b < c->values.size(), "operand value does not exist");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    const bool ragged = !c->values[a].per.empty() || !c->values[b].per.empty();
-    if (ragged) {
-        // per-element shapes are static: every downstream size is computed here, on the host
-        csgn_circuit::Value v;
-        v.terms = 0;
-        v.csr_offset = 0;
-        v.total = 0;
-        v.max_terms = 0;
-        v.per.resize(c->batch);
-        for (uint64_t i = 0; i < c->batch; ++i) {
-            const uint64_t ta = terms_of(c->values[a], i), tb = terms_of(c->values[b], i);
-            if (kind && !product_below(ta, tb, dl, 1ull << 32))
-                return fail(CSGN_ERR_UNSUPPORTED, "element %llu: product of %llu x %llu terms exceeds 2^32 words",
-                            (unsigned long long)i, (unsigned long long)ta, (unsigned long long)tb);
-            const uint64_t t = kind ? ta * tb : ta + tb;
-            if (!kind && t * dl >= (1ull << 31))
-                return fail(CSGN_ERR_UNSUPPORTED, "element %llu: sum of %llu terms exceeds 2^31 words",
-                            (unsigned long long)i, (unsigned long long)t);
-            v.per[i] = t;
-            v.total += t;
-            v.max_terms = t > v.max_terms ? t : v.max_terms;
-        }
-        if (!product_below(v.total ? v.total : 1, 1, dl, 1ull << 57))
-            return fail(CSGN_ERR_UNSUPPORTED, "value of %llu terms: size overflows", (unsigned long long)v.total);
-        v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
-        v.dynamic = c->values[a].dynamic || c->values[b].dynamic;
-        c->values.push_back(v);
-        const uint32_t out = (uint32_t)(c->values.size() - 1);
-        (void)ensure_csr(c, a);
-        (void)ensure_csr(c, b);
-        (void)ensure_csr(c, out);
-        csgn_circuit::Op op = {};
-        op.kind = kind;
-        op.a = a;
-        op.b = b;
-        op.out = out;
-        if (kind && v.dynamic)                     // the device-side plan of csgn_mul_ragged_async
-            op.scratch = circuit_reserve(c, (size_t)csgn::mul_ragged_async_plan_words(c->batch) * 8);
-        c->ops.push_back(op);
-        *value = out;
-        return CSGN_OK;
-    }
-    const uint64_t ta = c->values[a].terms, tb = c->values[b].terms;
-    const uint64_t terms = kind ? ta * tb : ta + tb;
-    if (kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || !product_below(ta, tb, dl, 1ull << 32)))
-        return fail(CSGN_ERR_UNSUPPORTED, "product of %llu x %llu terms exceeds 2^32 words",
-                    (unsigned long long)ta, (unsigned long long)tb);
-    if (!kind && (ta >= (1ull << 31) || tb >= (1ull << 31) || terms * dl >= (1ull << 31)))
-        return fail(CSGN_ERR_UNSUPPORTED, "sum of %llu terms exceeds 2^31 words", (unsigned long long)terms);
-    if (!product_below(c->batch, terms, dl, 1ull << 57))
-        return fail(CSGN_ERR_UNSUPPORTED, "value of %llu x %llu terms: size overflows",
-                    (unsigned long long)c->batch, (unsigned long long)terms);
-    c->values.push_back(make_uniform(c, terms, circuit_reserve(c, (size_t)(c->batch * terms * dl * 8))));
-    const uint32_t out = (uint32_t)(c->values.size() - 1);
-    csgn_circuit::Op op = {};
-    op.kind = kind;
-    op.a = a;
-    op.b = b;
-    op.out = out;
-    c->ops.push_back(op);
-    *value = out;
-    return CSGN_OK;
-}
-
-int csgn_circuit_add(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 0, a, b, value); }
-int csgn_circuit_mul(csgn_circuit *c, uint32_t a, uint32_t b, uint32_t *value) { return circuit_binary(c, 1, a, b, value); }
-
-int csgn_circuit_compact(csgn_circuit *c, uint32_t a, uint32_t *value)
-{
-    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
-    REQUIRE(a < c->values.size(), "operand value does not exist");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    const csgn_circuit::Value &va = c->values[a];
-    REQUIRE(va.total < (1ull << 31) && c->batch < (1ull << 31), "compaction handles fewer than 2^31 ciphertexts and terms");
-    csgn_circuit::Value v;
-    v.terms = 0;
-    v.csr_offset = 0;
-    v.total = va.total;                              // bounds: nothing may cancel
-    v.max_terms = va.max_terms;
-    v.per.resize(c->batch);
-    for (uint64_t i = 0; i < c->batch; ++i)
-        v.per[i] = terms_of(va, i);
-    v.dynamic = true;
-    v.offset = circuit_reserve(c, (size_t)((v.total ? v.total : 1) * dl * 8));
-    c->values.push_back(v);
-    const uint32_t out = (uint32_t)(c->values.size() - 1);
-    (void)ensure_csr(c, a);
-    (void)ensure_csr(c, out);
-    csgn_circuit::Op op = {};
-    op.kind = 6;
-    op.a = a;
-    op.b = a;
-    op.out = out;
-    op.scratch = circuit_reserve(c, csgn::compact_scratch_bytes(c->n_bits, c->batch, v.total));
-    c->ops.push_back(op);
-    *value = out;
-    return CSGN_OK;
-}
-
-int csgn_circuit_decrypt(csgn_circuit *c, uint32_t a, const uint64_t *d_mask, uint32_t *bits_id)
-{
-    REQUIRE(c && bits_id && d_mask && !c->exec, "null argument, or the circuit is already built");
-    REQUIRE(a < c->values.size(), "operand value does not exist");
-    const size_t scratch = circuit_reserve(c, csgn::decrypt_scratch_bytes(c->batch, c->values[a].total));
-    const size_t bits = circuit_reserve(c, (size_t)c->batch);
-    csgn_circuit::Op op = {};
-    op.kind = 2;
-    op.a = a;
-    op.mask = d_mask;
-    op.scratch = scratch;
-    op.bits = bits;
-    c->ops.push_back(op);
-    c->bits_offsets.push_back(bits);
-    *bits_id = (uint32_t)(c->bits_offsets.size() - 1);
-    return CSGN_OK;
-}
-
-int csgn_circuit_permute(csgn_circuit *c, uint32_t a, const uint32_t *d_perm, uint32_t *value)
-{
-    REQUIRE(c && value && d_perm && !c->exec, "null argument, or the circuit is already built");
-    REQUIRE(a < c->values.size(), "operand value does not exist");
-    // reference semantics (src/Ciphertext.cpp:7-82): the result is ONE term, the permuted first term
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    if (!c->values[a].per.empty())
-        return fail(CSGN_ERR_UNSUPPORTED, "permutation of a ragged circuit value is not supported");
-    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
-    const uint32_t out = (uint32_t)(c->values.size() - 1);
-    csgn_circuit::Op op = {};
-    op.kind = 3;
-    op.a = a;
-    op.out = out;
-    op.mask = d_perm;
-    c->ops.push_back(op);
-    *value = out;
-    return CSGN_OK;
-}
-
-int csgn_circuit_encrypt(csgn_circuit *c, uint64_t d, const uint8_t *d_plain, const uint64_t *d_key,
-                         const uint64_t *d_mask, const csgn_rng *h_rng, uint64_t first_ciphertext,
-                         uint32_t *value)
-{
-    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
-    REQUIRE(d_plain && d_key && d_mask && h_rng, "null argument");
-    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
-    REQUIRE(h_rng->rounds == 8 || h_rng->rounds == 12 || h_rng->rounds == 20, "rng rounds must be 8, 12 or 20");
-    REQUIRE(first_ciphertext + c->batch >= first_ciphertext && first_ciphertext + c->batch < (1ull << 56),
-            "ciphertext index range too large");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    if (!product_below(c->batch, 1, dl, 1ull << 57))
-        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)c->batch);
-    if (!c->has_encrypt) {
-        c->has_encrypt = true;
-        c->epoch_offset = circuit_reserve(c, 8);
-    }
-    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
-    const uint32_t out = (uint32_t)(c->values.size() - 1);
-    csgn_circuit::Op op = {};
-    op.kind = 4;
-    op.out = out;
-    op.mask = d_mask;
-    op.plain = d_plain;
-    op.key = d_key;
-    op.d = d;
-    op.first = first_ciphertext;
-    // The node encrypts under its OWN key, derived here from (h_rng->key, h_rng->nonce), and uses the
-    // nonce words for nothing but the run number: run r of the node draws from (node key, nonce = r).
-    // Round 2 added r to the caller's nonce, so run 2 under nonce N was run 1 under N + 1.
-    op.rng = *h_rng;
-    node_key_from(*h_rng, op.rng.key);
-    op.rng.nonce = 0;
-    c->ops.push_back(op);
-    *value = out;
-    return CSGN_OK;
-}
-
-int csgn_circuit_encrypt_mul(csgn_circuit *c, uint64_t d, const uint8_t *d_plain_a, const uint8_t *d_plain_b,
-                             const uint64_t *d_key, const uint64_t *d_mask, const csgn_rng *h_rng_a,
-                             const csgn_rng *h_rng_b, uint64_t first_ciphertext, uint32_t *value, uint32_t *bits_id)
-{
-    REQUIRE(c && value && !c->exec, "null circuit/value, or the circuit is already built");
-    REQUIRE(d_plain_a && d_plain_b && d_key && d_mask && h_rng_a && h_rng_b, "null argument");
-    REQUIRE(d >= 1 && d < (1ull << 32), "d must be in [1, 2^32)");
-    REQUIRE(h_rng_a->rounds == 8 || h_rng_a->rounds == 12 || h_rng_a->rounds == 20, "rng rounds must be 8, 12 or 20");
-    REQUIRE(h_rng_a->rounds == h_rng_b->rounds, "both generators must use the same number of rounds");
-    REQUIRE(memcmp(h_rng_a->key, h_rng_b->key, sizeof(h_rng_a->key)) != 0 || h_rng_a->nonce != h_rng_b->nonce,
-            "the two operands must draw from different streams (same key AND nonce given)");
-    REQUIRE(first_ciphertext + c->batch >= first_ciphertext && first_ciphertext + c->batch < (1ull << 56),
-            "ciphertext index range too large");
-    const uint64_t dl = csgn_default_len(c->n_bits);
-    if (!product_below(c->batch, 1, dl, 1ull << 57))
-        return fail(CSGN_ERR_UNSUPPORTED, "batch of %llu ciphertexts: size overflows", (unsigned long long)c->batch);
-    if (!c->has_encrypt) {
-        c->has_encrypt = true;
-        c->epoch_offset = circuit_reserve(c, 8);
-    }
-    c->values.push_back(make_uniform(c, 1, circuit_reserve(c, (size_t)(c->batch * dl * 8))));
-    const uint32_t out = (uint32_t)(c->values.size() - 1);
-    csgn_circuit::Op op = {};
-    op.kind = 5;
-    op.out = out;
-    op.mask = d_mask;
-    op.plain = d_plain_a;
-    op.plain_b = d_plain_b;
-    op.key = d_key;
-    op.d = d;
-    op.first = first_ciphertext;
-    // as csgn_circuit_encrypt: each operand under its own derived node key, nonce = run number
-    op.rng = *h_rng_a;
-    node_key_from(*h_rng_a, op.rng.key);
-    op.rng.nonce = 0;
-    op.rng_b = *h_rng_b;
-    node_key_from(*h_rng_b, op.rng_b.key);
-    op.rng_b.nonce = 0;
-    op.want_bits = bits_id != nullptr;
-    if (bits_id) {
-        op.bits = circuit_reserve(c, (size_t)c->batch);
-        c->bits_offsets.push_back(op.bits);
-        *bits_id = (uint32_t)(c->bits_offsets.size() - 1);
-    }
-    c->ops.push_back(op);
-    *value = out;
-    return CSGN_OK;
-}
-
-uint64_t csgn_circuit_epoch(const csgn_circuit *c) { return c ? c->runs : 0; }
-
-int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8])
-{
-    REQUIRE(h_rng && h_node_key, "null argument");
-    node_key_from(*h_rng, h_node_key);
-    return CSGN_OK;
-}
-
-int csgn_circuit_build(csgn_circuit *c)
-{
-    REQUIRE(c && !c->exec, "null circuit, or already built");
-    REQUIRE(!c->ops.empty(), "the circuit has no operations");
-    if (c->graph) {                     // an earlier build attempt failed at instantiation
-        (void)hipGraphDestroy(c->graph);
-        c->graph = nullptr;
-    }
-    if (c->block) {                     // ... or after the allocation
-        (void)hipFree(c->block);
-        c->block = nullptr;
-    }
-    HIP_TRY(hipMalloc(&c->block, c->bytes ? c->bytes : 256));
-    hipStream_t s = nullptr;
-    {
-        const hipError_t es = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        if (es != hipSuccess) {
-            (void)hipFree(c->block);
-            c->block = nullptr;
-            return hip_fail(es, "hipStreamCreateWithFlags");
-        }
-    }
-    unsigned char *base = static_cast<unsigned char *>(c->block);
-    uint64_t *epoch = reinterpret_cast<uint64_t *>(base + c->epoch_offset);
-    if (c->has_encrypt) {
-        const hipError_t ez = hipMemset(epoch, 0, 8);
-        if (ez != hipSuccess) {
-            (void)hipStreamDestroy(s);
-            return hip_fail(ez, "hipMemset (circuit epoch)");
-        }
-        c->runs = 0;
-    }
-    // CSR offsets of the ragged values (and of uniform values that meet one): known on the host
-    for (size_t i = 0; i < c->values.size(); ++i) {
-        const csgn_circuit::Value &v = c->values[i];
-        if (!v.csr_offset || v.dynamic)                // a dynamic value's offsets are written by the device
-            continue;
-        std::vector<uint64_t> off(c->batch + 1, 0);
-        for (uint64_t k = 0; k < c->batch; ++k)
-            off[k + 1] = off[k] + terms_of(v, k);
-        const hipError_t eu = hipMemcpy(base + v.csr_offset, off.data(), off.size() * 8, hipMemcpyHostToDevice);
-        if (eu != hipSuccess) {
-            (void)hipStreamDestroy(s);
-            return hip_fail(eu, "hipMemcpy (circuit CSR offsets)");
-        }
-    }
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess && c->has_encrypt)
-        e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under (node key, nonce = its own run number)
-    for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
-        const csgn_circuit::Op &op = c->ops[i];
-        if (op.kind == 4) {
-            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
-            e = csgn::encrypt_keyed(c->n_bits, op.d, c->batch, op.first, op.plain, (const u64 *)op.key,
-                                    (const u64 *)op.mask, op.rng.key, op.rng.nonce, op.rng.rounds,
-                                    (const u64 *)epoch, (u64 *)O, s);
-            continue;
-        }
-        if (op.kind == 5) {
-            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
-            e = csgn::encrypt_mul_keyed(c->n_bits, op.d, c->batch, op.first, op.plain, op.plain_b, (const u64 *)op.key,
-                                        (const u64 *)op.mask, op.rng.key, op.rng.nonce, op.rng_b.key, op.rng_b.nonce,
-                                        op.rng.rounds, (const u64 *)epoch, (u64 *)O,
-                                        op.want_bits ? base + op.bits : nullptr, s);
-            continue;
-        }
-        const uint64_t *A = reinterpret_cast<const uint64_t *>(base + c->values[op.a].offset);
-        if (op.kind == 6) {
-            const csgn_circuit::Value &va = c->values[op.a], &vo = c->values[op.out];
-            e = va.total ? csgn::compact(c->n_bits, c->batch, va.total, va.max_terms, (const u64 *)A,
-                                         reinterpret_cast<const u64 *>(base + va.csr_offset),
-                                         reinterpret_cast<u64 *>(base + vo.offset),
-                                         reinterpret_cast<u64 *>(base + vo.csr_offset), base + op.scratch, s)
-                         : csgn::circuit_zero_words(reinterpret_cast<u64 *>(base + vo.csr_offset), c->batch + 1, s);
-            continue;
-        }
-        if (op.kind == 2) {
-            const csgn_circuit::Value &va = c->values[op.a];
-            if (!va.per.empty())
-                e = csgn::decrypt(c->n_bits, c->batch, 0, va.total, (const u64 *)A,
-                                  reinterpret_cast<const u64 *>(base + va.csr_offset), (const u64 *)op.mask,
-                                  base + op.bits, base + op.scratch, s);
-            else
-                e = csgn::decrypt(c->n_bits, c->batch, va.terms, c->batch * va.terms, (const u64 *)A, nullptr,
-                                  (const u64 *)op.mask, base + op.bits, base + op.scratch, s);
-        } else if (!c->values[op.out].per.empty()) {
-            // ragged add / multiply: the CSR forms, offsets already in the block
-            const csgn_circuit::Value &va = c->values[op.a], &vb = c->values[op.b], &vo = c->values[op.out];
-            const u64 *B = reinterpret_cast<const u64 *>(base + vb.offset);
-            u64 *O = reinterpret_cast<u64 *>(base + vo.offset);
-            const u64 *oa = reinterpret_cast<const u64 *>(base + va.csr_offset);
-            const u64 *ob = reinterpret_cast<const u64 *>(base + vb.csr_offset);
-            u64 *oo = reinterpret_cast<u64 *>(base + vo.csr_offset);
-            if (op.kind && vo.dynamic)
-                // sizes known to the device only: plan kernels + CSR multiply back to back, the static bound sizes the launch
-                e = csgn::mul_ragged_async(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total,
-                                           reinterpret_cast<u64 *>(base + op.scratch), s);
-            else if (op.kind)
-                e = vo.total ? csgn::mul_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, va.max_terms,
-                                                vb.max_terms, vo.total, s, nullptr, va.total + vb.total)
-                             : hipSuccess;
-            else
-                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s, vo.dynamic);
-        } else if (op.kind == 3) {
-            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
-            e = csgn::permute(c->n_bits, c->batch, c->values[op.a].terms, false, (const u64 *)A,
-                              (const u32 *)op.mask, (u64 *)O, s);
-        } else {
-            const uint64_t *B = reinterpret_cast<const uint64_t *>(base + c->values[op.b].offset);
-            uint64_t *O = reinterpret_cast<uint64_t *>(base + c->values[op.out].offset);
-            const uint64_t ta = c->values[op.a].terms, tb = c->values[op.b].terms;
-            e = op.kind ? csgn::mul_uniform(c->n_bits, c->batch, ta, tb, (const u64 *)A, (const u64 *)B, (u64 *)O, 0, s)
-                        : csgn::add_uniform(c->n_bits, c->batch, ta, tb, (const u64 *)A, (const u64 *)B, (u64 *)O, s);
-        }
-    }
-    hipGraph_t g = nullptr;
-    const hipError_t e2 = hipStreamEndCapture(s, &g);
-    (void)hipStreamDestroy(s);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        if (g)
-            (void)hipGraphDestroy(g);
-        return hip_fail(e != hipSuccess ? e : e2, "csgn_circuit_build (stream capture)");
-    }
-    const hipError_t e3 = hipGraphInstantiate(&c->exec, g, nullptr, nullptr, 0);
-    if (e3 != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        c->exec = nullptr;
-        return hip_fail(e3, "hipGraphInstantiate");
-    }
-    c->graph = g;
-    return CSGN_OK;
-}
-
-uint64_t *csgn_circuit_value(csgn_circuit *c, uint32_t value)
-{
-    if (!c || !c->block || value >= c->values.size())
-        return nullptr;
-    return reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(c->block) + c->values[value].offset);
-}
-
-uint64_t csgn_circuit_value_terms(csgn_circuit *c, uint32_t value)
-{
-    return (c && value < c->values.size()) ? c->values[value].terms : 0;
-}
-
-uint64_t csgn_circuit_value_total_terms(csgn_circuit *c, uint32_t value)
-{
-    return (c && value < c->values.size()) ? c->values[value].total : 0;
-}
-
-const uint64_t *csgn_circuit_value_offsets(csgn_circuit *c, uint32_t value)
-{
-    if (!c || !c->block || value >= c->values.size() || c->values[value].per.empty())
-        return nullptr;
-    return reinterpret_cast<const uint64_t *>(static_cast<unsigned char *>(c->block) + c->values[value].csr_offset);
-}
-
-uint8_t *csgn_circuit_bits(csgn_circuit *c, uint32_t bits_id)
-{
-    if (!c || !c->block || bits_id >= c->bits_offsets.size())
-        return nullptr;
-    return static_cast<unsigned char *>(c->block) + c->bits_offsets[bits_id];
-}
-
-int csgn_circuit_run(csgn_circuit *c, void *stream)
-{
-    REQUIRE(c && c->exec, "the circuit is not built");
-    HIP_TRY(hipGraphLaunch(c->exec, S(stream)));
-    c->runs += 1;
-    return CSGN_OK;
 }
 
 /* ------------------------------------------------------------------ tuning ---- */

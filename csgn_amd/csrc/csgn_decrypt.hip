@@ -437,6 +437,16 @@ __global__ void __launch_bounds__(256) k_combine_bits(const uint8_t *__restrict_
         out[i] = is_product ? (a[i] & b[i] & 1u) : ((a[i] ^ b[i]) & 1u);
 }
 
+hipError_t combine_bits(const uint8_t *a, const uint8_t *b, u64 n, bool is_product, uint8_t *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    if (n > kMaxBlocks256 * 256u)
+        return hipErrorInvalidValue;
+    k_combine_bits<<<ceil_div_u64(n, 256), 256, 0, s>>>(a, b, n, is_product ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 size_t decrypt_combined_scratch_bytes(u64 batch, u64 t1, u64 t2)
 {
     const size_t pad = 256;

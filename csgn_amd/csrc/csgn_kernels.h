@@ -23,8 +23,10 @@ MulTuning mul_tuning();
 // (16-byte aligned buffers assumed)
 const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2);
 
+// out_pitch_words != 0 (circuit placement): element e's product is written at out + e * out_pitch_words instead of
+// densely, e.g. into its slice of the sum that consumes it; out_slots is ignored then
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
-                       u64 out_slots, hipStream_t s);
+                       u64 out_slots, hipStream_t s, u64 out_pitch_words = 0);
 u64 mul_ragged_plan_scratch_words(u64 batch);
 u64 mul_ragged_plan_head_words();       // [plan4][huge-pair count][records][operand terms][offsets checksum]: what the host copies back
 // What a plan learned beyond its four numbers; lives in the caller's csgn_mul_plan object.
@@ -62,8 +64,10 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
 u64 mul_ragged_async_plan_words(u64 batch);
 hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R, const u64 *offR,
                             u64 *out, u64 *offOut, u64 capacity_terms, u64 *d_plan, hipStream_t s);
+// out_pitch_words != 0 (circuit placement): element e's t1 + t2 terms go to out + e * out_pitch_words; with t1 or t2
+// zero (that operand's pointer is then not read) this is the strided copy of one operand into its slice of a sum
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
-                       hipStream_t s);
+                       hipStream_t s, u64 out_pitch_words = 0);
 // device_end: total_terms_out is only an upper bound (sizes the launch); the real end is read from the offsets
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s,
@@ -103,6 +107,8 @@ hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *ou
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 
 size_t decrypt_scratch_bytes(u64 batch, u64 total_terms);
+// out[i] = a[i] & b[i] (is_product) or a[i] ^ b[i]: Dec(a*b) = Dec(a) & Dec(b), Dec(a+b) = Dec(a) ^ Dec(b)
+hipError_t combine_bits(const uint8_t *a, const uint8_t *b, u64 n, bool is_product, uint8_t *out, hipStream_t s);
 size_t decrypt_combined_scratch_bytes(u64 batch, u64 t1, u64 t2);
 hipError_t decrypt_combined(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R,
                             const u64 *mask, bool is_product, uint8_t *bits, void *scratch, hipStream_t s);

@@ -30,12 +30,14 @@ __global__ void __launch_bounds__(256) k_and_stream(const Unit *__restrict__ a,
 // (pair, left term i, right column c).  Operands are tiny and re-read through L1/L2.
 // Replaces the general path of Ciphertext::multiply (src/Ciphertext.cpp:146-163).
 // ---------------------------------------------------------------------------------------
-template <typename Unit, int MF, bool XCD>
+// PITCH (circuit placement, csgn_circuit.hip): pair p's product starts at out + p * opitch units instead of
+// p * t1*t2*U -- the producer of a sum's operand writes straight into its slice of the sum.
+template <typename Unit, int MF, bool XCD, bool PITCH = false>
 __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
                                                   const Unit *__restrict__ R,
                                                   Unit *__restrict__ out, u32 total_units, u32 t1,
                                                   u32 t2, u32 U, FastDiv dPU, FastDiv dCU, FastDiv dU,
-                                                  u32 pf_rows, u32 total_rows)
+                                                  u32 pf_rows, u32 total_rows, u32 opitch = 0)
 {
     // One launch covers < 2^32 output units, so every index below is 32-bit.  Loads are
     // unconditional on clamped indices so that all 2*MF of them are in flight together.
@@ -51,12 +53,14 @@ __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
     const u32 bid = XCD ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const u32 last = total_units - 1;
     Unit l[MF], r[MF], pf_val;
+    u64 oidx[MF];
     bool pf_on = false;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const u32 g = min(bid * (256u * MF) + (u32)m * 256u + threadIdx.x, last);
         const u32 pair = csgn_fastdiv(g, dPU);
         const u32 rr = g - pair * PU;
+        oidx[m] = PITCH ? (u64)pair * opitch + rr : 0;
         const u32 i = csgn_fastdiv(rr, dCU);
         const u32 c = rr - i * CU;
         const u32 k = c - csgn_fastdiv(c, dU) * U;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(256) k_mul_flat(const Unit *__restrict__ L,
     for (int m = 0; m < MF; ++m) {
         const u32 g = bid * (256u * MF) + (u32)m * 256u + threadIdx.x;
         if (g <= last)
-            unit_store<Unit, true>(out + g, l[m] & r[m]);
+            unit_store<Unit, true>(out + (PITCH ? oidx[m] : (u64)g), l[m] & r[m]);
     }
     if (pf_on)
         asm volatile("" ::"v"(pf_val));
@@ -106,6 +110,7 @@ struct MulArgs {
     u32 xcd_remap;
     u32 pair_base;      // ragged launches cut into chunks: first pair of this launch
     const u32 *pair_list;   // ragged, size classes: the launch's pairs by index into this list (nullptr: consecutive pairs)
+    u32 opitch;         // uniform only: units from one pair's product to the next in `out` (0 = dense, t1*t2*U)
 };
 
 template <typename Unit, int M, bool SAMEK, bool RAGGED, bool NT>
@@ -137,7 +142,7 @@ __global__ void __launch_bounds__(512) k_mul_tiled(MulArgs a)
         t2 = a.t2;
         lbase = (u64)pair * t1 * U;
         rbase = (u64)pair * t2 * U;
-        obase = (u64)pair * t1 * t2 * U;
+        obase = a.opitch ? (u64)pair * a.opitch : (u64)pair * t1 * t2 * U;
     }
     const u32 cu = t2 * U;
     const u32 i0 = row_tile * a.TI;
@@ -1107,7 +1112,7 @@ hipError_t launch_tiled(MulArgs a, u64 pairs, u32 U, hipStream_t s, u32 bs_hint 
         if (!RAGGED) {
             b.L = reinterpret_cast<const Unit *>(a.L) + p0 * a.t1 * U;
             b.R = reinterpret_cast<const Unit *>(a.R) + p0 * a.t2 * U;
-            b.out = reinterpret_cast<Unit *>(a.out) + p0 * a.t1 * a.t2 * U;
+            b.out = reinterpret_cast<Unit *>(a.out) + p0 * (a.opitch ? (u64)a.opitch : (u64)a.t1 * a.t2 * U);
         }
         const u32 blocks = (u32)(np * tiles);
         hipError_t e;
@@ -1294,7 +1299,7 @@ __global__ void __launch_bounds__(256) k_touch_ragged(const u32 *__restrict__ L,
 // One uniform chunk (pairs are contiguous in L, R and out).
 template <typename Unit>
 hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, const u64 *L, const u64 *R,
-                             u64 *out, hipStream_t s)
+                             u64 *out, hipStream_t s, u32 opitch = 0)
 {
     const Unit *Lu = reinterpret_cast<const Unit *>(L);
     const Unit *Ru = reinterpret_cast<const Unit *>(R);
@@ -1304,7 +1309,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
     if (total == 0)
         return hipSuccess;
     const MulTuning tune = mul_tuning();
-    if (t1 == 1 && t2 == 1) {
+    if (t1 == 1 && t2 == 1 && !opitch) {
         // at most 2^31-1 workgroups of 256 units per launch
         const u64 per_launch = kMaxBlocks256 * 256u;
         for (u64 u0 = 0; u0 < total; u0 += per_launch) {
@@ -1351,7 +1356,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
             const u32 trows = (u32)(np * t1);
             const u32 blocks = ceil_div_u64(tot, 256u * (u64)mf);
             const Unit *Lc = Lu + p0 * t1 * U, *Rc = Ru + p0 * t2 * U;
-            Unit *Oc = Ou + p0 * PU;
+            Unit *Oc = Ou + p0 * (opitch ? (u64)opitch : PU);
             if (plan.touch) {
                 const u32 lb = 128;       // the L2 fills whole 128-byte lines (a 256-byte stride loses the gain)
                 const u64 ll = (np * t1 * U * sizeof(Unit) + lb - 1) / lb, rl = (np * t2 * U * sizeof(Unit) + lb - 1) / lb;
@@ -1365,7 +1370,9 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
             }
 #define CSGN_FLAT(MF)                                                                                  \
     do {                                                                                               \
-        if (tune.xcd)                                                                                  \
+        if (opitch)                                                                                    \
+            k_mul_flat<Unit, MF, true, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows, opitch);  \
+        else if (tune.xcd)                                                                             \
             k_mul_flat<Unit, MF, true><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows);  \
         else                                                                                           \
             k_mul_flat<Unit, MF, false><<<blocks, 256, 0, s>>>(Lc, Rc, Oc, tot, t1, t2, U, dPU, dCU, dU, pfr, trows); \
@@ -1389,6 +1396,7 @@ hipError_t mul_uniform_chunk(u32 U, u64 pairs, u64 call_pairs, u32 t1, u32 t2, c
     a.out = out;
     a.t1 = t1;
     a.t2 = t2;
+    a.opitch = opitch;
     return launch_tiled<Unit, false>(a, pairs, U, s, plan.bs, plan.ti);
 }
 
@@ -1434,13 +1442,21 @@ const char *mul_uniform_kernel_name(u64 n_bits, u64 pairs, u64 t1, u64 t2)
 }
 
 hipError_t mul_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
-                       u64 out_slots, hipStream_t s)
+                       u64 out_slots, hipStream_t s, u64 out_pitch_words)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || t1 == 0 || t2 == 0)
         return hipSuccess;
-    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out);
+    const bool wide = (dL % 2 == 0) && aligned16(L) && aligned16(R) && aligned16(out) && out_pitch_words % 2 == 0;
     const u32 U = (u32)(wide ? dL / 2 : dL);
+    if (out_pitch_words) {
+        // placed output (csgn_circuit.hip): element e's product at out + e * out_pitch_words, no arena
+        if (out_pitch_words < t1 * t2 * dL || out_pitch_words >= (1ull << 32))
+            return hipErrorInvalidValue;
+        const u32 opitch = (u32)(wide ? out_pitch_words / 2 : out_pitch_words);
+        return wide ? mul_uniform_chunk<unit16>(U, batch, batch, (u32)t1, (u32)t2, L, R, out, s, opitch)
+                    : mul_uniform_chunk<unit8>(U, batch, batch, (u32)t1, (u32)t2, L, R, out, s, opitch);
+    }
     const u64 slots = (out_slots == 0 || out_slots > batch) ? batch : out_slots;
     for (u64 p0 = 0; p0 < batch; p0 += slots) {
         const u64 np = (batch - p0 < slots) ? batch - p0 : slots;

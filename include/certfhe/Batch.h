@@ -131,10 +131,19 @@ class BatchCircuit {
     unsigned compact(unsigned a);
     unsigned permute(unsigned a, const Permutation &p);   // applyPermutation: ONE term, the permuted first term
     unsigned decrypt(unsigned a, const SecretKey &key);   // returns the id for bits()
+    // COMPILED circuits (csgn_circuit_optimize): call before build().  By default every value described above is
+    // computed into a buffer of its own and value() answers for all of them.  optimize() lets build() arrange the
+    // work -- a product whose only reader is an add is written straight into the sum, a product or sum whose only
+    // reader is a decrypt is never computed (Dec(a*b) = Dec(a) & Dec(b), Dec(a+b) = Dec(a) ^ Dec(b)), buffers are
+    // reused once their last reader has run -- and afterwards value() answers only for inputs and for values named by
+    // keep().  Bits and kept values are the same words either way.  passes: CSGN_CIRCUIT_* of csgn_hip.h.
+    void optimize(unsigned passes = 7u /* CSGN_CIRCUIT_ALL */);
+    void keep(unsigned value);
+    uint64_t blockBytes() const;                              // HBM held by the built circuit
     void build();
     void set(unsigned input, const CiphertextBatch &batch);   // copies the batch into the input's buffer
     void run();                                                // one graph launch (asynchronous)
-    CiphertextBatch value(unsigned id) const;                  // copy of any value after run()
+    CiphertextBatch value(unsigned id) const;                  // copy of a value after run() (compiled circuits: inputs and keep()-ed values)
     std::vector<unsigned char> bits(unsigned bits_id) const;   // synchronises
 };
 

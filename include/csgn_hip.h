@@ -437,7 +437,7 @@ int csgn_circuit_encrypt(csgn_circuit *circuit, uint64_t d, const uint8_t *d_pla
  * key as a result buffer.  BASELINE configs 2 / 4 end to end (encrypt, encrypt, multiply, decrypt) are
  * then two graph nodes (run counter + this kernel) and one pass over 8*dL bytes per pair.  The operands
  * themselves are never materialised; a circuit that needs them as values uses csgn_circuit_encrypt and
- * csgn_circuit_mul instead (the circuit never rewrites what the caller described: every value it was asked
+ * csgn_circuit_mul instead (a tape circuit never rewrites what the caller described: every value it was asked
  * for stays addressable through csgn_circuit_value).  Keys, nonces and runs as for csgn_circuit_encrypt. */
 int csgn_circuit_encrypt_mul(csgn_circuit *circuit, uint64_t d, const uint8_t *d_plain_a, const uint8_t *d_plain_b,
                              const uint64_t *d_key, const uint64_t *d_mask, const csgn_rng *h_rng_a,
@@ -446,8 +446,47 @@ uint64_t csgn_circuit_epoch(const csgn_circuit *circuit);      /* runs launched 
 /* The key a circuit encrypt node built from *h_rng encrypts under: words 0..7 of the ChaCha20 block
  * (constants "csgn node key v1", key = h_rng->key, nonce = h_rng->nonce, counter 0).  Host only. */
 int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8]);
+/* COMPILED circuits (round 5; SURVEY 8f-2 "never materialise").  By default a circuit is a TAPE: every value it was
+ * asked for is written to a region of its own and stays addressable after every run, one kernel per node.
+ * csgn_circuit_optimize(flags != 0) before csgn_circuit_build turns the build into a compiler: only inputs, the
+ * values named by csgn_circuit_output and the decrypt bits survive a run (csgn_circuit_value returns NULL for
+ * every other value), and the passes selected by `flags` arrange the rest:
+ *   CSGN_CIRCUIT_REUSE         liveness -- the graph is a chain of kernel nodes, so the region of a value is handed
+ *                              out again once its last reader has been emitted: the block is the peak live set
+ *                              (csgn_circuit_block_bytes), not the sum of all values;
+ *   CSGN_CIRCUIT_PLACE         add is concatenation (src/Ciphertext.cpp:107-122): a product or sum whose only
+ *                              consumer is an add is written by its producer straight into its slice of the sum
+ *                              (per-element output pitch) -- that operand's copy disappears; operands that cannot be
+ *                              placed (inputs, shared values) are copied into their slice alone;
+ *   CSGN_CIRCUIT_FUSE_DECRYPT  Dec(a*b) = Dec(a) & Dec(b), Dec(a+b) = Dec(a) ^ Dec(b) (src/SecretKey.cpp:131-140 XORs
+ *                              hits over terms): a product or sum whose ONLY consumer is a decrypt is never computed,
+ *                              its operands are decrypted and the bits combined -- ONE level;
+ *   CSGN_CIRCUIT_PUSHDOWN      the same through every level of single-consumer values (a circuit that only asks for
+ *                              bits then decrypts little more than its inputs).
+ * Nodes whose value nothing reads any more are dropped.  Shared sub-expressions are never fused or placed (a value
+ * with two readers is materialised once).  Retained words and all bits are those of the tape, of the one-by-one
+ * calls and of the reference.  The graph must be launched on the stream the inputs were written on, or after
+ * synchronising with it. */
+#define CSGN_CIRCUIT_REUSE 1u
+#define CSGN_CIRCUIT_PLACE 2u
+#define CSGN_CIRCUIT_FUSE_DECRYPT 4u
+#define CSGN_CIRCUIT_ALL 7u
+#define CSGN_CIRCUIT_PUSHDOWN 8u
+int csgn_circuit_optimize(csgn_circuit *circuit, uint32_t flags);
+int csgn_circuit_output(csgn_circuit *circuit, uint32_t value);                /* keep this value materialised and addressable */
 int csgn_circuit_build(csgn_circuit *circuit);
-uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer, NULL before build */
+uint64_t csgn_circuit_block_bytes(const csgn_circuit *circuit);               /* size of the circuit's HBM block; 0 before build */
+/* After build: {block bytes, algorithmic bytes of one run (reads + writes of every emitted kernel, SURVEY 8d's
+ * per-operation figures), nodes described, kernels emitted, add operands placed (copies that disappeared),
+ * decrypts fused, nodes dropped, value regions in the block}. */
+int csgn_circuit_stats(const csgn_circuit *circuit, uint64_t h_stats[8]);
+/* What csgn_circuit_build would do, without touching a device (host only, before build): a JSON object
+ * {"bytes", "values": [{region, addressable, offset, pitch, parent, terms, total}], "ops": [{kind, a, b, out, elided,
+ * placed_a, placed_b, expr}], "exprs": [{kind (-1 leaf, 0 xor, 1 and), value, l, r}], "regions": [{at, bytes, from, to}]}
+ * -- `from`/`to` are the first node that writes and the last that reads a region (-1 = before the run, 2^31-1 = kept).
+ * For tests of the compiler and for a caller who wants to see where the bytes of a circuit went. */
+int csgn_circuit_plan_json(csgn_circuit *circuit, char *h_json, size_t cap);
+uint64_t *csgn_circuit_value(csgn_circuit *circuit, uint32_t value);          /* device pointer; NULL before build, and for a value a compiled circuit did not retain */
 uint64_t csgn_circuit_value_terms(csgn_circuit *circuit, uint32_t value);      /* per element; 0 for a ragged value */
 uint64_t csgn_circuit_value_total_terms(csgn_circuit *circuit, uint32_t value); /* over the whole batch */
 const uint64_t *csgn_circuit_value_offsets(csgn_circuit *circuit, uint32_t value);   /* device CSR offsets (batch+1) of a ragged value, NULL otherwise */

@@ -718,6 +718,34 @@ static int cmd_graph(int count)
     }
     const unsigned res = c.decrypt(x, psk);
     c.build();
+    // the same circuit COMPILED (BatchCircuit::optimize): products written straight into the sums that consume them,
+    // the last product fused into the decrypt, buffers reused -- same bits, a fraction of the HBM, and value() only
+    // for what was kept
+    BatchCircuit cc(ctx, (uint64_t)count);
+    std::vector<unsigned> craw;
+    unsigned cx = 0, cres = 0;
+    {
+        std::vector<unsigned> cin;
+        for (int i = 0; i < inputs; ++i) {
+            craw.push_back(cc.input(1));
+            cin.push_back(cc.permute(craw.back(), perm));
+        }
+        cx = cin[0];
+        int ck = 1;
+        for (int level = 1; level <= levels; ++level) {
+            if (level % 2) {
+                cx = cc.add(cx, cin[ck]);
+                ck += 1;
+            } else {
+                cx = cc.mul(cx, cc.add(cin[ck], cin[ck + 1]));
+                ck += 2;
+            }
+        }
+        cres = cc.decrypt(cx, psk);
+        cc.optimize();
+        cc.build();
+        EXPECT(cc.blockBytes() * 2 < c.blockBytes());
+    }
     for (int round = 0; round < 3; ++round) {
         std::vector<std::vector<unsigned char> > bits(inputs, std::vector<unsigned char>(count));
         std::vector<CiphertextBatch> fresh;
@@ -726,8 +754,10 @@ static int cmd_graph(int count)
                 bits[i][j] = (unsigned char)(((j + 3 * round) * 2654435761u + i * 40503u) >> 11 & 1);
             fresh.push_back(CiphertextBatch::encrypt(sk, bits[i], 7000 + 100 * round + i));
             c.set(raw[i], fresh.back());
+            cc.set(craw[i], fresh.back());
         }
         c.run();
+        cc.run();
         std::vector<unsigned char> yb = bits[0];
         k = 1;
         for (int level = 1; level <= levels; ++level) {
@@ -742,6 +772,16 @@ static int cmd_graph(int count)
             }
         }
         EXPECT(c.bits(res) == yb);
+        EXPECT(cc.bits(cres) == yb);
+        {
+            bool refused = false;
+            try {
+                (void)cc.value(cx);
+            } catch (const std::invalid_argument &) {
+                refused = true;
+            }
+            EXPECT(refused);                      // not kept: never computed
+        }
         CiphertextBatch g = c.value(x);
         EXPECT(g.terms() == 766);
         // sampled elements: the same circuit through the per-object API (applyPermutation, +=, *=)

@@ -2206,6 +2206,178 @@ def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 5, 7), (4096, 32, 3, 7), (130, 3, 70, 7), (1247, 16, 9, 15),
+                                             (1247, 16, 5, 2), (4096, 32, 4, 5)])
+def test_circuit_compiled_matches_tape_on_random_dags(hip, oracle, n, d, batch, flags):
+    """The compiler property on the real kernels: 60 random DAG circuits -- chains, shared
+    sub-expressions, a*a and a+a, values nobody reads, several decrypts, random retained outputs -- built twice, as a
+    TAPE and COMPILED (liveness + placement + decrypt fusion; one parameter set with PUSHDOWN, two with single
+    passes).  Every bit vector of the compiled graph equals the tape's and the circuit evaluated in the clear on
+    the plaintext bits; every retained value is word-identical to the tape's; values the compiler did not retain
+    answer NULL; element 0 of every retained value equals the oracle's mul/add chain; the compiled block is
+    never larger than the tape's."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    from tests.test_circuit_compiler import random_circuit
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 31)
+    dmask = hip.upload(hip.key_mask(n, key))
+    dkey = hip.upload(key)
+    placed = fused = 0
+    for seed in range(60):
+        tape = random_circuit(lib, 3000 + seed, n, batch, dmask.data_ptr(), max_terms=300)
+        comp = random_circuit(lib, 3000 + seed, n, batch, dmask.data_ptr(), max_terms=300)
+        try:
+            check(lib.csgn_circuit_optimize(comp.c, flags))             # (the generator marked the same outputs on both)
+            check(lib.csgn_circuit_build(tape.c))
+            check(lib.csgn_circuit_build(comp.c))
+            assert lib.csgn_circuit_block_bytes(comp.c) <= lib.csgn_circuit_block_bytes(tape.c)
+            stats = (C.c_uint64 * 8)()
+            check(lib.csgn_circuit_stats(comp.c, stats))
+            placed += stats[4]
+            fused += stats[5]
+            ins = [v for v, nd in enumerate(tape.nodes) if nd[0] == "in"]
+            nterms = sum(tape.terms[v] for v in ins)
+            plain = np.random.default_rng(seed).integers(0, 2, size=(nterms, batch)).astype(np.uint8)
+            fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), dkey, dmask, seed=seed + 1)
+            # input v, element e = the terms' fresh ciphertexts side by side; clear value = XOR of their bits
+            row, clear, host = 0, {}, {}
+            hf = hip.download(fresh).reshape(nterms, batch, dl)
+            for v in ins:
+                t = tape.terms[v]
+                words = np.ascontiguousarray(hf[row:row + t].transpose(1, 0, 2))      # [batch, t, dl]
+                clear[v] = np.bitwise_xor.reduce(plain[row:row + t], axis=0)
+                host[v] = words
+                dw = hip.upload(words.reshape(-1))
+                for c in (tape.c, comp.c):
+                    check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, v), dw.data_ptr(), batch * t * dl * 8, hip.stream))
+                row += t
+            check(lib.csgn_circuit_run(tape.c, hip.stream))
+            check(lib.csgn_circuit_run(comp.c, hip.stream))
+            torch.cuda.synchronize()
+            for v, nd in enumerate(tape.nodes):
+                if nd[0] == "add":
+                    clear[v] = clear[nd[1]] ^ clear[nd[2]]
+                elif nd[0] == "mul":
+                    clear[v] = clear[nd[1]] & clear[nd[2]]
+            def fetch(c, ptr, nbytes, dtype):
+                t = torch.empty(nbytes // np.dtype(dtype).itemsize, dtype=torch.int64 if dtype == np.uint64 else torch.uint8,
+                                device=fresh.device)
+                check(lib.csgn_memcpy_d2d(t.data_ptr(), ptr, nbytes, hip.stream))
+                return hip.download(t)
+            for bid, v in enumerate(tape.decrypts):
+                bt = fetch(tape.c, lib.csgn_circuit_bits(tape.c, bid), batch, np.uint8)
+                bc = fetch(comp.c, lib.csgn_circuit_bits(comp.c, bid), batch, np.uint8)
+                assert np.array_equal(bt, bc), (seed, bid)
+                if d >= 16:                                              # (a 3-index key hits by chance)
+                    assert np.array_equal(bc, clear[v]), (seed, bid)
+            for v in range(len(tape.terms)):
+                ptr = lib.csgn_circuit_value(comp.c, v)
+                if v in tape.outputs or tape.nodes[v][0] == "in":
+                    assert ptr is not None, (seed, v)
+                    nb = batch * tape.terms[v] * dl * 8
+                    wc = fetch(comp.c, ptr, nb, np.uint64)
+                    wt = fetch(tape.c, lib.csgn_circuit_value(tape.c, v), nb, np.uint64)
+                    assert np.array_equal(wc, wt), (seed, v)
+                else:
+                    assert ptr is None, (seed, v)
+            # element 0 of the retained outputs against the oracle's chain
+            want0 = {}
+            def oracle_value(v):
+                if v in want0:
+                    return want0[v]
+                nd = tape.nodes[v]
+                if nd[0] == "in":
+                    r = np.ascontiguousarray(host[v][0].reshape(-1))
+                elif nd[0] == "add":
+                    r, _ = oracle.add(oracle_value(nd[1]), oracle_value(nd[2]))
+                else:
+                    r, _ = oracle.mul(n, oracle_value(nd[1]), oracle_value(nd[2]))
+                want0[v] = r
+                return r
+            for v in tape.outputs:
+                got = fetch(comp.c, lib.csgn_circuit_value(comp.c, v), tape.terms[v] * dl * 8, np.uint64)
+                assert np.array_equal(got, oracle_value(v)), (seed, v)
+        finally:
+            tape.close()
+            comp.close()
+    if flags & 2:
+        assert placed > 20
+    if flags & 12:
+        assert fused > 20
+
+
+@pytest.mark.parametrize("n,d,batch", [(4096, 32, 64), (1247, 16, 300), (1247, 16, 1)])
+def test_circuit_compiled_config5(hip, oracle, n, d, batch):
+    """BASELINE config 5 compiled (tests/basic_operations.cpp:34-40 style flow, depth 16, 766 terms): bits equal the tape's
+    and the clear circuit; with the final value marked as an output its words equal the tape's and (element 0) the
+    oracle's; the stats say what the compiler did (7 products placed, 1 decrypt fused, the last product and the add
+    in front of nothing dropped), and a second run on new inputs is right too (regions are reused ACROSS runs)."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    from tests.test_circuit_compiler import config5
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 5)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    tape, x = config5(lib, n, batch, mask_ptr=dmask.data_ptr())
+    comp, _ = config5(lib, n, batch, mask_ptr=dmask.data_ptr())
+    kept, _ = config5(lib, n, batch, mask_ptr=dmask.data_ptr())
+    ins = [v for v, nd in enumerate(tape.nodes) if nd[0] == "in"]
+    try:
+        check(lib.csgn_circuit_optimize(comp.c, 7))
+        check(lib.csgn_circuit_optimize(kept.c, 7))
+        kept.output(x)
+        for c in (tape, comp, kept):
+            check(lib.csgn_circuit_build(c.c))
+        st = (C.c_uint64 * 8)()
+        check(lib.csgn_circuit_stats(comp.c, st))
+        assert st[4] == 7 and st[5] == 1 and st[6] == 1                   # placed, fused, dropped (the last product)
+        st_t = (C.c_uint64 * 8)()
+        check(lib.csgn_circuit_stats(tape.c, st_t))
+        assert st[1] * 2 < st_t[1] and st[0] * 2 < st_t[0]                # algorithmic bytes and block: less than half
+        assert lib.csgn_circuit_value(comp.c, x) is None and lib.csgn_circuit_value(kept.c, x) is not None
+        for rnd in range(2):
+            plain = np.random.default_rng(rnd + batch).integers(0, 2, size=(25, batch)).astype(np.uint8)
+            fresh = hip.encrypt_device_rng(n, d, hip.upload(plain.reshape(-1)), dkey, dmask, seed=rnd + 3)
+            for c in (tape, comp, kept):
+                for i in range(25):
+                    check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c.c, ins[i]), fresh[i * batch * dl:].data_ptr(),
+                                              batch * dl * 8, hip.stream))
+                check(lib.csgn_circuit_run(c.c, hip.stream))
+            xb, k = plain[0].copy(), 1
+            for level in range(1, 17):
+                if level % 2:
+                    xb ^= plain[k]; k += 1
+                else:
+                    xb &= plain[k] ^ plain[k + 1]; k += 2
+            got = {}
+            for name, c in (("tape", tape), ("comp", comp), ("kept", kept)):
+                gb = torch.empty(batch, dtype=torch.uint8, device=fresh.device)
+                check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c.c, 0), batch, hip.stream))
+                got[name] = hip.download(gb)
+                assert np.array_equal(got[name], xb), (name, rnd)
+            wt, wk = hip.empty_words(batch * 766 * dl), hip.empty_words(batch * 766 * dl)
+            check(lib.csgn_memcpy_d2d(wt.data_ptr(), lib.csgn_circuit_value(tape.c, x), batch * 766 * dl * 8, hip.stream))
+            check(lib.csgn_memcpy_d2d(wk.data_ptr(), lib.csgn_circuit_value(kept.c, x), batch * 766 * dl * 8, hip.stream))
+            assert torch.equal(wt, wk)
+            hf = hip.download(fresh).reshape(25, batch, dl)
+            h, k = hf[0, 0], 1
+            for level in range(1, 17):
+                if level % 2:
+                    h, _ = oracle.add(h, hf[k, 0]); k += 1
+                else:
+                    r, _ = oracle.add(hf[k, 0], hf[k + 1, 0])
+                    h, _ = oracle.mul(n, h, r); k += 2
+            assert np.array_equal(hip.download(wk)[:766 * dl], h)
+    finally:
+        for c in (tape, comp, kept):
+            c.close()
+
+
 def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     """A ragged product above 1 GiB (7 000 pairs of 20..44 x 20..44 terms, N=1247) goes in slices, each
     preceded by the device-side operand touch; identical to the unsliced run, sampled pairs equal
