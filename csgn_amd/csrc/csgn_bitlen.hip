@@ -177,7 +177,7 @@ hipError_t decrypt_bitlen(u64 n_bits, u64 d, u64 len, const u64 *v, const u64 *b
     u64 *pos = reinterpret_cast<u64 *>(scratch);
     u64 *partial = pos + len + 1;
     u32 *parity = reinterpret_cast<u32 *>(partial + (len + 1023) / 1024 + 1);
-    hipError_t e = hipMemsetAsync(parity, 0, 8, s);
+    hipError_t e = zero_words(reinterpret_cast<u64 *>(parity), 1, s);      // (a kernel, as every zero fill of a compute path: csgn_device.h)
     if (e != hipSuccess)
         return e;
     const u64 terms = len / dL;                            // src/SecretKey.cpp:126 (times = len/defLen)
@@ -202,7 +202,7 @@ hipError_t permute_bitlen(u64 n_bits, u64 len, const u64 *v, const u64 *bitlen, 
     if (e != hipSuccess)
         return e;
     if (len == 0)
-        return hipMemsetAsync(out, 0, dL * 8, s);
+        return zero_words(out, dL, s);
     k_permute_stream<<<(u32)dL, 64, 0, s>>>(n_bits, len, v, pos, perm, out);
     return hipGetLastError();
 }

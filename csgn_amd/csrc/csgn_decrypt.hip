@@ -409,7 +409,10 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
         // long uniform ciphertexts: chunked fold + one atomicXor per (ciphertext, chunk)
         u32 *partial = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(scratch) +
                                                decrypt_bitmap_bytes(total_terms));
-        hipError_t e = hipMemsetAsync(partial, 0, (size_t)batch * 4u, s);
+        // (a kernel, as every zero fill a circuit may capture: csgn_device.h, zero_words; the bitmap is 32-byte
+        // granular + 64, so `partial` is 8-byte aligned and (batch + 1) / 2 words cover batch u32 and stay inside
+        // the scratch, which ends 16 bytes past them)
+        hipError_t e = zero_words(reinterpret_cast<u64 *>(partial), (batch + 1) / 2, s);
         if (e != hipSuccess)
             return e;
         const u32 chunks = (u32)((terms_uniform + 65535) / 65536);

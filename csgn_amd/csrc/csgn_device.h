@@ -244,6 +244,8 @@ inline hipError_t zero_words(u64 *p, u64 n, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
+    if (tune(TUNE_ZERO_MEMSET))                      // dev: the round-4 form, to test the hypothesis above
+        return hipMemsetAsync(p, 0, n * 8, s);
     const u32 blocks = (u32)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     k_zero_words<<<blocks, 256, 0, s>>>(p, n);
     return hipGetLastError();

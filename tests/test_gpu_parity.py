@@ -2378,6 +2378,63 @@ def test_circuit_compiled_config5(hip, oracle, n, d, batch):
             c.close()
 
 
+@pytest.mark.parametrize("zero_memset", [0, 1])
+def test_circuit_decrypts_a_long_uniform_value_uploaded_just_before_the_run(hip, oracle, knobs, zero_memset):
+    """a circuit whose decrypt takes the long-uniform path (> 4096 terms per element: per-ciphertext partial
+    words are zero-filled inside the graph), inputs uploaded IMMEDIATELY before csgn_circuit_run on the same stream,
+    five times over with new inputs.  With the zero fill as a kernel node (the product) and, through the dev knob
+    zero_memset, as the hipMemsetAsync node round 4 blamed for stale inputs (tools/graph_memset_probe.hip did not
+    reproduce that): the bits equal the one-by-one decrypt and the oracle either way."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    n, d, batch, t = 1247, 16, 3, 70
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 3)
+    dmask = hip.upload(hip.key_mask(n, key))
+    knobs.set("zero_memset", zero_memset)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    a, b = new(lib.csgn_circuit_input, t), new(lib.csgn_circuit_input, t)
+    p = new(lib.csgn_circuit_mul, a, b)                                  # 4900 terms per element
+    bid = new(lib.csgn_circuit_decrypt, p, dmask.data_ptr())
+    check(lib.csgn_circuit_build(c))
+    try:
+        for rnd in range(5):
+            plain = np.random.default_rng(rnd).integers(0, 2, size=2 * t * batch).astype(np.uint8)
+            fresh = hip.encrypt_device_rng(n, d, hip.upload(plain), hip.upload(key), dmask, seed=rnd + 40)
+            torch.cuda.synchronize()
+            half = batch * t * dl
+            check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, a), fresh.data_ptr(), half * 8, hip.stream))
+            check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, b), fresh[half:].data_ptr(), half * 8, hip.stream))
+            check(lib.csgn_circuit_run(c, hip.stream))
+            gb = torch.empty(batch, dtype=torch.uint8, device=fresh.device)
+            check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+            prod = hip.mul_uniform(n, batch, t, t, fresh[:half], fresh[half:])
+            want = hip.download(hip.decrypt_uniform(n, batch, t * t, prod, dmask))
+            got = hip.download(gb)
+            assert np.array_equal(got, want), rnd
+            h0 = hip.download(prod)[:t * t * dl]
+            assert got[0] == oracle.decrypt_canonical(n, key, h0)
+            pb = plain.reshape(2, batch, t)
+            assert np.array_equal(got, np.bitwise_xor.reduce(pb[0], axis=1) & np.bitwise_xor.reduce(pb[1], axis=1))
+    finally:
+        lib.csgn_circuit_destroy(c)
+
+
+def test_circuit_compaction_with_zero_fills_as_memset_nodes(hip, oracle, knobs):
+    """The case round 4 recorded ("the inputs of a circuit with a compaction node read as zeros" with hipMemsetAsync
+    captured as memset nodes), re-run with exactly those nodes back (dev knob zero_memset): see DESIGN 4.9 for what it
+    shows."""
+    knobs.set("zero_memset", 1)
+    test_circuit_with_compaction_bounds_growth(hip, oracle, 1247, 16, 300)
+
+
 def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     """A ragged product above 1 GiB (7 000 pairs of 20..44 x 20..44 terms, N=1247) goes in slices, each
     preceded by the device-side operand touch; identical to the unsliced run, sampled pairs equal

@@ -3,6 +3,10 @@
 // hipMemsetAsync by a kernel without finding the cause.)  Two graphs of the same shape are captured from a side stream:
 //   A: hipMemsetAsync(scratch) -> k_plus_one(in -> out)        (memset node + kernel node)
 //   B: k_zero(scratch)         -> k_plus_one(in -> out)        (kernel nodes only)
+//   C: as A, but input and scratch are two ranges of ONE allocation (input at offset 0, scratch behind it) -- how a
+//      circuit's block is laid out: does the memset node clear the range it was given, or the start of the allocation?
+//   D: as C with the scratch range cleared by a 2-byte-wide memset of odd length (hipMemsetD16Async is not what the
+//      library used; this is hipMemsetAsync of a length that is not a multiple of 4, the decrypt's per-batch partial words)
 // and each is replayed ROUNDS times behind an upload of fresh input on the SAME stream, for every combination of launch
 // stream (the legacy NULL stream, a blocking created stream, a non-blocking created stream) and upload (H2D from pinned
 // memory, H2D from pageable memory, D2D).  A result that does not match the input uploaded just before the launch means
@@ -44,8 +48,10 @@ int main(int argc, char **argv)
     const size_t words = (argc > 1 ? (size_t)atoll(argv[1]) : 64) << 17;      // MiB -> u64 words
     const int rounds = argc > 2 ? atoi(argv[2]) : 12;
     const size_t bytes = words * 8, scratch_words = 1 << 16;
-    unsigned long long *d_in, *d_out, *d_scratch, *d_stage, *h_pin, *h_res;
-    CHECK(hipMalloc(&d_in, bytes));
+    unsigned long long *d_in0, *d_out, *d_scratch, *d_stage, *h_pin, *h_res;
+    unsigned long long *d_block;
+    CHECK(hipMalloc(&d_block, bytes + scratch_words * 8 + 256));
+    CHECK(hipMalloc(&d_in0, bytes));
     CHECK(hipMalloc(&d_out, bytes));
     CHECK(hipMalloc(&d_stage, bytes));
     CHECK(hipMalloc(&d_scratch, scratch_words * 8));
@@ -53,16 +59,20 @@ int main(int argc, char **argv)
     CHECK(hipHostMalloc(&h_res, bytes));
     std::vector<unsigned long long> h_page(words);
 
-    hipGraphExec_t exec[2];
-    for (int g = 0; g < 2; ++g) {
+    hipGraphExec_t exec[4];
+    for (int g = 0; g < 4; ++g) {
         hipStream_t cap;
         CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
         CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
         if (g == 0)
             CHECK(hipMemsetAsync(d_scratch, 0, scratch_words * 8, cap));
-        else
+        else if (g == 1)
             k_zero<<<64, 256, 0, cap>>>(d_scratch, scratch_words);
-        k_plus_one<<<4096, 256, 0, cap>>>(d_in, d_out, words);
+        else if (g == 2)
+            CHECK(hipMemsetAsync(d_block + words, 0, scratch_words * 8, cap));
+        else
+            CHECK(hipMemsetAsync(reinterpret_cast<char *>(d_block + words) + 2, 0, scratch_words * 8 - 3, cap));
+        k_plus_one<<<4096, 256, 0, cap>>>(g >= 2 ? d_block : d_in0, d_out, words);
         hipGraph_t graph;
         CHECK(hipStreamEndCapture(cap, &graph));
         CHECK(hipGraphInstantiate(&exec[g], graph, nullptr, nullptr, 0));
@@ -74,13 +84,14 @@ int main(int argc, char **argv)
     hipStream_t streams[3] = {nullptr, blocking, nonblocking};
     const char *stream_name[3] = {"NULL stream", "created (blocking)", "created (non-blocking)"};
     const char *copy_name[3] = {"H2D pinned", "H2D pageable", "D2D"};
-    const char *graph_name[2] = {"memset node + kernel", "kernel nodes only"};
+    const char *graph_name[4] = {"memset node + kernel", "kernel nodes only", "memset INSIDE the block", "odd memset inside block"};
     int bad_total = 0;
     unsigned long long tag = 1;
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < 4; ++g)
         for (int si = 0; si < 3; ++si)
             for (int ci = 0; ci < 3; ++ci) {
                 hipStream_t s = streams[si];
+                unsigned long long *d_in = g >= 2 ? d_block : d_in0;
                 int bad = 0, zeros = 0;
                 for (int r = 0; r < rounds; ++r) {
                     tag += 0x100000001ull;
@@ -113,7 +124,7 @@ int main(int argc, char **argv)
                     bad += ok ? 0 : 1;
                     zeros += zero ? 1 : 0;
                 }
-                printf("%-22s | launch on %-24s | upload %-13s | %2d of %d runs read stale input%s\n", graph_name[g],
+                printf("%-24s | launch on %-24s | upload %-13s | %2d of %d runs read stale input%s\n", graph_name[g],
                        stream_name[si], copy_name[ci], bad, rounds, zeros ? " (zeros)" : "");
                 bad_total += bad;
             }
