@@ -231,10 +231,15 @@ __device__ inline void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Zero-fill as a KERNEL.  Calls that may be captured into a hipGraph (csgn_circuit_*) do not use
-// hipMemsetAsync: with a memset node in the graph, launches on ROCm 7.2 were seen to start before copies
-// enqueued earlier on the same stream had landed (round 4: the inputs of a circuit with a compaction node
-// read as zeros); graphs of kernel nodes only never showed it.
+// Zero-fill as a KERNEL: no compute path of this library calls hipMemsetAsync, so a circuit's graph
+// (csgn_circuit_*) holds kernel nodes only.  Why (profiles/r05/graph_memset_*.log): circuits whose
+// zero fills were captured as memset NODES have twice returned wrong data inside the long-lived test process
+// (round 4: the inputs of a circuit with a compaction node read as zeros; round 5: one wrong bit in the second
+// of five runs of a long-uniform decrypt), never with kernel nodes.  The cause is NOT pinned: a minimal HIP
+// program (tools/graph_memset_probe.hip: memset node against uploads, fills and atomics on every stream kind,
+// under the ROCm 7.2.0 runtime and under the 7.0.2 one torch bundles) orders memset nodes correctly, and the
+// failing circuit alone ran 240 times clean (tools/graph_memset_case.py).  Dev knob zero_memset = 1 brings the
+// memset form back for such experiments.
 __global__ void __launch_bounds__(256) k_zero_words(u64 *__restrict__ p, u64 n)
 {
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u)
@@ -244,7 +249,7 @@ inline hipError_t zero_words(u64 *p, u64 n, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
-    if (tune(TUNE_ZERO_MEMSET))                      // dev: the round-4 form, to test the hypothesis above
+    if (tune(TUNE_ZERO_MEMSET))                      // dev only (see above)
         return hipMemsetAsync(p, 0, n * 8, s);
     const u32 blocks = (u32)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     k_zero_words<<<blocks, 256, 0, s>>>(p, n);

@@ -46,13 +46,13 @@ def test_bench_contract_line_on_the_gpu():
     """A short run of bench.py (reduced batch; the real shape per pair) prints exactly ONE JSON line on
     stdout with the contract's keys, a roofline object, a cpu_baseline object, and verified results."""
     p = run(["--batch", "512", "--slots", "32", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1.5",
-             "--no-cpu-all-cores"])
+             "--no-cpu-all-cores", "--secondary-seconds", "120"])
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout[:500]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "secondary"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "mult/s" and d["dtype"] == "u64"
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
@@ -65,6 +65,20 @@ def test_bench_contract_line_on_the_gpu():
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    # the secondary suite: every case timed and checked against the oracle, none skipped or failed
+    sec = {row["name"]: row for row in d["secondary"]}
+    for name in ("config5_graph_compiled_n4096", "config5_graph_compiled_n1247", "config5_graph_tape_n4096",
+                 "config5_graph_tape_n1247", "mul_1x1", "add_1024", "decrypt_1024", "permute_1m", "encrypt_keyed_1m",
+                 "mul_ragged_mean8_kernel", "mul_ragged_mean8_async", "mul_ragged_mean16_kernel", "mul_ragged_mean16_async",
+                 "compact_0pct", "compact_50pct"):
+        assert name in sec, name
+        row = sec[name]
+        assert "error" not in row and "skipped" not in row, row
+        assert row["verified"] is True and row["ms"] > 0 and row["bytes"] > 0, row
+        assert abs(row["frac"] - row["bytes"] / (row["ms"] / 1e3) / 8.0e12) < 1e-9 and row["frac"] < 1.0, row
+    # the compiled config-5 graph moves about a third of the tape's bytes and takes less than two thirds of its time
+    assert sec["config5_graph_compiled_n4096"]["bytes"] * 2 < sec["config5_graph_tape_n4096"]["bytes"]
+    assert sec["config5_graph_compiled_n4096"]["ms"] * 1.5 < sec["config5_graph_tape_n4096"]["ms"]
 
 
 @pytest.mark.gpu

@@ -43,6 +43,141 @@ __global__ void k_fill(unsigned long long *p, size_t n, unsigned long long v)
         p[i] = v + i;
 }
 
+__global__ void k_add_one(unsigned long long *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] += 1ull;
+}
+
+// Second question (what the circuits really depend on): is a memset node ORDERED with the kernel nodes around it?
+//   E: k_fill(buf, 7) -> hipMemsetAsync(buf, 0) -> k_add_one(buf)       every replay must leave buf[i] == 1
+//   F: k_fill(buf, 7) -> k_zero(buf)            -> k_add_one(buf)       (kernel nodes only: the control)
+// A memset that runs before the fill leaves 8 + i, one that runs after the add leaves 0, one that is skipped 8 + i.
+// Prints the graph's nodes and edges as captured (a missing edge would be a capture problem, not an execution one).
+static int order_probe(size_t words, int rounds)
+{
+    unsigned long long *d_buf, *h_res;
+    CHECK(hipMalloc(&d_buf, words * 8));
+    CHECK(hipHostMalloc(&h_res, words * 8));
+    int bad_total = 0;
+    for (int g = 0; g < 2; ++g) {
+        hipStream_t cap;
+        CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        k_fill<<<1024, 256, 0, cap>>>(d_buf, words, 7);
+        if (g == 0)
+            CHECK(hipMemsetAsync(d_buf, 0, words * 8, cap));
+        else
+            k_zero<<<1024, 256, 0, cap>>>(d_buf, words);
+        k_add_one<<<1024, 256, 0, cap>>>(d_buf, words);
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CHECK(hipStreamEndCapture(cap, &graph));
+        size_t nn = 0, ne = 0;
+        CHECK(hipGraphGetNodes(graph, nullptr, &nn));
+        CHECK(hipGraphGetEdges(graph, nullptr, nullptr, &ne));
+        CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        CHECK(hipStreamDestroy(cap));
+        hipStream_t s;
+        CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        int bad = 0;
+        unsigned long long first_bad = 0;
+        for (int r = 0; r < rounds; ++r) {
+            CHECK(hipGraphLaunch(exec, s));
+            CHECK(hipMemcpyAsync(h_res, d_buf, words * 8, hipMemcpyDeviceToHost, s));
+            CHECK(hipStreamSynchronize(s));
+            bool ok = true;
+            for (size_t i = 0; i < words && ok; i += 1021)
+                if (h_res[i] != 1ull) {
+                    ok = false;
+                    if (!bad)
+                        first_bad = h_res[i] - (h_res[i] >= 8 ? i : 0);
+                }
+            bad += ok ? 0 : 1;
+        }
+        printf("fill -> %-14s -> add one, %zu MiB | %zu nodes, %zu edges | %2d of %d replays wrong%s\n",
+               g == 0 ? "MEMSET node" : "zeroing kernel", words >> 17, nn, ne, bad, rounds,
+               bad ? (first_bad == 0 ? " (0: the memset ran AFTER the add)" : first_bad == 8 ? " (8 + i: the memset ran before the fill, or not at all)" : " (other)") : "");
+        bad_total += bad;
+        CHECK(hipStreamDestroy(s));
+        CHECK(hipGraphExecDestroy(exec));
+        CHECK(hipGraphDestroy(graph));
+    }
+    CHECK(hipFree(d_buf));
+    CHECK(hipHostFree(h_res));
+    return bad_total;
+}
+
+// Third form, the shape of the circuit that showed a wrong bit (tests/test_gpu_parity.py::
+// test_circuit_decrypts_a_long_uniform_value_uploaded_just_before_the_run[1], gpurun_out/s3): a long kernel, then a
+// 16-byte zero fill of accumulators, then a kernel whose workgroups atomicXor into them, then a reader.
+//   [k_fill(big)] -> zero(acc, 16 B) -> k_xor(acc) -> k_copy(acc -> out)      every replay must leave out == expected
+__global__ void k_xor(unsigned int *acc, int n_acc)
+{
+    if (threadIdx.x == 0)
+        atomicXor(acc + blockIdx.x % n_acc, 1u << (blockIdx.x / n_acc % 31));
+}
+__global__ void k_copy4(const unsigned int *acc, unsigned int *out)
+{
+    if (threadIdx.x < 4)
+        out[threadIdx.x] = acc[threadIdx.x];
+}
+static int accum_probe(int replays, bool null_stream)
+{
+    unsigned long long *d_big;
+    unsigned int *d_acc, *d_out, *h_out;
+    const size_t big = (size_t)1 << 22;
+    CHECK(hipMalloc(&d_big, big * 8 + 4096));
+    d_acc = reinterpret_cast<unsigned int *>(d_big + big) + 6;          // inside the block, 8-byte aligned, not 16
+    CHECK(hipMalloc(&d_out, 64));
+    CHECK(hipHostMalloc(&h_out, 64));
+    int bad_total = 0;
+    for (int g = 0; g < 2; ++g) {
+        hipStream_t cap;
+        CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        k_fill<<<1024, 256, 0, cap>>>(d_big, big, 3);
+        if (g == 0)
+            CHECK(hipMemsetAsync(d_acc, 0, 16, cap));
+        else
+            k_zero<<<1, 64, 0, cap>>>(reinterpret_cast<unsigned long long *>(d_acc), 2);
+        k_xor<<<3 * 31, 256, 0, cap>>>(d_acc, 3);
+        k_copy4<<<1, 64, 0, cap>>>(d_acc, d_out);
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CHECK(hipStreamEndCapture(cap, &graph));
+        CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        CHECK(hipStreamDestroy(cap));
+        hipStream_t s = nullptr;
+        if (!null_stream)
+            CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        int bad = 0;
+        unsigned int seen = 0;
+        for (int r = 0; r < replays; ++r) {
+            CHECK(hipGraphLaunch(exec, s));
+            CHECK(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, s));
+            CHECK(hipStreamSynchronize(s));
+            const bool ok = h_out[0] == 0x7fffffffu && h_out[1] == 0x7fffffffu && h_out[2] == 0x7fffffffu;
+            if (!ok && !bad)
+                seen = h_out[0] ^ h_out[1] ^ h_out[2];
+            bad += ok ? 0 : 1;
+        }
+        printf("long kernel -> %-14s (16 B) -> atomicXor kernel -> reader, launched on %-12s | %3d of %d replays wrong%s\n",
+               g == 0 ? "MEMSET node" : "zeroing kernel", null_stream ? "NULL stream" : "a stream", bad, replays,
+               bad ? " (accumulators not zero when the XORs ran, or zeroed after some)" : "");
+        (void)seen;
+        bad_total += bad;
+        if (s)
+            CHECK(hipStreamDestroy(s));
+        CHECK(hipGraphExecDestroy(exec));
+        CHECK(hipGraphDestroy(graph));
+    }
+    CHECK(hipFree(d_big));
+    CHECK(hipFree(d_out));
+    CHECK(hipHostFree(h_out));
+    return bad_total;
+}
+
 int main(int argc, char **argv)
 {
     const size_t words = (argc > 1 ? (size_t)atoll(argv[1]) : 64) << 17;      // MiB -> u64 words
@@ -129,5 +264,11 @@ int main(int argc, char **argv)
                 bad_total += bad;
             }
     printf("stale runs in all: %d\n", bad_total);
+    int order_bad = 0;
+    for (size_t w : {(size_t)1 << 4, (size_t)1 << 10, (size_t)1 << 17, (size_t)1 << 23})      // 128 B, 8 KiB, 1 MiB, 64 MiB
+        order_bad += order_probe(w, rounds);
+    printf("mis-ordered replays in all: %d\n", order_bad);
+    const int accum_bad = accum_probe(300, true) + accum_probe(300, false);
+    printf("wrong accumulator replays in all: %d\n", accum_bad);
     return 0;
 }
