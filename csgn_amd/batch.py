@@ -143,7 +143,8 @@ class HipPath:
 
     def add_ragged(self, n_bits: int, left: torch.Tensor, off_left: torch.Tensor,
                    right: torch.Tensor, off_right: torch.Tensor,
-                   total_terms_out: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   total_terms_out: Optional[int] = None, max_t1: int = 0, max_t2: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """max_t1 / max_t2: upper bounds on one element's terms if the caller knows them (csgn_add_ragged_bounded)."""
         batch = off_left.numel() - 1
         dl = self.default_len(n_bits)
         if total_terms_out is None:
@@ -151,8 +152,8 @@ class HipPath:
         total = total_terms_out
         out = self.empty_words(max(total * dl, 1))
         off_out = self.empty_words(batch + 1)
-        check(self.lib.csgn_add_ragged(n_bits, batch, _ptr(left), _ptr(off_left), _ptr(right),
-                                       _ptr(off_right), _ptr(out), _ptr(off_out), total, self.stream))
+        check(self.lib.csgn_add_ragged_bounded(n_bits, batch, max_t1, max_t2, _ptr(left), _ptr(off_left), _ptr(right),
+                                               _ptr(off_right), _ptr(out), _ptr(off_out), total, self.stream))
         return out[: total * dl], off_out
 
     # -- decrypt ----------------------------------------------------------------------
@@ -166,15 +167,16 @@ class HipPath:
         return bits[:batch]
 
     def decrypt_ragged(self, n_bits: int, words: torch.Tensor, off: torch.Tensor,
-                       mask: torch.Tensor, total_terms: Optional[int] = None) -> torch.Tensor:
+                       mask: torch.Tensor, total_terms: Optional[int] = None, max_terms: int = 0) -> torch.Tensor:
+        """max_terms: an upper bound on the terms of one ciphertext if the caller knows one (csgn_decrypt_ragged_bounded)."""
         batch = off.numel() - 1
         if total_terms is None:
             total_terms = int(self.download(off[-1:])[0])
         bits = torch.empty(max(batch, 1), dtype=torch.uint8, device=self.device)
         scratch = torch.empty(int(self.lib.csgn_decrypt_scratch_bytes(batch, total_terms)),
                               dtype=torch.uint8, device=self.device)
-        check(self.lib.csgn_decrypt_ragged(n_bits, batch, total_terms, _ptr(words), _ptr(off),
-                                           _ptr(mask), _ptr(bits), _ptr(scratch), self.stream))
+        check(self.lib.csgn_decrypt_ragged_bounded(n_bits, batch, total_terms, max_terms, _ptr(words), _ptr(off),
+                                                   _ptr(mask), _ptr(bits), _ptr(scratch), self.stream))
         return bits[:batch]
 
     def decrypt_combined_uniform(self, n_bits: int, batch: int, t1: int, t2: int, left: torch.Tensor,

@@ -64,9 +64,11 @@ SIGNATURES = {
     "csgn_mul_ragged_async_result": (C.c_int, [vp, C.POINTER(u64 * 5), vp]),
     "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
     "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
+    "csgn_add_ragged_bounded": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
     "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64, u64]),
     "csgn_decrypt_uniform": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp]),
     "csgn_decrypt_ragged": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp, vp]),
+    "csgn_decrypt_ragged_bounded": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_decrypt_combined_scratch_bytes": (C.c_size_t, [u64, u64, u64]),
     "csgn_decrypt_product_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),
     "csgn_decrypt_sum_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp]),

@@ -212,9 +212,10 @@ CiphertextBatch CiphertextBatch::operator+(const CiphertextBatch &rhs) const
         const uint64_t total = totalTerms() + rhs.totalTerms();
         std::shared_ptr<DevicePayload> off_out = detail::allocWords(count_ + 1);
         out.payload = detail::allocWords(total * ctx.getDefaultN());
-        detail::check(csgn_add_ragged(ctx.getN(), count_, deviceValues(), deviceOffsets(), rhs.deviceValues(),
-                                      rhs.deviceOffsets(), out.payload->data(), off_out->data(), total, detail::stream()),
-                      "csgn_add_ragged");
+        detail::check(csgn_add_ragged_bounded(ctx.getN(), count_, maxTerms(), rhs.maxTerms(), deviceValues(), deviceOffsets(),
+                                              rhs.deviceValues(), rhs.deviceOffsets(), out.payload->data(), off_out->data(), total,
+                                              detail::stream()),
+                      "csgn_add_ragged_bounded");
         out.offsets_.resize(count_ + 1);
         for (uint64_t i = 0, run = 0; i <= count_; ++i) {
             out.offsets_[i] = run;
@@ -275,9 +276,9 @@ std::vector<unsigned char> CiphertextBatch::decrypt(const SecretKey &key) const
                                            d_bits, work->ptr, detail::stream()),
                       "csgn_decrypt_uniform");
     else
-        detail::check(csgn_decrypt_ragged(ctx.getN(), count_, totalTerms(), deviceValues(), deviceOffsets(),
-                                          key.device_mask->data(), d_bits, work->ptr, detail::stream()),
-                      "csgn_decrypt_ragged");
+        detail::check(csgn_decrypt_ragged_bounded(ctx.getN(), count_, totalTerms(), maxTerms(), deviceValues(), deviceOffsets(),
+                                                  key.device_mask->data(), d_bits, work->ptr, detail::stream()),
+                      "csgn_decrypt_ragged_bounded");
     detail::downloadBytes(bits.data(), d_bits, count_);
     return bits;
 }

@@ -606,13 +606,27 @@ int csgn_add_ragged(uint64_t n_bits, uint64_t batch,
                     const uint64_t *d_right, const uint64_t *d_off_right,
                     uint64_t *d_out, uint64_t *d_off_out, uint64_t total_terms_out, void *stream)
 {
+    return csgn_add_ragged_bounded(n_bits, batch, 0, 0, d_left, d_off_left, d_right, d_off_right, d_out, d_off_out,
+                                   total_terms_out, stream);
+}
+
+int csgn_add_ragged_bounded(uint64_t n_bits, uint64_t batch, uint64_t max_t1, uint64_t max_t2,
+                            const uint64_t *d_left, const uint64_t *d_off_left,
+                            const uint64_t *d_right, const uint64_t *d_off_right,
+                            uint64_t *d_out, uint64_t *d_off_out, uint64_t total_terms_out, void *stream)
+{
     if (int rc = check_n(n_bits))
         return rc;
     REQUIRE(d_off_left && d_off_right && d_off_out, "null offset pointer");
     REQUIRE(total_terms_out == 0 || batch == 0 || (d_left && d_right && d_out), "null device pointer");
+    const bool bounded = max_t1 != 0 || max_t2 != 0;
+    REQUIRE(!bounded || (max_t1 < (1ull << 31) && max_t2 < (1ull << 31) &&
+                         !product_below(batch, max_t1 + max_t2, 1, total_terms_out)),
+            "bounds %llu + %llu cannot hold: %llu sums of at most that many terms are fewer than total_terms_out = %llu",
+            (unsigned long long)max_t1, (unsigned long long)max_t2, (unsigned long long)batch, (unsigned long long)total_terms_out);
     hipError_t e = csgn::add_ragged(n_bits, batch, (const u64 *)d_left, (const u64 *)d_off_left,
                                     (const u64 *)d_right, (const u64 *)d_off_right, (u64 *)d_out,
-                                    (u64 *)d_off_out, total_terms_out, S(stream));
+                                    (u64 *)d_off_out, total_terms_out, S(stream), false, max_t1, max_t2);
     if (e == hipErrorInvalidValue)
         return fail(CSGN_ERR_UNSUPPORTED, "ragged batch of 2^32 or more pairs; split it");
     HIP_TRY(e);
@@ -641,9 +655,9 @@ int csgn_decrypt_uniform(uint64_t n_bits, uint64_t batch, uint64_t terms,
     return CSGN_OK;
 }
 
-int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
-                        const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
-                        uint8_t *d_bits, void *d_scratch, void *stream)
+int csgn_decrypt_ragged_bounded(uint64_t n_bits, uint64_t batch, uint64_t total_terms, uint64_t max_terms,
+                                const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
+                                uint8_t *d_bits, void *d_scratch, void *stream)
 {
     if (int rc = check_n(n_bits))
         return rc;
@@ -651,9 +665,19 @@ int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
         return CSGN_OK;
     REQUIRE(d_off && d_mask && d_bits && d_scratch && (d_terms || total_terms == 0),
             "null device pointer");
+    REQUIRE(max_terms == 0 || !product_below(batch, max_terms, 1, total_terms),
+            "max_terms = %llu cannot hold: %llu ciphertexts of at most that many terms are fewer than total_terms = %llu",
+            (unsigned long long)max_terms, (unsigned long long)batch, (unsigned long long)total_terms);
     HIP_TRY(csgn::decrypt(n_bits, batch, 0, total_terms, (const u64 *)d_terms, (const u64 *)d_off,
-                          (const u64 *)d_mask, d_bits, d_scratch, S(stream)));
+                          (const u64 *)d_mask, d_bits, d_scratch, S(stream), max_terms));
     return CSGN_OK;
+}
+
+int csgn_decrypt_ragged(uint64_t n_bits, uint64_t batch, uint64_t total_terms,
+                        const uint64_t *d_terms, const uint64_t *d_off, const uint64_t *d_mask,
+                        uint8_t *d_bits, void *d_scratch, void *stream)
+{
+    return csgn_decrypt_ragged_bounded(n_bits, batch, total_terms, 0, d_terms, d_off, d_mask, d_bits, d_scratch, stream);
 }
 
 size_t csgn_decrypt_combined_scratch_bytes(uint64_t batch, uint64_t t1, uint64_t t2)

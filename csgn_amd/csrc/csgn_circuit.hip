@@ -820,7 +820,7 @@ hipError_t emit_expr(csgn_circuit *c, unsigned char *base, const Op &op, int ei,
         *kernels += 1;
         if (!va.per.empty())
             return csgn::decrypt(c->n_bits, c->batch, 0, va.total, A, reinterpret_cast<const u64 *>(base + va.csr_offset),
-                                 (const u64 *)op.mask, base + e.bits, base + e.scratch, s);
+                                 (const u64 *)op.mask, base + e.bits, base + e.scratch, s, va.dynamic ? 0 : va.max_terms);
         return csgn::decrypt(c->n_bits, c->batch, va.terms, c->batch * va.terms, A, nullptr, (const u64 *)op.mask,
                              base + e.bits, base + e.scratch, s);
     }
@@ -940,7 +940,7 @@ int csgn_circuit_build(csgn_circuit *c)
             } else if (!va.per.empty()) {
                 e = csgn::decrypt(c->n_bits, c->batch, 0, va.total, (const u64 *)A,
                                   reinterpret_cast<const u64 *>(base + va.csr_offset), (const u64 *)op.mask,
-                                  bits, base + op.scratch, s);
+                                  bits, base + op.scratch, s, va.dynamic ? 0 : va.max_terms);
             } else {
                 e = csgn::decrypt(c->n_bits, c->batch, va.terms, c->batch * va.terms, (const u64 *)A, nullptr,
                                   (const u64 *)op.mask, bits, base + op.scratch, s);
@@ -976,7 +976,8 @@ int csgn_circuit_build(csgn_circuit *c)
                                                 vb.max_terms, vo.total, s, nullptr, va.total + vb.total)
                              : hipSuccess;
             else
-                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s, vo.dynamic);
+                e = csgn::add_ragged(c->n_bits, c->batch, (const u64 *)A, oa, B, ob, O, oo, vo.total, s, vo.dynamic,
+                                     vo.dynamic ? 0 : va.max_terms, vo.dynamic ? 0 : vb.max_terms);
             alg += op.kind ? (va.total + vb.total + vo.total) * dl * 8 : 2 * vo.total * dl * 8;
             kernels += 1;
             continue;

@@ -316,11 +316,17 @@ size_t decrypt_scratch_bytes(u64 batch, u64 total_terms)
 }
 
 hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, const u64 *terms,
-                   const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s)
+                   const u64 *off, const u64 *mask, uint8_t *bits, void *scratch, hipStream_t s, u64 max_terms)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0)
         return hipSuccess;
+    // a CSR batch in which every ciphertext has exactly max_terms terms (the caller's bound is met with equality) IS a
+    // uniform batch: no offsets are read, single-term ciphertexts get their plaintext bytes from pass 1 itself
+    if (off && max_terms != 0 && batch * max_terms == total_terms) {
+        off = nullptr;
+        terms_uniform = max_terms;
+    }
     u64 *hits = reinterpret_cast<u64 *>(scratch);
     LongWork work = {};
     if (off) {
@@ -399,7 +405,7 @@ hipError_t decrypt(u64 n_bits, u64 batch, u64 terms_uniform, u64 total_terms, co
             return hipErrorInvalidValue;
         // (the work area's counters were zeroed by pass 1; with no terms at all nothing is queued)
         k_hits_parity<1, 1><<<ceil_div_u64(batch, 256), 256, 0, s>>>(hits, off, 0, batch, bits, work);
-        if (total_terms > kLongTerms) {
+        if (total_terms > kLongTerms && (max_terms == 0 || max_terms > kLongTerms)) {       // (a bound says: nothing is queued)
             const u64 max_entries = decrypt_max_entries(batch, total_terms);
             k_hits_parity_chunks<<<(u32)std::min<u64>(8192, max_entries), 256, 0, s>>>(hits, off, work, bits);
         }

@@ -55,6 +55,23 @@ __device__ inline u32 xcd_contiguous_block(u32 b, u32 nblocks)
     return x * q + min(x, r) + (b >> 3);
 }
 
+// The same with the XCDs taking GROUPS of `group` consecutive logical blocks in turn (XCD x owns groups x, x + 8, ...)
+// instead of one contiguous eighth each: every XCD still writes runs of group x 4-16 KiB, but a stretch of the output
+// whose blocks are slow (the single-term pairs behind one huge pair of a skewed ragged batch: latency-bound workgroups)
+// is spread over all eight XCDs instead of being the tail of ONE (round 5: 640 such workgroups, 6 % of the output,
+// were 2.5 rounds of 32 CUs at the end of a launch the other 224 CUs had left).  group = 0: the contiguous eighths.
+// Bijective for any grid size: the blocks past the last whole round of 8 groups keep their own index.
+__device__ inline u32 xcd_grouped_block(u32 b, u32 nblocks, u32 group)
+{
+    if (group == 0u)
+        return xcd_contiguous_block(b, nblocks);
+    const u32 round = 8u * group, full = nblocks - nblocks % round;
+    if (b >= full)
+        return b;
+    const u32 x = b & 7u, q = b >> 3;                            // XCD, index inside the XCD
+    return ((q / group) * 8u + x) * group + q % group;
+}
+
 // largest p in [lo, hi) with off[p] <= term   (requires off[lo] <= term)
 __device__ inline u32 csr_find(const u64 *__restrict__ off, u32 lo, u32 hi, u64 term)
 {

@@ -25,6 +25,8 @@ const Knob kKnobs[TUNE_COUNT] = {
     {"enc_lds", 0},      {"enc_wave", 1},      {"enc_compact", -1},  {"shared_gpu", 0},
     {"compact_tag_bits", 0}, {"compact_nt", 1}, {"compact_grid", 0}, {"ragged_classes", 0},
     {"ragged_coop", -1}, {"ragged_coop_span", 0}, {"ragged_coop_k", 0}, {"ragged_coop_touch", 128}, {"ragged_slice_mb", 0}, {"ragged_coop_pipe", 0},
+    {"ragged_xcd_group", 64},
+    {"ragged_coop_xcd_group", 0},
     {"zero_memset", 0},
 };
 

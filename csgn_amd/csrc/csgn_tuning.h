@@ -44,6 +44,8 @@ enum TuneKey {
     TUNE_RAGGED_COOP_TOUCH, // ... a wave touches the operands of an offset window.s pairs when it loads the window (one dword per 128-byte line): KiB a side at most, 0 = off
     TUNE_RAGGED_SLICE_MB, // ragged multiply: output slice size in MiB, each slice behind a touch of its operands (0 = by the operand share: 1 GiB, 512 MiB or unsliced)
     TUNE_RAGGED_COOP_PIPE, // ... 1 = software-pipelined form (loads of the next group in front of the stores of this one; hand-counted waits), 0 = loads, wait, stores (the default: level with the pipelined form since the operand touch)
+    TUNE_RAGGED_XCD_GROUP, // CSR multiply / add: logical blocks per XCD turn (xcd_grouped_block); 0 = one contiguous eighth of the launch per XCD
+    TUNE_RAGGED_COOP_XCD_GROUP, // wave-cooperative multiply: workgroups per XCD turn (xcd_grouped_block); 0 = contiguous eighths
     TUNE_ZERO_MEMSET,    // dev: 1 = zero fills on capturable paths are hipMemsetAsync (memset NODES in a circuit's graph) instead of the k_zero_words kernel (csgn_device.h, zero_words; tools/graph_memset_probe.hip)
     TUNE_COUNT
 };

@@ -2426,6 +2426,87 @@ def test_circuit_decrypts_a_long_uniform_value_uploaded_just_before_the_run(hip,
         lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("capacity_factor", [1, 40])
+def test_mul_ragged_async_offsets_that_do_not_start_at_zero(hip, oracle, capacity_factor):
+    """offset arrays that are a SUB-RANGE of a larger CSR (first entries 5 and 7, not 0) -- csgn_mul_ragged_async
+    on 3 000 fresh 1 x 1 pairs takes the all-1x1 stream (inside the CSR kernel with a tight capacity bound, as the gated
+    stream kernel in front of the wave-cooperative one with a loose bound) and must read the operands from where the
+    offsets say; the same for a mixed batch through the CSR / wave-cooperative kernels.  Every pair against the oracle."""
+    n, dl = 1247, 20
+    rng = np.random.default_rng(12)
+    for shapes in ([(1, 1)] * 3000, [(int(a), int(b)) for a, b in rng.integers(1, 6, size=(500, 2))]):
+        t1s, t2s = [a for a, _ in shapes], [b for _, b in shapes]
+        offL, offR = csr(t1s) + np.uint64(5), csr(t2s) + np.uint64(7)
+        L, R = hip.synth_fill(61, n, 0, int(offL[-1]) * dl), hip.synth_fill(62, n, 0, int(offR[-1]) * dl)
+        total = int(np.sum(np.asarray(t1s) * np.asarray(t2s)))
+        out, off_out, plan = hip.mul_ragged_async(n, L, hip.upload(offL), R, hip.upload(offR), total * capacity_factor)
+        res = hip.mul_ragged_async_result(plan)
+        assert res[0] == total and res[4] == 0
+        out, oo = hip.download(out), hip.download(off_out)
+        hl, hr = hip.download(L), hip.download(R)
+        for b in range(len(shapes)):
+            want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+            assert np.array_equal(out[int(oo[b]) * dl:int(oo[b + 1]) * dl], want), b
+
+
+def test_add_ragged_with_bounds_on_the_term_counts(hip, oracle):
+    """csgn_add_ragged_bounded: bounds met with equality send a CSR batch to the uniform kernel (50 000 sums of 1 + 1
+    terms, 700 of 3 + 2) -- words and offsets equal csgn_add_ragged's and the oracle's; loose bounds change nothing; bounds
+    too small for the total are refused."""
+    from csgn_amd.capi import CsgnError
+    n, dl = 1247, 20
+    for batch, t1, t2 in ((50000, 1, 1), (700, 3, 2)):
+        L, R = hip.synth_fill(90 + t1, n, 0, batch * t1 * dl), hip.synth_fill(91 + t2, n, 0, batch * t2 * dl)
+        oL, oR = hip.upload(csr([t1] * batch)), hip.upload(csr([t2] * batch))
+        ref, ref_off = hip.add_ragged(n, L, oL, R, oR, total_terms_out=batch * (t1 + t2))
+        ref, ref_off = hip.download(ref), hip.download(ref_off)
+        for b1, b2 in ((t1, t2), (t1 + 1, t2), (40, 50)):
+            got, off = hip.add_ragged(n, L, oL, R, oR, total_terms_out=batch * (t1 + t2), max_t1=b1, max_t2=b2)
+            assert np.array_equal(hip.download(got), ref) and np.array_equal(hip.download(off), ref_off), (batch, b1, b2)
+        hl, hr = hip.download(L), hip.download(R)
+        for b in (0, batch - 1):
+            want, _ = oracle.add(hl[b * t1 * dl:(b + 1) * t1 * dl], hr[b * t2 * dl:(b + 1) * t2 * dl])
+            assert np.array_equal(ref[b * (t1 + t2) * dl:(b + 1) * (t1 + t2) * dl], want)
+        with pytest.raises(CsgnError):
+            hip.add_ragged(n, L, oL, R, oR, total_terms_out=batch * (t1 + t2), max_t1=t1, max_t2=t2 - 1)
+
+
+def test_decrypt_ragged_with_a_bound_on_the_term_counts(hip, oracle):
+    """csgn_decrypt_ragged_bounded: a CSR batch whose bound is met with equality (batch * max_terms == total_terms)
+    runs the uniform kernels -- 70 000 single-term ciphertexts and 900 three-term ones give the bits of
+    csgn_decrypt_uniform, csgn_decrypt_ragged and the oracle; a bound that is not tight, and one above the
+    long-ciphertext threshold, change nothing; a bound too small for total_terms is refused."""
+    from csgn_amd.capi import CsgnError
+    n, dl = 1247, 20
+    key = make_key(n, 2, 9)                                             # short key: one synthetic term in four hits
+    dmask = hip.upload(hip.key_mask(n, key))
+    for batch, t in ((70000, 1), (900, 3)):
+        W = hip.synth_fill(77 + t, n, 0, batch * t * dl)
+        off = hip.upload(csr([t] * batch))
+        want = hip.download(hip.decrypt_uniform(n, batch, t, W, dmask))
+        assert 0 < want.sum() < batch
+        for bound in (t, 0, t + 5, 5000):
+            got = hip.download(hip.decrypt_ragged(n, W, off, dmask, total_terms=batch * t, max_terms=bound))
+            assert np.array_equal(got, want), (batch, t, bound)
+        h = hip.download(W)
+        for b in (0, batch // 2, batch - 1):
+            assert want[b] == oracle.decrypt_canonical(n, key, h[b * t * dl:(b + 1) * t * dl])
+    # ragged for real: the bound only drops the long-ciphertext launch
+    counts = np.random.default_rng(4).integers(0, 9, size=3000)
+    off_h = csr(counts.tolist())
+    W = hip.synth_fill(80, n, 0, int(off_h[-1]) * dl)
+    off = hip.upload(off_h)
+    a = hip.download(hip.decrypt_ragged(n, W, off, dmask, total_terms=int(off_h[-1])))
+    b = hip.download(hip.decrypt_ragged(n, W, off, dmask, total_terms=int(off_h[-1]), max_terms=8))
+    assert np.array_equal(a, b) and a.any()
+    h = hip.download(W)
+    for i in (0, 1, 1500, 2999):
+        v = h[int(off_h[i]) * dl:int(off_h[i + 1]) * dl]
+        assert a[i] == (oracle.decrypt_canonical(n, key, v) if v.size else 0)
+    with pytest.raises(CsgnError):
+        hip.decrypt_ragged(n, W, off, dmask, total_terms=int(off_h[-1]), max_terms=3)   # 3000 * 3 < total
+
+
 def test_ragged_mul_sliced_with_operand_touch(hip, oracle, knobs):
     """A ragged product above 1 GiB (7 000 pairs of 20..44 x 20..44 terms, N=1247) goes in slices, each
     preceded by the device-side operand touch; identical to the unsliced run, sampled pairs equal
