@@ -49,22 +49,17 @@ void mul_plan_notes_from_head(MulPlanNotes &notes, const u64 *offL, const u64 *o
 u32 offsets_checksum_words();          // d_sum of offsets_checksum: this many words, to be added up on the host
 hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u64 *offOut, u64 *d_sum, hipStream_t s);
 // gate (csgn_mul_ragged_async only): three device words the last plan kernel fills for the kernels behind it
-// touchL / touchR (csgn_mul_ragged_async): the operands -- the plan kernel reads one dword per line of the operands of the
-// huge pairs it records, in place of the touch launch the async call cannot size (term_words: words per term)
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
-                           hipStream_t s, u64 *gate = nullptr, u64 capacity_terms = 0, bool can_stream = false,
-                           const u64 *touchL = nullptr, const u64 *touchR = nullptr, u32 term_words = 0);
+                           hipStream_t s, u64 *gate = nullptr, u64 capacity_terms = 0, bool can_stream = false);
 // notes: what the plan of exactly these offset arrays learned about huge pairs and operand size (nullptr: nothing;
 // a circuit's offsets never came from a plan).  operand_terms: left + right terms of the whole batch when the
 // caller knows them (a circuit does: its shapes are static), 0 = unknown; sizes the output slices of a large product.
 // d_gate: csgn_mul_ragged_async -- {real output terms, ...} left on the DEVICE by the plan kernels; the grid is then
-// sized by total_out_terms (the caller's bound) and only the CSR kernel is used.  d_huge: the plan's huge-pair records on
-// the device ([count][32 x {pair, offL, offR, t1, t2, offOut}]): a workgroup of the CSR kernel that starts inside one
-// takes its pair from there instead of searching.
+// sized by total_out_terms (the caller's bound) and only the CSR kernel is used.
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
                       u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes = nullptr, u64 operand_terms = 0,
-                      const u64 *d_gate = nullptr, const u64 *d_huge = nullptr);
+                      const u64 *d_gate = nullptr);
 // plan + multiply enqueued back to back, nothing read back (csgn_mul_ragged_async); d_plan: mul_ragged_async_plan_words(batch)
 u64 mul_ragged_async_plan_words(u64 batch);
 hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R, const u64 *offR,

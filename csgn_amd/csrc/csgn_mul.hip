@@ -226,8 +226,7 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          const u64 *__restrict__ offOut, u32 batch,
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU,
                                                          u32 pf_pairs, const u64 *__restrict__ d_gate,
-                                                         u32 skip_t1, u32 skip_t2, const u64 *__restrict__ d_huge = nullptr,
-                                                         u32 xcd_group = 0)
+                                                         u32 skip_t1, u32 skip_t2, u32 xcd_group = 0)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
     // csgn_mul_ragged_async: the grid was sized for the caller's bound; the real end of the output is
@@ -243,31 +242,7 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         return;
     const u64 term0 = g_begin / U;                              // workgroup-uniform
     const u32 r0blk = (u32)(g_begin - term0 * U);
-    // csgn_mul_ragged_async: the plan kernel has written down the batch's HUGE pairs ({pair, offL, offR, t1, t2, offOut},
-    // at most 32).  Nearly all workgroups of a skewed batch start inside one of them: a look at the records -- one
-    // coalesced round trip, L2-hot -- finds such a workgroup's pair where the 64-ary search below makes three or four
-    // dependent ones (one 1024 x 1024 pair among 65 535 singles: 57 -> 4x us, the search was most of a workgroup's life).
-    u32 pw = 0;
-    bool found = false;
-    if (d_huge) {
-        const u32 lane = threadIdx.x & (kWave - 1);
-        const u32 nrec = (u32)min(d_huge[0], (u64)kHugeRecords);
-        bool hit = false;
-        u32 pair = 0;
-        if (lane < nrec) {
-            const u64 *rec = d_huge + 1 + lane * 6u;
-            const u64 o0 = rec[5], tt = rec[3] * rec[4];
-            hit = term0 >= o0 && term0 - o0 < tt;
-            pair = (u32)rec[0];
-        }
-        const u64 who = __ballot(hit);
-        if (who) {
-            pw = (u32)__shfl((int)pair, (int)__builtin_ctzll(who), kWave);
-            found = true;
-        }
-    }
-    if (!found)
-        pw = wave_find(offOut, 0u, batch, term0);               // the same answer in every wave
+    u32 pw = wave_find(offOut, 0u, batch, term0);               // the same answer in every wave
     // The workgroup that holds the start of a pair pulls the operands of the pair `pf_pairs` further
     // on into the caches (one dword per 128-byte line, values unused): by the time that pair's
     // rows are written its left terms are hits instead of HBM misses under full write load.
@@ -844,20 +819,13 @@ __global__ void __launch_bounds__(kPlanThreads) k_plan(u64 batch, u32 nchunks, c
                                                           const u64 *__restrict__ offR, u64 *__restrict__ offOut,
                                                           u64 *__restrict__ head, u64 *__restrict__ scan, u32 classes,
                                                           u64 *__restrict__ gate, u64 capacity_terms, u32 can_stream, u32 vec,
-                                                          u32 resident, const u32 *__restrict__ touchL = nullptr,
-                                                          const u32 *__restrict__ touchR = nullptr, u32 term_dwords = 0)
+                                                          u32 resident)
 {
     constexpr u32 kWaves = kPlanThreads / kWave;
     __shared__ u64 wtot[kWaves], wmax[3][kWaves], s_prefix;
     __shared__ u32 s_chunk;
     __shared__ u32 h_pairs[kNumClasses];
     __shared__ u64 h_terms[kNumClasses];
-    // csgn_mul_ragged_async: the huge pairs this workgroup meets, for the operand touch at the end
-    constexpr u32 kTouchList = 8;
-    __shared__ u64 s_touch[kTouchList][4];
-    __shared__ u32 s_ntouch;
-    if (threadIdx.x == 0)
-        s_ntouch = 0;
     u64 *plan4 = head, *huge = head + 4;
     const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
 #ifdef CSGN_PLAN_STAMPS
@@ -995,12 +963,6 @@ __global__ void __launch_bounds__(kPlanThreads) k_plan(u64 batch, u32 nchunks, c
                 u64 *rec = huge + 1 + slot * 6;
                 rec[0] = b; rec[1] = l[j]; rec[2] = r[j]; rec[3] = t1; rec[4] = t2; rec[5] = run;
             }
-            if (touchL) {
-                const u32 at = atomicAdd(&s_ntouch, 1u);
-                if (at < kTouchList) {
-                    s_touch[at][0] = l[j]; s_touch[at][1] = t1; s_touch[at][2] = r[j]; s_touch[at][3] = t2;
-                }
-            }
         }
         run += c;
         if (b + 1 == batch) {                       // the owner of the last pair: the closing entries of the three arrays
@@ -1028,31 +990,6 @@ __global__ void __launch_bounds__(kPlanThreads) k_plan(u64 batch, u32 nchunks, c
         if (tid < kNumClasses && h_pairs[tid]) {
             atomicAdd(reinterpret_cast<unsigned long long *>(head + kClassAt + tid), (unsigned long long)h_pairs[tid]);
             atomicAdd(reinterpret_cast<unsigned long long *>(head + kClassAt + kNumClasses + tid), (unsigned long long)h_terms[tid]);
-        }
-    }
-    // csgn_mul_ragged_async (round 5): a huge pair's rows each begin with a left term nobody has loaded -- an HBM miss
-    // under full write load per row, which is why the uniform path and the sliced CSR path run behind an operand touch
-    // (4.6 -> 7.4 TB/s at 1024 x 1024).  The async call cannot size a touch launch (the shapes are device data) and a
-    // launch is 3 us; the plan kernel, which has just SEEN the shapes, reads one dword of every 128-byte line of the
-    // operands of the huge pairs it met (at most 4 MiB a side and pair, 8 pairs a workgroup): by the time the multiply
-    // behind it reaches their rows the lines sit in the L2 / memory-side cache.  One 1024 x 1024 pair among 65 535
-    // singles: the CSR kernel 57 -> 36 us.
-    if (touchL) {
-        __syncthreads();
-        const u32 nt = min(s_ntouch, kTouchList);
-        for (u32 q = 0; q < nt; ++q) {
-#pragma unroll 1
-            for (int side = 0; side < 2; ++side) {
-                const u32 *base = (side ? touchR : touchL) + s_touch[q][side * 2] * term_dwords;
-                const u64 lines = min((s_touch[q][side * 2 + 1] * term_dwords * 4u + 127u) / 128u, (u64)(4u << 20) / 128u);
-                for (u64 ln = tid; ln < lines; ln += kPlanThreads * 4u) {
-                    u32 v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        v[k] = base[min(ln + (u64)k * kPlanThreads, lines - 1u) * 32u];
-                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-                }
-            }
         }
     }
     if (tid != kWave)
@@ -1541,8 +1478,7 @@ u64 mul_ragged_plan_scratch_words(u64 batch) { return plan_lists_at(batch) + (ba
 u64 mul_ragged_plan_head_words() { return kPlanHeadWords; }
 
 hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *offOut, u64 *d_work,
-                           hipStream_t s, u64 *gate, u64 capacity_terms, bool can_stream, const u64 *touchL,
-                           const u64 *touchR, u32 term_words)
+                           hipStream_t s, u64 *gate, u64 capacity_terms, bool can_stream)
 {
     // d_work: [head: plan4 (total, max t1, max t2, max t1*t2), huge count + records, operand totals, checksum slots,
     //          class histogram][scan: one granule per 4096-pair chunk, ticket][class bases][class lists]
@@ -1560,9 +1496,7 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 0;                                                   // unknown: tickets always
     k_plan<<<(u32)nchunks, kPlanThreads, 0, s>>>(batch, (u32)nchunks, offL, offR, offOut, d_work, scan, classes ? 1u : 0u, gate,
-                                                 capacity_terms, can_stream ? 1u : 0u, vec, (u32)cus,
-                                                 reinterpret_cast<const u32 *>(touchL), reinterpret_cast<const u32 *>(touchR),
-                                                 term_words * 2u);
+                                                 capacity_terms, can_stream ? 1u : 0u, vec, (u32)cus);
     if (classes && batch) {
         u64 *bases = d_work + plan_bases_at(batch);
         k_class_bases<<<1, 1, 0, s>>>(d_work, bases);
@@ -1643,7 +1577,7 @@ hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
                       u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes, u64 operand_terms,
-                      const u64 *d_gate, const u64 *d_huge)
+                      const u64 *d_gate)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
@@ -1887,11 +1821,11 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
             k_mul_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                               \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
                 reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs,  \
-                d_gate, skip_t1, skip_t2, d_huge, xcd_group);                                       \
+                d_gate, skip_t1, skip_t2, xcd_group);                                       \
         else                                                                                        \
             k_mul_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
                                                                     (u32)batch, u0, u0 + nu, U, dU, \
-                                                                    pf_pairs, d_gate, skip_t1, skip_t2, d_huge, xcd_group); \
+                                                                    pf_pairs, d_gate, skip_t1, skip_t2, xcd_group); \
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
@@ -1994,15 +1928,19 @@ hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL
     const u64 stream_blocks = (batch * U + 255) / 256;
     const bool can_stream = capacity_terms >= batch && stream_blocks <= kMaxBlocks256;
     // the plan kernels; the last of them also writes the gate (real output terms / does not fit / all pairs 1x1)
-    hipError_t e = mul_ragged_plan(batch, offL, offR, offOut, work, s, gate, capacity_terms, can_stream,
-                                   wide ? L : nullptr, wide ? R : nullptr, (u32)dL);
+    hipError_t e = mul_ragged_plan(batch, offL, offR, offOut, work, s, gate, capacity_terms, can_stream);
     if (e != hipSuccess)
         return e;
     if (capacity_terms == 0)
         return hipGetLastError();
-    // (the stream folded into the CSR kernel -- a launch saved -- was tried in round 5 and measured SLOWER on the batch it
-    // is for: 116.9 against 111.3 us on a million 1 x 1 pairs; k_and_stream's one unit per lane, one short-lived
-    // workgroup per 4 KiB is what that stream wants)
+    // Round 5, tried for the skewed batch (one 1024 x 1024 pair + 65 535 singles, 70 us end to end) and NOT kept: the stream
+    // folded into the CSR kernel (a launch saved: 116.9 against 111.3 us on a million 1 x 1 pairs -- k_and_stream's one
+    // unit per lane and one short-lived workgroup per 4 KiB is what that stream wants); an operand touch of the huge
+    // pairs from inside the plan kernel, and CSR workgroups that start from the plan's huge-pair records instead of the
+    // 64-ary search (no change, 71.7 / 71.9 us: the batch's 21 MB of operands stay in the memory-side cache anyway and the
+    // search was not what the time went to).  What it went to was the TAIL: the 640 latency-bound workgroups of the
+    // singles, 6 % of the output, all on the one XCD that owned the last contiguous eighth of the launch --
+    // xcd_grouped_block (csgn_device.h), 70 -> 54 us.
     if (can_stream) {
         const u64 blocks = stream_blocks;
         {
@@ -2015,7 +1953,7 @@ hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL
         }
     }
     // everything else: the CSR kernel over the caller's bound, stopping at the real end
-    return mul_ragged(n_bits, batch, L, offL, R, offR, out, offOut, 1, 1, capacity_terms, s, nullptr, 0, gate, work + 4);
+    return mul_ragged(n_bits, batch, L, offL, R, offR, out, offOut, 1, 1, capacity_terms, s, nullptr, 0, gate);
 }
 
 } // namespace csgn

@@ -27,6 +27,7 @@ const Knob kKnobs[TUNE_COUNT] = {
     {"ragged_coop", -1}, {"ragged_coop_span", 0}, {"ragged_coop_k", 0}, {"ragged_coop_touch", 128}, {"ragged_slice_mb", 0}, {"ragged_coop_pipe", 0},
     {"ragged_xcd_group", 64},
     {"ragged_coop_xcd_group", 0},
+    {"compact_stagger_us", 8},
     {"zero_memset", 0},
 };
 

@@ -46,6 +46,7 @@ enum TuneKey {
     TUNE_RAGGED_COOP_PIPE, // ... 1 = software-pipelined form (loads of the next group in front of the stores of this one; hand-counted waits), 0 = loads, wait, stores (the default: level with the pipelined form since the operand touch)
     TUNE_RAGGED_XCD_GROUP, // CSR multiply / add: logical blocks per XCD turn (xcd_grouped_block); 0 = one contiguous eighth of the launch per XCD
     TUNE_RAGGED_COOP_XCD_GROUP, // wave-cooperative multiply: workgroups per XCD turn (xcd_grouped_block); 0 = contiguous eighths
+    TUNE_COMPACT_STAGGER_US, // compaction: microseconds by which every second workgroup of the main kernel starts late (phases of the two workgroups of a CU interleave), 0 = together
     TUNE_ZERO_MEMSET,    // dev: 1 = zero fills on capturable paths are hipMemsetAsync (memset NODES in a circuit's graph) instead of the k_zero_words kernel (csgn_device.h, zero_words; tools/graph_memset_probe.hip)
     TUNE_COUNT
 };
