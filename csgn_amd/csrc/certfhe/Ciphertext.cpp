@@ -12,35 +12,49 @@
 
 #include "runtime.h"
 
-#include <sys/mman.h>
 
 namespace certFHE {
 
 namespace {
 // ------------------------------------------------------------------ host mirror storage
-// The host mirror behind getValues() is library-owned ("DO NOT DELETE", src/Ciphertext.h:93-102).  A large
-// one is 2 MiB-aligned and advised onto transparent huge pages: filling fresh 4 KiB pages costs a fault per
-// page -- measured 4.4 GB/s for a 168 MB mirror, a quarter of what the copy itself sustains.
-const size_t kHugeMirrorBytes = (size_t)2 << 20;
+// The host mirror behind getValues() is library-owned ("DO NOT DELETE", src/Ciphertext.h:93-102).  A LARGE one
+// (1 MiB and up) is a PINNED block out of the runtime's pool (detail::pinnedTake): the copy from HBM is then one DMA
+// at the link's rate.  (Round 4's pageable mirror -- 2 MiB-aligned, on transparent huge pages, filled piece by piece
+// through the staging buffers -- reached 8.2 GB/s on a 168 MB product, a sixth of the link: the host's memcpy and
+// first-touch faults, not the copy.)  A 64-byte head in front of the words says which kind the block is.
+const size_t kPinnedMirrorBytes = (size_t)1 << 20;
+struct MirrorHead {
+    uint64_t pinned_capacity;                      // 0: malloc
+    uint64_t pad[7];
+};
 
 uint64_t *allocMirror(uint64_t words)
 {
-    const size_t bytes = (size_t)(words ? words : 1) * 8;
-    void *p = nullptr;
-    if (bytes >= 2 * kHugeMirrorBytes) {
-        const size_t rounded = (bytes + kHugeMirrorBytes - 1) & ~(kHugeMirrorBytes - 1);
-        if (posix_memalign(&p, kHugeMirrorBytes, rounded) != 0)
-            throw std::bad_alloc();
-        (void)madvise(p, rounded, MADV_HUGEPAGE);               // best effort
+    const size_t bytes = (size_t)(words ? words : 1) * 8 + sizeof(MirrorHead);
+    MirrorHead *h = nullptr;
+    if (bytes >= kPinnedMirrorBytes) {
+        size_t capacity = 0;
+        h = static_cast<MirrorHead *>(detail::pinnedTake(bytes, &capacity));
+        h->pinned_capacity = capacity;
     } else {
-        p = malloc(bytes);
-        if (!p)
+        h = static_cast<MirrorHead *>(malloc(bytes));
+        if (!h)
             throw std::bad_alloc();
+        h->pinned_capacity = 0;
     }
-    return static_cast<uint64_t *>(p);
+    return reinterpret_cast<uint64_t *>(h + 1);
 }
 
-void freeMirror(uint64_t *p) { free(p); }
+void freeMirror(uint64_t *p)
+{
+    if (!p)
+        return;
+    MirrorHead *h = reinterpret_cast<MirrorHead *>(p) - 1;
+    if (h->pinned_capacity)
+        detail::pinnedGive(h, (size_t)h->pinned_capacity);
+    else
+        free(h);
+}
 } // namespace
 
 
@@ -174,23 +188,8 @@ Context Ciphertext::getContext() const { return requireContext(certFHEcontext); 
 uint64_t *Ciphertext::getValues() const
 {
     if (!host_v && len && payload) {
-        host_v = allocMirror(len);
-        if ((size_t)len * 8 >= 2 * detail::kStageBytes) {
-            // large mirror: DMA into the pinned staging buffers piece by piece, each piece copied into the
-            // (pageable) mirror while the next one is on the link
-            struct Dest {
-                char *at;
-                static void take(void *ctx, const void *piece, size_t n)
-                {
-                    Dest *d = static_cast<Dest *>(ctx);
-                    memcpy(d->at, piece, n);
-                    d->at += n;
-                }
-            } dest = {reinterpret_cast<char *>(host_v)};
-            detail::downloadStaged(payload->ptr, (size_t)len * 8, &Dest::take, &dest);
-        } else {
-            detail::downloadBytes(host_v, payload->ptr, (size_t)len * 8);
-        }
+        host_v = allocMirror(len);                                 // pinned when large: the copy is one DMA
+        detail::downloadBytes(host_v, payload->ptr, (size_t)len * 8);
     }
     return host_v;
 }

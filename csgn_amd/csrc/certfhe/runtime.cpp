@@ -2,6 +2,7 @@
 #include "runtime.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace certFHE {
@@ -219,19 +220,100 @@ void downloadBytes(void *host, const void *dev, size_t bytes)
         check(csgn_memcpy_d2h(host, dev, bytes, stream()), "csgn_memcpy_d2h");
 }
 
+// ---- pinned host blocks, process-wide (see runtime.h)
+namespace {
+struct PinnedPool {
+    std::mutex lock;
+    std::vector<void *> free_list[BlockCache::kClasses];
+    size_t cached = 0;
+};
+// never destroyed: objects with static storage may drop their mirrors after any destructor of ours has run, and
+// page-locked memory goes back to the system with the process
+PinnedPool &pinnedPool()
+{
+    static PinnedPool *pool = new PinnedPool();
+    return *pool;
+}
+} // namespace
+
+void *pinnedTake(size_t bytes, size_t *capacity)
+{
+    ensureDevice();
+    const int c = BlockCache::size_class(bytes, capacity);
+    PinnedPool &pool = pinnedPool();
+    if (c < BlockCache::kClasses) {
+        std::lock_guard<std::mutex> hold(pool.lock);
+        if (!pool.free_list[c].empty()) {
+            void *p = pool.free_list[c].back();
+            pool.free_list[c].pop_back();
+            pool.cached -= *capacity;
+            return p;
+        }
+    }
+    void *host = nullptr, *alias = nullptr;
+    int rc = csgn_host_alloc(&host, &alias, *capacity);
+    if (rc != CSGN_OK && pool.cached) {            // the system refuses more locked pages: drop what is cached, retry once
+        releasePinnedPool();
+        rc = csgn_host_alloc(&host, &alias, *capacity);
+    }
+    check(rc, "csgn_host_alloc");
+    return host;
+}
+
+void pinnedGive(void *host, size_t capacity)
+{
+    if (!host)
+        return;
+    size_t same = 0;
+    const int c = BlockCache::size_class(capacity, &same);
+    PinnedPool &pool = pinnedPool();
+    {
+        std::lock_guard<std::mutex> hold(pool.lock);
+        if (c < BlockCache::kClasses && pool.cached + capacity <= kPinnedPoolBytes) {
+            pool.free_list[c].push_back(host);
+            pool.cached += capacity;
+            return;
+        }
+    }
+    (void)csgn_host_free(host);
+}
+
+void releasePinnedPool()
+{
+    PinnedPool &pool = pinnedPool();
+    std::lock_guard<std::mutex> hold(pool.lock);
+    for (int c = 0; c < BlockCache::kClasses; ++c) {
+        for (size_t i = 0; i < pool.free_list[c].size(); ++i)
+            (void)csgn_host_free(pool.free_list[c][i]);
+        pool.free_list[c].clear();
+    }
+    pool.cached = 0;
+}
+
+// Staging buffers: two per host thread and device, made on first use and FREED when the thread ends (a server
+// with thread churn would otherwise leak 16 MiB of locked pages per thread that ever serialised something).
 namespace {
 struct StagePair {
     void *host[2] = {nullptr, nullptr};
     void *dev[2] = {nullptr, nullptr};
 };
-thread_local StagePair g_stage[16];
+struct StageSet {
+    StagePair pair[17];                            // one per device, the last for device numbers past 15
+    ~StageSet()
+    {
+        for (int d = 0; d < 17; ++d)
+            for (int w = 0; w < 2; ++w)
+                if (pair[d].host[w])
+                    (void)csgn_host_free(pair[d].host[w]);
+    }
+};
+thread_local StageSet g_stage;
 } // namespace
 
 void *stageBuffer(int which)
 {
     ensureDevice();
-    static thread_local StagePair local;
-    StagePair &sp = (g_device >= 0 && g_device < 16) ? g_stage[g_device] : local;
+    StagePair &sp = g_stage.pair[(g_device >= 0 && g_device < 16) ? g_device : 16];
     if (!sp.host[which])
         check(csgn_host_alloc(&sp.host[which], &sp.dev[which], kStageBytes), "csgn_host_alloc");
     return sp.host[which];

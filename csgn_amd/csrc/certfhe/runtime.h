@@ -53,6 +53,15 @@ void uploadStaged(void *dev, size_t bytes, void (*produce)(void *ctx, void *piec
 // Pinned host byte(s) a kernel can write directly (valid after syncDevice()); *dev_alias is the
 // address to hand to the kernel.  One slot per thread and device, reused by every call.
 volatile unsigned char *resultSlot(void **dev_alias);
+// Pinned (page-locked) host blocks for LARGE host mirrors (Ciphertext::getValues): a device-to-host copy into pinned
+// memory is one DMA at the link's rate, into pageable memory it is staged through a bounce buffer and a host memcpy
+// (8 GB/s for a 168 MB mirror, a sixth of the link).  Pinning itself is slow (tens of milliseconds for such a block),
+// so freed blocks are kept per size class -- process-wide, a mirror may be dropped on any thread -- and handed out
+// again; at most kPinnedPoolBytes stay cached.  *capacity receives the block's real size (pass it back to pinnedGive).
+const size_t kPinnedPoolBytes = (size_t)2 << 30;
+void *pinnedTake(size_t bytes, size_t *capacity);
+void pinnedGive(void *host, size_t capacity);
+void releasePinnedPool();
 // Returns every cached HBM block of the calling thread to the driver.
 void releaseBlockCache();
 
