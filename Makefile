@@ -9,7 +9,7 @@ HIPCC   ?= $(or $(shell command -v hipcc 2>/dev/null),/opt/rocm/bin/hipcc)
 CXX     ?= g++
 CSRC    := csgn_amd/csrc
 LIBDIR  := csgn_amd/lib
-HIP_SRC := $(addprefix $(CSRC)/,csgn_capi.hip csgn_circuit.hip csgn_mul.hip csgn_add.hip csgn_decrypt.hip csgn_encrypt.hip \
+HIP_SRC := $(addprefix $(CSRC)/,csgn_capi.hip csgn_circuit.hip csgn_mul.hip csgn_add.hip csgn_smallops.hip csgn_decrypt.hip csgn_encrypt.hip \
                                 csgn_permute.hip csgn_compact.hip csgn_harness.hip csgn_bitlen.hip csgn_tuning.cpp)
 OBJDIR  := $(LIBDIR)/obj
 HIP_OBJ := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(basename $(HIP_SRC)))

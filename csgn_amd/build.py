@@ -23,7 +23,7 @@ CERTFHE_LIB = os.path.join(LIBDIR, "libcertFHE.so")
 SHARD_LIB = os.path.join(LIBDIR, "libcsgn_shard.so")
 CERTFHE_SHARD_LIB = os.path.join(LIBDIR, "libcertFHE_shard.so")
 
-HIP_SOURCES = ["csgn_capi.hip", "csgn_circuit.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
+HIP_SOURCES = ["csgn_capi.hip", "csgn_circuit.hip", "csgn_mul.hip", "csgn_add.hip", "csgn_smallops.hip", "csgn_decrypt.hip", "csgn_encrypt.hip",
                "csgn_permute.hip", "csgn_compact.hip", "csgn_harness.hip", "csgn_bitlen.hip", "csgn_tuning.cpp"]
 HIP_HEADERS = ["csgn_common.h", "csgn_kernels.h", "csgn_device.h", "csgn_tuning.h", "csgn_capi_util.h"]
 OBJDIR = os.path.join(LIBDIR, "obj")

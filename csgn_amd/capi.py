@@ -44,6 +44,7 @@ SIGNATURES = {
     "csgn_event_create": (C.c_int, [C.POINTER(vp)]),
     "csgn_event_destroy": (C.c_int, [vp]),
     "csgn_event_record": (C.c_int, [vp, vp]),
+    "csgn_event_sync": (C.c_int, [vp]),
     "csgn_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     "csgn_default_len": (u64, [u64]),
     "csgn_context_s": (u64, [u64, u64]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "csgn_mul_ragged_async_result": (C.c_int, [vp, C.POINTER(u64 * 5), vp]),
     "csgn_add_uniform": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp]),
     "csgn_add_ragged": (C.c_int, [u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
+    "csgn_small_ops": (C.c_int, [u64, u64, vp, vp]),
     "csgn_add_ragged_bounded": (C.c_int, [u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, u64, vp]),
     "csgn_decrypt_scratch_bytes": (C.c_size_t, [u64, u64]),
     "csgn_decrypt_uniform": (C.c_int, [u64, u64, u64, vp, vp, vp, vp, vp]),

@@ -127,8 +127,19 @@ void Ciphertext::dropMirrors()
 void Ciphertext::publish(const std::shared_ptr<DevicePayload> &p, uint64_t words)
 {
     dropMirrors();
+    lazy.reset();
     payload = p;
     len = words;
+}
+
+// A ciphertext made by a queued operation (detail::deferSmallOp) has no payload yet: the first look at its words
+// evaluates the queue.
+void Ciphertext::resolve() const
+{
+    if (lazy) {
+        payload = detail::valueOf(lazy);
+        lazy.reset();
+    }
 }
 
 Ciphertext &Ciphertext::operator=(const Ciphertext &c)
@@ -137,6 +148,7 @@ Ciphertext &Ciphertext::operator=(const Ciphertext &c)
         return *this;
     dropMirrors();
     payload = c.payload;                       // immutable payload: sharing == deep copy
+    lazy = c.lazy;                             // ... and so is sharing the node of a queued operation
     len = c.len;
     if (c.custom_bitlen && c.host_bitlen) {
         host_bitlen = new uint64_t[len ? len : 1];
@@ -156,6 +168,7 @@ void Ciphertext::setValues(const uint64_t *V, const uint64_t length)
     std::shared_ptr<DevicePayload> p = detail::uploadWords(V, length);
     freeMirror(host_v);
     host_v = nullptr;
+    lazy.reset();
     payload = p;
     len = length;
 }
@@ -187,6 +200,7 @@ Context Ciphertext::getContext() const { return requireContext(certFHEcontext); 
 
 uint64_t *Ciphertext::getValues() const
 {
+    resolve();
     if (!host_v && len && payload) {
         host_v = allocMirror(len);                                 // pinned when large: the copy is one DMA
         detail::downloadBytes(host_v, payload->ptr, (size_t)len * 8);
@@ -211,7 +225,11 @@ uint64_t Ciphertext::getTerms() const
     return dl ? len / dl : 0;
 }
 
-const uint64_t *Ciphertext::deviceValues() const { return payload ? payload->data() : nullptr; }
+const uint64_t *Ciphertext::deviceValues() const
+{
+    resolve();
+    return payload ? payload->data() : nullptr;
+}
 
 bool Ciphertext::hasCanonicalBitlen() const { return !custom_bitlen; }
 
@@ -274,6 +292,21 @@ Ciphertext Ciphertext::combine(const Ciphertext &a, const Ciphertext &b, bool pr
     const uint64_t n = ctx.getN(), dl = ctx.getDefaultN();
     Ciphertext out;
     out.certFHEcontext = new Context(ctx);
+
+    // small operands (fresh ciphertexts, short sums): the operation is QUEUED, not launched (runtime.h, "deferred small
+    // operations") -- BASELINE config 1 through this API was one 2-3 us launch per 480-byte product
+    if (dl && !a.custom_bitlen && !b.custom_bitlen && a.len % dl == 0 && b.len % dl == 0 && a.len && b.len &&
+        a.len / dl <= detail::kDeferMaxTerms && b.len / dl <= detail::kDeferMaxTerms && (a.payload || a.lazy) &&
+        (b.payload || b.lazy) && requireContext(b.certFHEcontext).getN() == n) {
+        std::shared_ptr<detail::LazyNode> node =
+            detail::deferSmallOp(product, n, dl, a.len / dl, b.len / dl, a.lazy ? std::shared_ptr<DevicePayload>() : a.payload,
+                                 a.lazy, b.lazy ? std::shared_ptr<DevicePayload>() : b.payload, b.lazy);
+        if (node) {
+            out.lazy = node;
+            out.len = product ? (a.len / dl) * (b.len / dl) * dl : a.len + b.len;
+            return out;
+        }
+    }
 
     if (product) {
         const uint64_t t1 = dl ? a.len / dl : 0, t2 = dl ? b.len / dl : 0;
@@ -361,6 +394,7 @@ uint64_t getU64(std::istream &in)
 void Ciphertext::serialize(std::ostream &out) const
 {
     const Context &ctx = requireContext(certFHEcontext);
+    resolve();
     out.write(kWireMagic, 4);
     const unsigned char ver_flags[4] = {1, 0, (unsigned char)(custom_bitlen ? 1 : 0), 0};
     out.write(reinterpret_cast<const char *>(ver_flags), 4);

@@ -21,6 +21,10 @@ int Library::currentDevice() { return detail::activeDevice(); }
 
 void Library::releaseDeviceCache() { detail::releaseBlockCache(); }
 
+void Library::deferSmallOperations(bool on) { detail::setDeferral(on); }
+
+void Library::flush() { detail::flushDeferred(); }
+
 bool Helper::exists(const uint64_t *v, const uint64_t len, const uint64_t value)
 {
     for (uint64_t i = 0; i < len; ++i)

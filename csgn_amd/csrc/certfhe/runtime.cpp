@@ -1,6 +1,8 @@
 // runtime.cpp -- device bring-up, error translation and HBM buffers for the certFHE:: classes.
 #include "runtime.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -175,7 +177,7 @@ void ensureDevice()
 
 DevicePayload::~DevicePayload()
 {
-    if (!ptr)
+    if (!ptr || parent)                 // a view: the parent owns the bytes
         return;
     // only the cache of a thread bound to the SAME device may recycle the block
     BlockCache *c = (device == g_device) ? cache() : nullptr;
@@ -190,8 +192,15 @@ std::shared_ptr<DevicePayload> allocBytes(size_t bytes)
     ensureDevice();
     std::shared_ptr<DevicePayload> p = std::make_shared<DevicePayload>();
     p->device = g_device;
-    if (bytes)
-        p->ptr = cache()->take(bytes, &p->capacity);
+    if (bytes) {
+        BlockCache *c = cache();
+        if (c) {
+            p->ptr = c->take(bytes, &p->capacity);
+        } else {                                   // the thread is ending and its cache is gone: straight from the driver
+            p->capacity = bytes;
+            check(csgn_malloc(&p->ptr, bytes), "csgn_malloc");
+        }
+    }
     p->words = bytes / 8;
     return p;
 }
@@ -362,6 +371,287 @@ void syncDevice()
 {
     if (g_device >= 0)
         check(csgn_stream_sync(stream()), "csgn_stream_sync");
+}
+
+// ------------------------------------------------------------------ deferred small operations (see runtime.h)
+namespace {
+std::atomic<bool> g_defer_on(getenv("CSGN_NO_DEFER") == nullptr);
+}
+
+struct DeferQueue {
+    std::mutex lock;
+    std::vector<std::shared_ptr<LazyNode> > pending;
+    int device = -1;
+    uint64_t n_bits = 0;
+    // the records of a flush live in pinned, device-addressable memory: the kernel reads them over the link, no copy
+    // is enqueued.  A ring of slots, each with an event recorded behind its launches: a slot is rewritten only after
+    // that event has passed (it has, long since, unless the host runs eight flushes ahead of the GPU).
+    static const int kSlots = 8;
+    csgn_small_op *h_ops = nullptr, *d_ops = nullptr;
+    void *slot_event[kSlots] = {nullptr};
+    bool slot_used[kSlots] = {false};
+    int slot = 0;
+
+    ~DeferQueue()
+    {
+        for (int i = 0; i < kSlots; ++i)
+            if (slot_event[i])
+                (void)csgn_event_destroy(slot_event[i]);
+        if (h_ops)
+            (void)csgn_host_free(h_ops);
+    }
+
+    // evaluate everything that is pending.  Called with `lock` held, on ANY thread: the work goes to the queue's device.
+    void flushLocked()
+    {
+        if (pending.empty())
+            return;
+        const int caller_device = g_device;
+        const bool foreign = caller_device != device;
+        if (foreign)
+            check(csgn_init(device), "csgn_init (flush of another thread's queue)");
+        try {
+            evaluate(foreign);
+        } catch (...) {
+            if (foreign && caller_device >= 0)
+                (void)csgn_init(caller_device);
+            throw;
+        }
+        if (foreign && caller_device >= 0)
+            check(csgn_init(caller_device), "csgn_init");
+    }
+
+    void evaluate(bool foreign)
+    {
+        const size_t n = pending.size();
+        // One or two operations (a short sum in front of a large product: `big * (a + b)`): the ordinary kernels, one
+        // launch each, in queue order -- the record path's fixed costs (the event, records read over the link: 8 us a
+        // flush against 2.7 us a launch) only pay from a handful of operations on.
+        if (n <= 2 && !foreign) {
+            for (size_t i = 0; i < n; ++i) {
+                LazyNode &nd = *pending[i];
+                const uint64_t *A = nd.la ? nd.la->value->data() : nd.pa->data();
+                const uint64_t *B = nd.lb ? nd.lb->value->data() : nd.pb->data();
+                std::shared_ptr<DevicePayload> v = allocWords((nd.product ? (uint64_t)nd.t1 * nd.t2 : (uint64_t)nd.t1 + nd.t2) * nd.dl);
+                if (nd.product)
+                    check(csgn_mul_uniform(nd.n_bits, 1, nd.t1, nd.t2, A, B, v->data(), 0, stream()), "csgn_mul_uniform");
+                else
+                    check(csgn_add_uniform(nd.n_bits, 1, nd.t1, nd.t2, A, B, v->data(), stream()), "csgn_add_uniform");
+                nd.value = v;
+                nd.queue = nullptr;
+            }
+            for (size_t i = 0; i < n; ++i) {
+                pending[i]->pa.reset();
+                pending[i]->pb.reset();
+                pending[i]->la.reset();
+                pending[i]->lb.reset();
+            }
+            pending.clear();
+            return;
+        }
+        if (!h_ops) {
+            void *h = nullptr, *d = nullptr;
+            check(csgn_host_alloc(&h, &d, sizeof(csgn_small_op) * kDeferBatch * kSlots), "csgn_host_alloc");
+            h_ops = static_cast<csgn_small_op *>(h);
+            d_ops = static_cast<csgn_small_op *>(d);
+        }
+        // where every result goes: side by side in one block, 16-byte aligned
+        std::vector<uint64_t> at(n);
+        uint64_t total = 0;
+        int max_level = 0;
+        for (size_t i = 0; i < n; ++i) {
+            LazyNode &nd = *pending[i];
+            nd.index = (int)i;
+            nd.level = 0;
+            if (nd.la)
+                nd.level = std::max(nd.level, nd.la->level + 1);
+            if (nd.lb)
+                nd.level = std::max(nd.level, nd.lb->level + 1);
+            max_level = std::max(max_level, nd.level);
+            at[i] = total;
+            const uint64_t words = (nd.product ? (uint64_t)nd.t1 * nd.t2 : (uint64_t)nd.t1 + nd.t2) * nd.dl;
+            total += (words + 1) & ~1ull;
+        }
+        std::shared_ptr<DevicePayload> block;
+        if (!foreign) {
+            block = allocWords(total);
+        } else {                                   // another thread's device: not through this thread's block cache
+            block = std::make_shared<DevicePayload>();
+            block->device = device;
+            block->capacity = (size_t)total * 8;
+            block->words = total;
+            check(csgn_malloc(&block->ptr, block->capacity), "csgn_malloc");
+        }
+        uint64_t *base = block->data();
+        const int cur = slot;
+        slot = (slot + 1) % kSlots;
+        if (!slot_event[cur])
+            check(csgn_event_create(&slot_event[cur]), "csgn_event_create");
+        if (slot_used[cur])
+            check(csgn_event_sync(slot_event[cur]), "csgn_event_sync");     // the launch that read this slot has run
+        csgn_small_op *h = h_ops + (size_t)cur * kDeferBatch, *d = d_ops + (size_t)cur * kDeferBatch;
+        // records level by level: a level's operations only read payloads and results of earlier levels
+        std::vector<size_t> start((size_t)max_level + 2, 0);
+        for (size_t i = 0; i < n; ++i)
+            start[(size_t)pending[i]->level + 1] += 1;
+        for (size_t l = 1; l < start.size(); ++l)
+            start[l] += start[l - 1];
+        std::vector<size_t> fill(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < n; ++i) {
+            const LazyNode &nd = *pending[i];
+            csgn_small_op &op = h[fill[(size_t)nd.level]++];
+            op.left = nd.la ? base + at[(size_t)nd.la->index] : nd.pa->data();
+            op.right = nd.lb ? base + at[(size_t)nd.lb->index] : nd.pb->data();
+            op.out = base + at[i];
+            op.t1 = nd.t1;
+            op.t2 = nd.t2;
+            op.kind = nd.product ? 1u : 0u;
+            op.reserved = 0;
+        }
+        for (int l = 0; l <= max_level; ++l) {
+            const size_t cnt = start[(size_t)l + 1] - start[(size_t)l];
+            if (cnt)
+                check(csgn_small_ops(n_bits, cnt, d + start[(size_t)l], stream()), "csgn_small_ops");
+        }
+        check(csgn_event_record(slot_event[cur], stream()), "csgn_event_record");
+        slot_used[cur] = true;
+        for (size_t i = 0; i < n; ++i) {
+            LazyNode &nd = *pending[i];
+            std::shared_ptr<DevicePayload> v = std::make_shared<DevicePayload>();
+            v->ptr = base + at[i];
+            v->words = (nd.product ? (uint64_t)nd.t1 * nd.t2 : (uint64_t)nd.t1 + nd.t2) * nd.dl;
+            v->capacity = (size_t)v->words * 8;
+            v->device = device;
+            v->parent = block;
+            nd.value = v;
+            nd.pa.reset();
+            nd.pb.reset();
+            nd.queue = nullptr;
+        }
+        for (size_t i = 0; i < n; ++i) {              // (after every node has its value: a node may be another's operand)
+            pending[i]->la.reset();
+            pending[i]->lb.reset();
+        }
+        pending.clear();
+    }
+};
+
+namespace {
+thread_local DeferQueue *g_queue_ptr = nullptr;
+struct QueueGuard {
+    bool dead = false;
+    ~QueueGuard()
+    {
+        if (g_queue_ptr) {
+            try {
+                std::lock_guard<std::mutex> hold(g_queue_ptr->lock);
+                g_queue_ptr->flushLocked();          // results somebody still points at must exist
+            } catch (...) {
+            }
+            delete g_queue_ptr;
+            g_queue_ptr = nullptr;
+        }
+        dead = true;
+    }
+};
+thread_local QueueGuard g_queue_guard;
+
+DeferQueue *queue()
+{
+    if (!g_queue_ptr && !g_queue_guard.dead) {
+        ensureDevice();
+        g_queue_ptr = new DeferQueue();
+        g_queue_ptr->device = g_device;
+    }
+    return g_queue_ptr;
+}
+} // namespace
+
+void setDeferral(bool on)
+{
+    if (!on)
+        flushDeferred();
+    g_defer_on.store(on);
+}
+bool deferralOn() { return g_defer_on.load(); }
+
+void flushDeferred()
+{
+    if (!g_queue_ptr)
+        return;
+    std::lock_guard<std::mutex> hold(g_queue_ptr->lock);
+    g_queue_ptr->flushLocked();
+}
+
+std::shared_ptr<DevicePayload> valueOf(const std::shared_ptr<LazyNode> &node)
+{
+    if (!node)
+        return std::shared_ptr<DevicePayload>();
+    for (;;) {
+        DeferQueue *q = node->queue;                 // (read without the lock: nullptr only ever replaces a queue)
+        if (!q)
+            return node->value;
+        std::lock_guard<std::mutex> hold(q->lock);
+        if (node->queue == q) {                      // still pending there
+            q->flushLocked();
+            return node->value;
+        }
+    }
+}
+
+std::shared_ptr<LazyNode> deferSmallOp(bool product, uint64_t n_bits, uint64_t dl, uint64_t t1, uint64_t t2,
+                                       const std::shared_ptr<DevicePayload> &pa, const std::shared_ptr<LazyNode> &la,
+                                       const std::shared_ptr<DevicePayload> &pb, const std::shared_ptr<LazyNode> &lb)
+{
+    if (!g_defer_on.load() || t1 == 0 || t2 == 0 || t1 > kDeferMaxTerms || t2 > kDeferMaxTerms || dl == 0)
+        return std::shared_ptr<LazyNode>();
+    DeferQueue *q = queue();
+    if (!q || q->device != g_device)                 // thread shutting down, or it moved to another GPU meanwhile
+        return std::shared_ptr<LazyNode>();
+    // operands pending in ANOTHER thread's queue (or already evaluated) are taken as finished payloads, so that a
+    // queue only ever refers to its own nodes
+    std::shared_ptr<DevicePayload> fa = pa, fb = pb;
+    std::shared_ptr<LazyNode> na = la, nb = lb;
+    if (na && na->queue != q) {
+        fa = valueOf(na);
+        na.reset();
+    }
+    if (nb && nb->queue != q) {
+        fb = valueOf(nb);
+        nb.reset();
+    }
+    if ((!fa && !na) || (!fb && !nb))
+        return std::shared_ptr<LazyNode>();
+    if ((fa && fa->device != q->device) || (fb && fb->device != q->device))
+        return std::shared_ptr<LazyNode>();          // operands of another GPU: the immediate path reports that
+    std::lock_guard<std::mutex> hold(q->lock);
+    if (!q->pending.empty() && q->n_bits != n_bits)
+        q->flushLocked();                            // one launch serves one term size
+    if (na && !na->queue) {                          // (evaluated by the flush just above)
+        fa = na->value;
+        na.reset();
+    }
+    if (nb && !nb->queue) {
+        fb = nb->value;
+        nb.reset();
+    }
+    q->n_bits = n_bits;
+    std::shared_ptr<LazyNode> nd = std::make_shared<LazyNode>();
+    nd->pa = fa;
+    nd->pb = fb;
+    nd->la = na;
+    nd->lb = nb;
+    nd->n_bits = n_bits;
+    nd->dl = dl;
+    nd->t1 = (uint32_t)t1;
+    nd->t2 = (uint32_t)t2;
+    nd->product = product;
+    nd->queue = q;
+    nd->index = nd->level = 0;
+    q->pending.push_back(nd);
+    if (q->pending.size() >= kDeferBatch)
+        q->flushLocked();
+    return nd;
 }
 
 } // namespace detail

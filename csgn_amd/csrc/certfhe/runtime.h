@@ -20,6 +20,7 @@ struct DevicePayload {
     uint64_t words;
     size_t capacity;      // bytes actually reserved (a size class of the block cache)
     int device;           // GPU the block lives on
+    std::shared_ptr<DevicePayload> parent;   // set: this is a VIEW into parent's block (a result of a flushed queue); nothing of its own to free
     DevicePayload() : ptr(nullptr), words(0), capacity(0), device(-1) {}
     ~DevicePayload();
     DevicePayload(const DevicePayload &) = delete;
@@ -64,6 +65,36 @@ void pinnedGive(void *host, size_t capacity);
 void releasePinnedPool();
 // Returns every cached HBM block of the calling thread to the driver.
 void releaseBlockCache();
+
+// ---- deferred small operations (round 5).  A kernel launch is 2-3 us of host time; a 1 x 1 product is
+// 480 bytes.  operator* / operator+ on ciphertexts of at most kDeferMaxTerms terms a side therefore do not launch:
+// they append a LazyNode to the calling thread's queue and return a ciphertext that points at it.  The queue is
+// evaluated -- ONE csgn_small_ops launch per dependency level, results side by side in one HBM block -- when a value
+// is needed (getValues, decrypt, serialize, an operation that is not deferred), when kDeferBatch operations have
+// piled up, or when the thread ends.  A node keeps its operands alive (payloads are immutable), so the caller's
+// objects may die or be reassigned in between; results are the words of the immediate path.
+const uint32_t kDeferMaxTerms = 8;
+const size_t kDeferBatch = 256;
+struct DeferQueue;
+struct LazyNode {
+    std::shared_ptr<DevicePayload> value;          // set once evaluated (under the queue's lock)
+    std::shared_ptr<DevicePayload> pa, pb;         // finished operands ...
+    std::shared_ptr<LazyNode> la, lb;              // ... or operands still pending in the same queue
+    uint64_t n_bits, dl;
+    uint32_t t1, t2;
+    bool product;
+    DeferQueue *queue;                             // the queue that holds the node; nullptr once evaluated
+    int index, level;                              // scratch of the flush
+};
+// An operand: a finished payload or a pending node (exactly one of the two).  Returns nullptr when the operation is
+// not to be deferred (too large, deferral off, thread shutting down): the caller then computes at once.
+std::shared_ptr<LazyNode> deferSmallOp(bool product, uint64_t n_bits, uint64_t dl, uint64_t t1, uint64_t t2,
+                                       const std::shared_ptr<DevicePayload> &pa, const std::shared_ptr<LazyNode> &la,
+                                       const std::shared_ptr<DevicePayload> &pb, const std::shared_ptr<LazyNode> &lb);
+std::shared_ptr<DevicePayload> valueOf(const std::shared_ptr<LazyNode> &node);   // evaluates the node's queue if it has to
+void flushDeferred();                  // the calling thread's queue
+void setDeferral(bool on);             // process-wide switch (Library::deferSmallOperations; CSGN_NO_DEFER=1 starts off)
+bool deferralOn();
 
 inline void *stream() { return nullptr; }   // the classes run on the default stream
 

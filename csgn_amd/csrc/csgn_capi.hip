@@ -274,6 +274,13 @@ int csgn_event_record(void *event, void *stream)
     return CSGN_OK;
 }
 
+int csgn_event_sync(void *event)
+{
+    REQUIRE(event, "event is null");
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return CSGN_OK;
+}
+
 int csgn_event_elapsed_ms(void *start, void *stop, float *h_ms)
 {
     REQUIRE(start && stop && h_ms, "null argument");
@@ -629,6 +636,20 @@ int csgn_add_ragged_bounded(uint64_t n_bits, uint64_t batch, uint64_t max_t1, ui
                                     (u64 *)d_off_out, total_terms_out, S(stream), false, max_t1, max_t2);
     if (e == hipErrorInvalidValue)
         return fail(CSGN_ERR_UNSUPPORTED, "ragged batch of 2^32 or more pairs; split it");
+    HIP_TRY(e);
+    return CSGN_OK;
+}
+
+int csgn_small_ops(uint64_t n_bits, uint64_t count, const csgn_small_op *d_ops, void *stream)
+{
+    if (int rc = check_n(n_bits))
+        return rc;
+    if (count == 0)
+        return CSGN_OK;
+    REQUIRE(d_ops, "d_ops is null");
+    const hipError_t e = csgn::small_ops(n_bits, count, d_ops, S(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(CSGN_ERR_UNSUPPORTED, "more than 2^24 - 1 operations in one call; split the list");
     HIP_TRY(e);
     return CSGN_OK;
 }

@@ -4,6 +4,8 @@
 
 #include "csgn_common.h"
 
+struct csgn_small_op;   // include/csgn_hip.h
+
 namespace csgn {
 
 // Tunables of the tiled all-pairs kernel; defaults chosen by measurement on MI355X
@@ -108,6 +110,7 @@ hipError_t circuit_zero_words(u64 *p, u64 n, hipStream_t s);   // zero-fill by a
 hipError_t synth_fill(u64 seed, u64 n_bits, u64 first_word, u64 n_words, u64 *out, hipStream_t s);
 hipError_t digest(const u64 *w, u64 n_words, u64 first_index, u64 *d_digest, hipStream_t s);
 
+hipError_t small_ops(u64 n_bits, u64 count, const ::csgn_small_op *ops, hipStream_t s);
 size_t decrypt_scratch_bytes(u64 batch, u64 total_terms);
 // out[i] = a[i] & b[i] (is_product) or a[i] ^ b[i]: Dec(a*b) = Dec(a) & Dec(b), Dec(a+b) = Dec(a) ^ Dec(b)
 hipError_t combine_bits(const uint8_t *a, const uint8_t *b, u64 n, bool is_product, uint8_t *out, hipStream_t s);

@@ -28,13 +28,16 @@ namespace certFHE {
 
 namespace detail {
 struct DevicePayload;   // device buffer + word count (csgn_amd/csrc/certfhe/runtime.h)
+struct LazyNode;        // a queued small + or * whose result does not exist yet (runtime.h)
 }
 
 class SecretKey;
 class CiphertextBatch;
 
 class Ciphertext {
-    std::shared_ptr<detail::DevicePayload> payload; // immutable once published
+    mutable std::shared_ptr<detail::DevicePayload> payload; // immutable once published
+    mutable std::shared_ptr<detail::LazyNode> lazy; // set instead of payload while the producing operation is queued
+    void resolve() const;                           // queue evaluated, payload set
     uint64_t len;                                   // words (T * dL)
     Context *certFHEcontext;                        // owned copy, may be null (default ctor)
 

@@ -23,6 +23,13 @@ class Library {
     // Freed ciphertext buffers are cached per size class for re-use (hipMalloc/hipFree are
     // slow and hipFree synchronises); this hands the cached HBM back to the driver.
     static void releaseDeviceCache();
+    // operator* / operator+ on ciphertexts of at most 8 terms a side are QUEUED per thread and evaluated together -- one
+    // launch per 256 operations instead of one each -- when a value is looked at (getValues, decrypt, serialize, a larger
+    // operation) or the queue is full; results and their words are unchanged.  On by default (CSGN_NO_DEFER=1 in the
+    // environment starts with it off); deferSmallOperations(false) evaluates what is queued and computes at once from
+    // then on; flush() evaluates the calling thread's queue now (e.g. before timing something else).
+    static void deferSmallOperations(bool on);
+    static void flush();
 };
 
 class Helper {

@@ -92,6 +92,7 @@ int csgn_event_create(void **event);
 int csgn_event_destroy(void *event);
 int csgn_event_record(void *event, void *stream);
 int csgn_event_elapsed_ms(void *start, void *stop, float *h_ms);   /* synchronises on stop */
+int csgn_event_sync(void *event);                                  /* returns once the work recorded in front of the event has run */
 
 /* ------------------------------------------------- host-side metadata helpers ---- */
 
@@ -216,6 +217,27 @@ int csgn_add_ragged_bounded(uint64_t n_bits, uint64_t batch, uint64_t max_t1, ui
                             const uint64_t *d_right, const uint64_t *d_off_right,
                             uint64_t *d_out, uint64_t *d_off_out,
                             uint64_t total_terms_out, void *stream);
+
+/* A LIST of small, independent operations in one launch (round 5).  BASELINE config 1 is single operations on
+ * one- and two-term ciphertexts behind a value-semantic API (tests/basic_operations.cpp:26-40): 480 bytes of traffic
+ * and 2-3 us of launch each when issued one by one, 10-20 x the reference's 0.12-0.28 us.  A caller that can QUEUE
+ * such operations (the class layer does: csgn_amd/csrc/certfhe/runtime.cpp) hands the queue over as records
+ *     out = left + right (kind 0: concatenation, src/Ciphertext.cpp:107-122) or left * right (kind 1: all-pairs AND,
+ *     :146-163), t1 / t2 terms a side, one workgroup per record.
+ * d_ops must be readable by the device: device memory, or pinned host memory through its device alias
+ * (csgn_host_alloc) -- the records are then read over the link, no copy is enqueued.  The operations of ONE call
+ * must not read one another's outputs (split dependent ones over calls: the stream orders them); the record array
+ * must stay untouched until the launch has run.  Meant for small shapes (a workgroup walks its output): use the
+ * uniform / ragged calls for anything large.  Words are those of csgn_add_uniform / csgn_mul_uniform. */
+typedef struct csgn_small_op {
+    const uint64_t *left;
+    const uint64_t *right;
+    uint64_t *out;
+    uint32_t t1, t2;
+    uint32_t kind;           /* 0 add, 1 multiply */
+    uint32_t reserved;
+} csgn_small_op;
+int csgn_small_ops(uint64_t n_bits, uint64_t count, const csgn_small_op *d_ops, void *stream);
 
 /* ------------------------------------------------------------------- decrypt ---- */
 

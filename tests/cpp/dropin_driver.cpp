@@ -865,6 +865,69 @@ static int cmd_graph(int count)
     return 0;
 }
 
+static int cmd_deferred(int rounds)
+{
+    // The deferred queue against the immediate path, word for word: random expression DAGs over fresh ciphertexts
+    // (products and sums of operands that are themselves queued results, copies, reassigned and destroyed operands, more
+    // than one queue-full of operations), evaluated twice -- queued and one launch per operation.
+    Library::initializeLibrary();
+    Context ctx(1247, 16);
+    SecretKey sk(ctx);
+    uint32_t rng = 12345u;
+    auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (int r = 0; r < rounds; ++r) {
+        std::vector<int> bits;
+        std::vector<Ciphertext> fresh;
+        for (int i = 0; i < 6; ++i) {
+            bits.push_back((int)(next() & 1u));
+            Plaintext pt(bits.back());
+            fresh.push_back(sk.encrypt(pt));
+        }
+        const uint32_t seed = rng;
+        std::vector<std::vector<uint64_t> > words[2];
+        std::vector<int> clear[2];
+        for (int mode = 0; mode < 2; ++mode) {
+            Library::deferSmallOperations(mode == 0);
+            rng = seed;
+            std::vector<Ciphertext> pool(fresh);
+            std::vector<int> pbits(bits);
+            const int nops = 40 + (int)(next() % 600u);
+            for (int k = 0; k < nops; ++k) {
+                const size_t ia = next() % pool.size(), ib = next() % pool.size();
+                const bool mul = (next() & 1u) != 0u;
+                const uint64_t dl = ctx.getDefaultN(), ta = pool[ia].getLen() / dl, tb = pool[ib].getLen() / dl;
+                if ((mul ? ta * tb : ta + tb) > 48)
+                    continue;
+                Ciphertext res = mul ? pool[ia] * pool[ib] : pool[ia] + pool[ib];
+                const int bit = mul ? (pbits[ia] & pbits[ib]) : (pbits[ia] ^ pbits[ib]);
+                switch (next() % 4u) {
+                case 0: pool.push_back(res); pbits.push_back(bit); break;                 // a new value
+                case 1: pool[ia] = res; pbits[ia] = bit; break;                            // the operand is reassigned
+                case 2: { Ciphertext copy(res); pool[ib] = copy; pbits[ib] = bit; break; } // through a copy
+                default: break;                                                             // the result dies unread
+                }
+                if (pool.size() > 24) {
+                    pool.erase(pool.begin() + 6);
+                    pbits.erase(pbits.begin() + 6);
+                }
+            }
+            for (size_t i = 0; i < pool.size(); ++i) {
+                const uint64_t *v = pool[i].getValues();
+                words[mode].push_back(std::vector<uint64_t>(v, v + pool[i].getLen()));
+                clear[mode].push_back(pbits[i]);
+                EXPECT(sk.decrypt(pool[i]).getValue() == (unsigned)pbits[i]);
+            }
+        }
+        EXPECT(words[0].size() == words[1].size());
+        for (size_t i = 0; i < words[0].size(); ++i)
+            EXPECT(words[0][i] == words[1][i]);
+        EXPECT(clear[0] == clear[1]);
+    }
+    Library::deferSmallOperations(true);
+    printf("deferred ok rounds=%d\n", rounds);
+    return 0;
+}
+
 static int cmd_latency(int iters)
 {
     // steady-state cost of single operations through the value-semantic class API
@@ -882,9 +945,15 @@ static int cmd_latency(int iters)
     struct Case { const char *name; int kind; } cases[] = {
         {"mul 1x1", 0}, {"add 1+1", 1}, {"decrypt 1 term", 2}, {"encrypt", 3},
         {"mul 128x2", 4}, {"decrypt 128 terms", 5}, {"mul 64x64", 6}};
+    // every case twice: operations on small ciphertexts QUEUED (the default: one launch per 256 of them) and issued one
+    // by one (Library::deferSmallOperations(false)).  The clock stops after the queue has been evaluated and the GPU has
+    // finished: what is timed is work done, not work promised.
+    for (int pass = 0; pass < 2; ++pass)
     for (const Case &c : cases) {
+        Library::deferSmallOperations(pass == 0);
         Timer t(c.name);
         int acc = 0;
+        csgn_stream_sync(nullptr);
         t.start();
         for (int i = 0; i < iters; ++i) {
             switch (c.kind) {
@@ -897,9 +966,12 @@ static int cmd_latency(int iters)
             default: acc += sk.decrypt(big).getValue(); break;
             }
         }
+        Library::flush();
+        csgn_stream_sync(nullptr);
         double ms = t.stop();
-        printf("latency %-18s %8.2f us/op (acc %d)\n", c.name, ms * 1000.0 / iters, acc);
+        printf("latency %-18s %8.2f us/op (acc %d)%s\n", c.name, ms * 1000.0 / iters, acc, pass == 0 ? "" : "  [one launch per operation]");
     }
+    Library::deferSmallOperations(true);
     return 0;
 }
 
@@ -935,6 +1007,8 @@ int main(int argc, char **argv)
             return cmd_graph(argc > 2 ? atoi(argv[2]) : 5);
         if (cmd == "latency")
             return cmd_latency(argc > 2 ? atoi(argv[2]) : 2000);
+        if (cmd == "deferred")
+            return cmd_deferred(argc > 2 ? atoi(argv[2]) : 20);
         return 64;
     } catch (const std::exception &e) {
         fprintf(stderr, "certFHE error: %s\n", e.what());

@@ -61,6 +61,15 @@ def test_dropin_fails_loudly_without_gpu(driver):
 
 
 @pytest.mark.gpu
+def test_deferred_queue_equals_one_launch_per_operation(driver):
+    """Small operator* / operator+ are queued per thread and evaluated together (csgn_small_ops): 20 random expression
+    DAGs -- results feeding results, reassigned and destroyed operands, copies, more than a queue-full of operations --
+    give the words and plaintexts of the same program with one launch per operation."""
+    p = run(driver, "deferred", 20)
+    assert "deferred ok rounds=20" in p.stdout
+
+
+@pytest.mark.gpu
 def test_basic_operations_flow(driver):
     p = run(driver, "basic", 25)
     assert "Dec ( Enc (1) + Enc (0) ) = 1" in p.stdout
