@@ -34,6 +34,21 @@ class HipPath:
         check(self.lib.csgn_init(device))
         self.device = torch.device("cuda", device)
 
+    def close(self) -> None:
+        """Destroys the calling thread's csgn_mul_plan handle (its device block goes back to the driver).  Handles of
+        other threads are destroyed when those threads call close(), or with the process."""
+        plans = getattr(self, "_plans", None)
+        handle = getattr(plans, "handle", None) if plans is not None else None
+        if handle is not None:
+            self.lib.csgn_mul_plan_destroy(handle)
+            plans.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -- plumbing -------------------------------------------------------------------
     @property
     def stream(self) -> int:

@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(127))) k_m
     // The operand touch (touch_terms != 0).  Operands of a batch of small pairs are a quarter of its products and cold.  A
     // line's first load is an HBM round trip, and every other load of that line issued meanwhile -- the next row's block
     // re-reading the right operand, the next block of the row re-reading the left term -- waits for it inside the L1,
-    // whose pipe is in order: the stores of sixteen waves queue behind (the L1 stalled on its pending queue
+    // whose pipe is in order: the stores of sixteen waves queue behind (profiles/r04/NOTES_ragged_kernels.md: the L1 stalled on its pending queue
     // 69 % of the time; the same kernel on operands that sit in the memory-side cache needs half the cycles per block).
     // So a wave that has just loaded an offset window reads ONE dword of every 128-byte line of the operands of the
     // window's pairs that begin inside its stretch -- 64 lines per instruction, every line once, nothing re-read while it

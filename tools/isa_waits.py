@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static scan of the generated gfx950 code of every kernel for loads that are waited for at once (dev tool).
 
-What it looks for is what cost the CSR kernels 2-3 % and the wave-cooperative multiply much more:
+What it looks for is what cost the CSR kernels 2-3 % and the wave-cooperative multiply much more (profiles/r04/NOTES_ragged_kernels.md):
     a global_load followed within three instructions by `s_waitcnt vmcnt(0)` -- a load the compiler sank into the
     branch of its only use, a `cond ? A[i] : B[i]` turned into a branch around two loads, a loop-carried register
     the compiler cannot prove landed.

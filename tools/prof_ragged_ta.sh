@@ -1,6 +1,13 @@
 #!/bin/bash
 # texture-addresser / L1 counters of the ragged multiply on the long-tailed mean-8 batch, ONE counter per pass and a short
 # limit on each (a pass over several TA_* / TCP_* counters once took rocprofv3 down and hung until the outer limit).
+# What is known about that hang (nothing was re-run to provoke it): the pass asked for more TA / TCP counters
+# than one pass can hold -- these blocks have few counter registers per instance and rocprofv3 does not always refuse an
+# over-subscribed set up front; the process under it (41 multiplies, kernels that pass all tests with and without a
+# profiler attached, and that the single-counter passes below profile without incident) never reported a fault, and the
+# box's dmesg is not readable by the pool's user, so a kernel-side cause cannot be ruled in or out from the logs kept.
+# One counter per pass is the guide's prescription anyway (MI355X_MICROARCH.md, HBM / rocprofv3 section); the short
+# `timeout -k` is a belt, not a fix: with one counter per pass no pass has come near it.
 export TMPDIR=/tmp
 OUT=$1; shift
 mkdir -p $OUT
