@@ -240,11 +240,16 @@ Plaintext SecretKey::decrypt(Ciphertext &ciphertext)
     std::shared_ptr<DevicePayload> work = detail::allocBytes(scratch);
     // the answer lands in pinned host memory the kernel writes itself: no device-to-host copy
     void *d_bit = nullptr;
+    const uint64_t *d_terms = ciphertext.deviceValues();          // (evaluates a queued operation: before the slot is armed)
     volatile unsigned char *h_bit = detail::resultSlot(&d_bit);
-    detail::check(csgn_decrypt_uniform(n, 1, terms, ciphertext.deviceValues(), device_mask->data(),
+    *h_bit = 0xFF;                                                // neither 0 nor 1: the kernel's byte replaces it
+    detail::check(csgn_decrypt_uniform(n, 1, terms, d_terms, device_mask->data(),
                                        static_cast<uint8_t *>(d_bit), work->ptr, detail::stream()),
                   "csgn_decrypt_uniform");
-    detail::syncDevice();
+    // The byte arrives in host memory with the end of the last kernel; watching it costs a microsecond or two where
+    // hipStreamSynchronize costs eight (round 5: 12.8 -> x us per one-term decrypt).  A launch that failed or a byte that
+    // does not come falls back to the synchronise, which reports the error.
+    detail::awaitByte(h_bit, 0xFF);
     return Plaintext((int)(*h_bit & 1u));
 }
 

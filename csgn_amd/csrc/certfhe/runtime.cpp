@@ -129,6 +129,18 @@ volatile unsigned char *resultSlot(void **dev_alias)
     return static_cast<volatile unsigned char *>(sl.host);
 }
 
+void awaitByte(volatile unsigned char *slot, unsigned char armed)
+{
+    for (int spin = 0; spin < 200000; ++spin) {
+        if (*slot != armed)
+            return;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    syncDevice();
+}
+
 void check(int rc, const char *what)
 {
     if (rc == CSGN_OK)

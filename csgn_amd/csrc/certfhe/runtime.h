@@ -54,6 +54,9 @@ void uploadStaged(void *dev, size_t bytes, void (*produce)(void *ctx, void *piec
 // Pinned host byte(s) a kernel can write directly (valid after syncDevice()); *dev_alias is the
 // address to hand to the kernel.  One slot per thread and device, reused by every call.
 volatile unsigned char *resultSlot(void **dev_alias);
+// Spins (bounded: ~200 us) until *slot differs from `armed`, then returns; past the bound, or if the byte never comes,
+// synchronises the stream instead (which also surfaces a failed launch).
+void awaitByte(volatile unsigned char *slot, unsigned char armed);
 // Pinned (page-locked) host blocks for LARGE host mirrors (Ciphertext::getValues): a device-to-host copy into pinned
 // memory is one DMA at the link's rate, into pageable memory it is staged through a bounce buffer and a host memcpy
 // (8 GB/s for a 168 MB mirror, a sixth of the link).  Pinning itself is slow (tens of milliseconds for such a block),

@@ -1858,8 +1858,9 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
     lib.csgn_circuit_destroy(c)
 
 
-@pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 7), (129, 3, 33)])
-def test_circuit_with_compaction_bounds_growth(hip, oracle, n, d, batch):
+@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 300, 0), (4096, 32, 7, 0), (129, 3, 33, 0), (1247, 16, 300, 7),
+                                             (129, 3, 33, 15)])
+def test_circuit_with_compaction_bounds_growth(hip, oracle, n, d, batch, flags):
     """csgn_circuit_compact: x <- compact((x + a_k) * (x + a_k)) four times over, then + and Dec, as ONE
     hipGraph.  Uncompacted the chain would square its size every level (2 -> 9 -> 100 -> ... terms); compacted,
     (x + a)^2 = x^2 + a (the cross terms cancel, u & u = u) never grows past the distinct terms.  Every value
@@ -1891,7 +1892,15 @@ def test_circuit_with_compaction_bounds_growth(hip, oracle, n, d, batch):
     bits_y = new(lib.csgn_circuit_decrypt, y, dmask.data_ptr())
     with pytest.raises(Exception):
         new(lib.csgn_circuit_permute, x, dmask.data_ptr())        # no permutation of a ragged value
+    if flags:
+        # COMPILED (round 5): dynamic values under liveness, placement and decrypt fusion -- y = x + a is read by its
+        # decrypt alone and dissolves into Dec(x) ^ Dec(a) unless it is kept; x and y are kept here because the test reads them
+        check(lib.csgn_circuit_optimize(c, flags))
+        check(lib.csgn_circuit_output(c, x))
+        check(lib.csgn_circuit_output(c, y))
     check(lib.csgn_circuit_build(c))
+    if flags:
+        assert lib.csgn_circuit_value(c, stages[0]) is None       # an intermediate the compiler did not have to keep
     assert lib.csgn_circuit_value_terms(c, x) == 0                # ragged; the known sizes are bounds
     for rnd in range(2):
         plain = np.random.default_rng(rnd + batch).integers(0, 2, size=(levels + 2, batch)).astype(np.uint8)
@@ -2066,6 +2075,18 @@ def test_circuit_graph_fused_fresh_chain_node(hip, oracle, n, d, batch):
 
 @pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 40), (65, 4, 1000)])
 def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
+    _ragged_circuit(hip, oracle, n, d, batch, 0, True)
+
+
+@pytest.mark.parametrize("flags,keep", [(7, True), (7, False), (15, False), (3, True)])
+def test_circuit_graph_ragged_values_compiled(hip, oracle, flags, keep):
+    """The same circuit COMPILED: with x and s kept their words and offsets are the tape's; with nothing kept only the
+    bits exist -- Dec(x) = Dec(s) & Dec(a + u) from the materialised s (it has a second reader: its own decrypt) and the
+    sum a + u, or with PUSHDOWN from the leaves."""
+    _ragged_circuit(hip, oracle, 1247, 16, 200, flags, keep)
+
+
+def _ragged_circuit(hip, oracle, n, d, batch, flags, keep):
     """Ragged values in a captured circuit (static per-element shapes): x = (a*b + c) * (a + u) with
     ragged a, b, c (0..5 terms per element, empty ones included) and a uniform u, two decrypts.  Words
     against the one-by-one CSR calls and, per sampled element, the oracle; bits against the oracle."""
@@ -2096,6 +2117,11 @@ def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
     b_x = new(lib.csgn_circuit_decrypt, vx, dmask.data_ptr())
     with pytest.raises(CsgnError):
         new(lib.csgn_circuit_permute, va, dmask.data_ptr())     # ragged permute: refused
+    if flags:
+        check(lib.csgn_circuit_optimize(c, flags))
+        if keep:
+            check(lib.csgn_circuit_output(c, vx))
+            check(lib.csgn_circuit_output(c, vs))
     check(lib.csgn_circuit_build(c))
     assert lib.csgn_circuit_value_terms(c, vx) == 0 and lib.csgn_circuit_value_terms(c, vu) == 2
     tx = (ta * tb + tc) * (ta + 2)
@@ -2119,12 +2145,15 @@ def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
         t = hip.empty_words(max(total * dl, 1))
         check(lib.csgn_memcpy_d2d(t.data_ptr(), lib.csgn_circuit_value(c, v), total * dl * 8, hip.stream))
         return hip.download(t)[:total * dl]
-    gx, gs = grab(vx), grab(vs)
     off = lambda t: np.concatenate([[0], np.cumsum(t)]).astype(np.int64)
     oa, ob, oc, ox, os_ = off(ta), off(tb), off(tc), off(tx), off(ta * tb + tc)
-    got_off = torch.empty(batch + 1, dtype=torch.int64, device=hip.device)
-    check(lib.csgn_memcpy_d2d(got_off.data_ptr(), lib.csgn_circuit_value_offsets(c, vx), (batch + 1) * 8, hip.stream))
-    assert np.array_equal(hip.download(got_off).astype(np.int64), ox)
+    if keep:
+        gx, gs = grab(vx), grab(vs)
+        got_off = torch.empty(batch + 1, dtype=torch.int64, device=hip.device)
+        check(lib.csgn_memcpy_d2d(got_off.data_ptr(), lib.csgn_circuit_value_offsets(c, vx), (batch + 1) * 8, hip.stream))
+        assert np.array_equal(hip.download(got_off).astype(np.int64), ox)
+    else:
+        assert lib.csgn_circuit_value(c, vx) is None and lib.csgn_circuit_value_offsets(c, vx) is None
     bits = {}
     for name, bid in (("s", b_s), ("x", b_x)):
         gb = torch.empty(batch, dtype=torch.uint8, device=hip.device)
@@ -2137,8 +2166,9 @@ def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
         s_i = np.concatenate([ab, c_i])
         au = np.concatenate([a_i, u_i])
         x_i = oracle.mul(n, s_i, au)[0] if s_i.size else np.zeros(0, dtype=np.uint64)
-        assert np.array_equal(gs[os_[i] * dl:os_[i + 1] * dl], s_i), i
-        assert np.array_equal(gx[ox[i] * dl:ox[i + 1] * dl], x_i), i
+        if keep:
+            assert np.array_equal(gs[os_[i] * dl:os_[i + 1] * dl], s_i), i
+            assert np.array_equal(gx[ox[i] * dl:ox[i + 1] * dl], x_i), i
         assert bits["s"][i] == (oracle.decrypt_canonical(n, key, s_i) if s_i.size else 0)
         assert bits["x"][i] == (oracle.decrypt_canonical(n, key, x_i) if x_i.size else 0)
     assert bits["x"].any() or bits["s"].any()
