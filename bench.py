@@ -424,7 +424,7 @@ def secondary_suite(hip, budget_s: float = 25.0):
                          f"one hipGraph launch")
     for nb, dk in ((4096, 32), (N_BITS, D_KEY)):
         case(f"config5_graph_compiled_n{nb}", c5(nb, dk) + "; COMPILED (csgn_circuit_optimize: products written into the sums that "
-             "consume them, last product fused into the decrypt); bytes = the emitted kernels' algorithmic bytes", config5(nb, dk, 7))
+             "consume them, input copies in one prologue launch, last product fused into the decrypt); bytes = the emitted kernels' algorithmic bytes", config5(nb, dk, 23))
 
     def mul_1x1():
         B = 1 << 20

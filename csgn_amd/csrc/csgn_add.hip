@@ -169,6 +169,31 @@ __global__ void __launch_bounds__(256) k_add_flat(const Unit *__restrict__ L,
     }
 }
 
+// A LIST of strided copies in one launch (circuit prologue, csgn_circuit.hip): entry e moves `batch` elements of
+// elem_words words from src + i * src_pitch to dst + i * dst_pitch.  A workgroup takes 256 consecutive units (16 bytes when
+// everything of the entry is 16-byte aligned, else 8) of one entry; first[e] = the entry's first workgroup.
+__global__ void __launch_bounds__(256) k_copy_list(const CopyEntry *__restrict__ entries, const u32 *__restrict__ first, u32 n_entries)
+{
+    u32 e = 0;
+    while (e + 1u < n_entries && first[e + 1u] <= blockIdx.x)      // workgroup-uniform: scalar loads, a few dozen entries at most
+        ++e;
+    const CopyEntry en = entries[e];
+    const u32 local = (blockIdx.x - first[e]) * 256u + threadIdx.x;
+    const bool wide = ((reinterpret_cast<uintptr_t>(en.src) | reinterpret_cast<uintptr_t>(en.dst)) & 15u) == 0u &&
+                      ((en.elem_words | en.src_pitch | en.dst_pitch) & 1u) == 0u;
+    if (wide) {
+        const u32 eu = en.elem_words / 2u;
+        if (local < en.batch * eu) {
+            const u32 i = local / eu, k = local - i * eu;
+            const unit16 v = reinterpret_cast<const unit16 *>(en.src)[(u64)i * (en.src_pitch / 2u) + k];
+            unit_store<unit16, true>(reinterpret_cast<unit16 *>(en.dst) + (u64)i * (en.dst_pitch / 2u) + k, v);
+        }
+    } else if (local < en.batch * en.elem_words) {
+        const u32 i = local / en.elem_words, k = local - i * en.elem_words;
+        en.dst[(u64)i * en.dst_pitch + k] = en.src[(u64)i * en.src_pitch + k];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_off_sum(u64 n, const u64 *__restrict__ a,
                                                  const u64 *__restrict__ b, u64 *__restrict__ o)
 {
@@ -223,6 +248,20 @@ hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, cons
             return e;
     }
     return hipSuccess;
+}
+
+u32 copy_list_blocks(const CopyEntry &e)
+{
+    // (a launcher-side bound that holds for both unit widths: 8-byte units need twice the workgroups of 16-byte ones)
+    return ceil_div_u64((u64)e.batch * e.elem_words, 256u);
+}
+
+hipError_t copy_list(const CopyEntry *d_entries, const u32 *d_first, u32 n_entries, u32 total_blocks, hipStream_t s)
+{
+    if (n_entries == 0 || total_blocks == 0)
+        return hipSuccess;
+    k_copy_list<<<total_blocks, 256, 0, s>>>(d_entries, d_first, n_entries);
+    return hipGetLastError();
 }
 
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,

@@ -17,6 +17,10 @@
 //                     element (a per-element output pitch in k_mul_flat / k_mul_tiled / k_add_flat) -- that operand's half
 //                     of the add disappears; operands that cannot be placed (inputs, shared values) are copied into
 //                     their slice by a strided one-operand copy.
+//       HOIST         copies whose source is a circuit INPUT (an input added to a product, a sum of two inputs) do not depend
+//                     on anything the graph computes: all of them go into ONE strided-copy launch in front of the first
+//                     node (k_copy_list) instead of one small launch each -- config 5 is 16 of its 26 kernels lighter.
+//                     (The sums they write into are live from the start of the run: the block grows a little.)
 //       REUSE         liveness: the graph is a chain of kernel nodes, so a region is free once the last node that reads it
 //                     has been emitted; regions are dealt out of a free list and the block is the PEAK live set, not the
 //                     sum of all values (csgn_circuit_block_bytes).
@@ -74,6 +78,7 @@ struct csgn_circuit {
         // ---- filled by csgn_circuit_build
         bool elided;          // fused into a decrypt, or dead: no kernel
         bool placed_a, placed_b;   // add: that operand was written into the sum's slice by its producer
+        bool hoist_a, hoist_b;     // add: that operand is an input, copied into the slice by the prologue launch
         int expr;             // decrypt: root of its expression (index into exprs), -1 = plain decrypt of a
     };
     // a decrypt's expression: leaves are materialised values, inner nodes AND / XOR of bit vectors
@@ -92,6 +97,8 @@ struct csgn_circuit {
     uint32_t flags = 0;       // CSGN_CIRCUIT_* passes; 0 = tape
     size_t bytes = 0;         // block size
     size_t epoch_offset = 0;  // u64 run counter in the block, bumped by the graph's first node
+    size_t hoist_offset = 0;  // the prologue's copy table in the block: [CopyEntry x n][u32 first workgroup x (n + 1)]
+    uint32_t n_hoist = 0;
     bool has_encrypt = false;
     uint64_t runs = 0;
     uint64_t stats[8] = {0};
@@ -317,6 +324,24 @@ struct Compiler {
         }
     }
 
+    // operands of uniform adds that are circuit inputs: copied by the prologue launch
+    void hoist()
+    {
+        c->n_hoist = 0;
+        for (Op &op : c->ops) {
+            if (op.kind != 0 || op.elided || !c->values[op.out].per.empty())
+                continue;
+            if (!op.placed_a && c->values[op.a].is_input && c->values[op.a].per.empty()) {
+                op.hoist_a = true;
+                c->n_hoist += 1;
+            }
+            if (!op.placed_b && c->values[op.b].is_input && c->values[op.b].per.empty()) {
+                op.hoist_b = true;
+                c->n_hoist += 1;
+            }
+        }
+    }
+
     uint32_t root_of(uint32_t v, uint64_t *off) const
     {
         uint64_t o = 0;
@@ -382,8 +407,9 @@ struct Compiler {
             if (op.kind != 2) {
                 uint64_t off;
                 const uint32_t root = root_of(op.out, &off);
-                from[root] = std::min(from[root], i);
-                from[op.out] = std::min(from[op.out], i);
+                const int when = (op.hoist_a || op.hoist_b) ? -1 : i;     // the prologue writes its slice before node 0
+                from[root] = std::min(from[root], when);
+                from[op.out] = std::min(from[op.out], when);
             }
         }
         for (size_t v = 0; v < c->values.size(); ++v) {
@@ -400,7 +426,7 @@ struct Compiler {
             val.has_region = true;
             Item it = {};
             it.bytes = value_bytes(val);
-            it.from = val.is_input || retained[v] ? -1 : from[v];
+            it.from = val.is_input || retained[v] ? -1 : from[v];      // (-1 as well for a sum the prologue writes into)
             it.to = retained[v] ? kForever : to[v];
             if (val.is_input)
                 it.from = -1;
@@ -442,6 +468,9 @@ struct Compiler {
         }
         if (c->has_encrypt)
             items.push_back(Item{8, -1, kForever, &c->epoch_offset, 0});
+        if (c->n_hoist)
+            items.push_back(Item{(size_t)c->n_hoist * sizeof(csgn::CopyEntry) + ((size_t)c->n_hoist + 1) * 4 + 16, -1, kForever,
+                                 &c->hoist_offset, 0});
 
         Arena arena;
         // whatever outlives the run sits at the bottom and is never handed out again
@@ -494,9 +523,10 @@ struct Compiler {
     void run()
     {
         for (Op &op : c->ops) {
-            op.elided = op.placed_a = op.placed_b = false;
+            op.elided = op.placed_a = op.placed_b = op.hoist_a = op.hoist_b = false;
             op.expr = -1;
         }
+        c->n_hoist = 0;
         for (Value &v : c->values) {
             v.parent = -1;
             v.parent_off = 0;
@@ -512,6 +542,8 @@ struct Compiler {
             drop_dead();
             if (c->flags & CSGN_CIRCUIT_PLACE)
                 place();
+            if (c->flags & CSGN_CIRCUIT_HOIST)
+                hoist();
         }
         layout();
     }
@@ -557,6 +589,7 @@ int csgn_circuit_optimize(csgn_circuit *c, uint32_t flags)
 {
     REQUIRE(c && !c->exec, "null circuit, or the circuit is already built");
     REQUIRE((flags & ~(uint32_t)(CSGN_CIRCUIT_ALL | CSGN_CIRCUIT_PUSHDOWN)) == 0, "unknown optimisation flag");
+    REQUIRE(!(flags & CSGN_CIRCUIT_HOIST) || sizeof(csgn::CopyEntry) == 32, "internal: copy table layout");
     c->flags = flags;
     return CSGN_OK;
 }
@@ -888,10 +921,53 @@ int csgn_circuit_build(csgn_circuit *c)
     }
     const uint64_t dl = csgn_default_len(c->n_bits);
     uint64_t alg = 0, kernels = 0, placed = 0, fused = 0, dropped = 0;
+    // the prologue's copy table (HOIST): every input operand of a uniform add, into its slice of the sum
+    uint32_t hoist_blocks = 0;
+    uint64_t hoist_alg = 0;
+    if (c->n_hoist) {
+        std::vector<csgn::CopyEntry> table;
+        std::vector<u32> first(1, 0u);
+        for (const Op &op : c->ops) {
+            if (op.kind != 0 || op.elided || !(op.hoist_a || op.hoist_b))
+                continue;
+            const Value &va = c->values[op.a], &vb = c->values[op.b], &vo = c->values[op.out];
+            for (int side = 0; side < 2; ++side) {
+                if (!(side ? op.hoist_b : op.hoist_a))
+                    continue;
+                const Value &vs = side ? vb : va;
+                csgn::CopyEntry en;
+                en.src = reinterpret_cast<const u64 *>(base + vs.offset);
+                en.dst = reinterpret_cast<u64 *>(base + vo.offset) + (side ? va.terms * dl : 0);
+                en.elem_words = (u32)(vs.terms * dl);
+                en.src_pitch = (u32)(vs.terms * dl);
+                en.dst_pitch = (u32)vo.pitch;
+                en.batch = (u32)c->batch;
+                table.push_back(en);
+                first.push_back(first.back() + csgn::copy_list_blocks(en));
+                hoist_alg += 2 * c->batch * vs.terms * dl * 8;
+            }
+        }
+        hoist_blocks = first.back();
+        hipError_t eh = hipMemcpy(base + c->hoist_offset, table.data(), table.size() * sizeof(csgn::CopyEntry), hipMemcpyHostToDevice);
+        if (eh == hipSuccess)
+            eh = hipMemcpy(base + c->hoist_offset + table.size() * sizeof(csgn::CopyEntry), first.data(), first.size() * 4,
+                           hipMemcpyHostToDevice);
+        if (eh != hipSuccess || table.size() != c->n_hoist || c->batch >= (1ull << 32)) {
+            (void)hipStreamDestroy(s);
+            return hip_fail(eh != hipSuccess ? eh : hipErrorInvalidValue, "hipMemcpy (circuit prologue table)");
+        }
+    }
     std::vector<char> done(c->exprs.size(), 0);
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess && c->has_encrypt) {
         e = csgn::bump_epoch((u64 *)epoch, s);      // every replay encrypts under (node key, nonce = its own run number)
+        kernels += 1;
+    }
+    if (e == hipSuccess && c->n_hoist) {
+        e = csgn::copy_list(reinterpret_cast<const csgn::CopyEntry *>(base + c->hoist_offset),
+                            reinterpret_cast<const u32 *>(base + c->hoist_offset + (size_t)c->n_hoist * sizeof(csgn::CopyEntry)),
+                            c->n_hoist, hoist_blocks, s);
+        alg += hoist_alg;
         kernels += 1;
     }
     for (size_t i = 0; e == hipSuccess && i < c->ops.size(); ++i) {
@@ -990,14 +1066,15 @@ int csgn_circuit_build(csgn_circuit *c)
             kernels += 1;
             continue;
         }
-        // uniform add: whatever its producer has not already written into the sum is copied into its slice
+        // uniform add: whatever neither its producer nor the prologue has already written into the sum is copied into its slice
         placed += (op.placed_a ? 1u : 0u) + (op.placed_b ? 1u : 0u);
-        if (op.placed_a && op.placed_b)
+        const bool done_a = op.placed_a || op.hoist_a, done_b = op.placed_b || op.hoist_b;
+        if (done_a && done_b)
             continue;
-        if (!op.placed_a && !op.placed_b) {
+        if (!done_a && !done_b) {
             e = csgn::add_uniform(c->n_bits, c->batch, ta, tb, (const u64 *)A, B, O, s, dense ? 0 : vo.pitch);
             alg += 2 * c->batch * (ta + tb) * dl * 8;
-        } else if (op.placed_a) {
+        } else if (done_a) {
             e = csgn::add_uniform(c->n_bits, c->batch, 0, tb, nullptr, B, O + ta * dl, s, vo.pitch);
             alg += 2 * c->batch * tb * dl * 8;
         } else {
@@ -1031,7 +1108,8 @@ int csgn_circuit_build(csgn_circuit *c)
     c->stats[4] = placed;
     c->stats[5] = fused;
     c->stats[6] = dropped;
-    c->stats[7] = regions;
+    (void)regions;
+    c->stats[7] = c->n_hoist;
     return CSGN_OK;
 }
 
@@ -1067,7 +1145,8 @@ int csgn_circuit_plan_json(csgn_circuit *c, char *h_json, size_t cap)
         out += std::string(i ? ", " : "") + "{\"kind\": " + std::to_string(op.kind) + ", \"a\": " + std::to_string(op.a) +
                ", \"b\": " + std::to_string(op.b) + ", \"out\": " + std::to_string(op.out) + ", \"elided\": " +
                (op.elided ? "true" : "false") + ", \"placed_a\": " + (op.placed_a ? "true" : "false") + ", \"placed_b\": " +
-               (op.placed_b ? "true" : "false") + ", \"expr\": " + std::to_string(op.expr) + "}";
+               (op.placed_b ? "true" : "false") + ", \"hoist_a\": " + (op.hoist_a ? "true" : "false") + ", \"hoist_b\": " +
+               (op.hoist_b ? "true" : "false") + ", \"expr\": " + std::to_string(op.expr) + "}";
     }
     out += "], \"exprs\": [";
     for (size_t i = 0; i < c->exprs.size(); ++i) {

@@ -71,6 +71,15 @@ hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL
 hipError_t add_uniform(u64 n_bits, u64 batch, u64 t1, u64 t2, const u64 *L, const u64 *R, u64 *out,
                        hipStream_t s, u64 out_pitch_words = 0);
 // device_end: total_terms_out is only an upper bound (sizes the launch); the real end is read from the offsets
+// a list of strided copies in one launch (the prologue of a compiled circuit: copies whose sources are circuit inputs)
+struct CopyEntry {
+    const u64 *src;
+    u64 *dst;
+    u32 elem_words, src_pitch, dst_pitch, batch;   // words per element, words from element to element, elements
+};
+u32 copy_list_blocks(const CopyEntry &e);              // workgroups entry e needs
+// d_first[e] = first workgroup of entry e (exclusive sums of copy_list_blocks), total_blocks = their sum
+hipError_t copy_list(const CopyEntry *d_entries, const u32 *d_first, u32 n_entries, u32 total_blocks, hipStream_t s);
 // max_t1 / max_t2: upper bounds on one element's terms (0, 0 = unknown); met with equality = a uniform batch
 hipError_t add_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, u64 *offOut, u64 total_terms_out, hipStream_t s,

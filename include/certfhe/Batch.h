@@ -137,7 +137,7 @@ class BatchCircuit {
     // reader is a decrypt is never computed (Dec(a*b) = Dec(a) & Dec(b), Dec(a+b) = Dec(a) ^ Dec(b)), buffers are
     // reused once their last reader has run -- and afterwards value() answers only for inputs and for values named by
     // keep().  Bits and kept values are the same words either way.  passes: CSGN_CIRCUIT_* of csgn_hip.h.
-    void optimize(unsigned passes = 7u /* CSGN_CIRCUIT_ALL */);
+    void optimize(unsigned passes = 23u /* CSGN_CIRCUIT_ALL */);
     void keep(unsigned value);
     uint64_t blockBytes() const;                              // HBM held by the built circuit
     void build();

@@ -507,7 +507,10 @@ int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8]);
  *                              hits over terms): a product or sum whose ONLY consumer is a decrypt is never computed,
  *                              its operands are decrypted and the bits combined -- ONE level;
  *   CSGN_CIRCUIT_PUSHDOWN      the same through every level of single-consumer values (a circuit that only asks for
- *                              bits then decrypts little more than its inputs).
+ *                              bits then decrypts little more than its inputs); not part of CSGN_CIRCUIT_ALL;
+ *   CSGN_CIRCUIT_HOIST         copies whose source is a circuit INPUT (an input added to a product, a sum of two
+ *                              inputs) depend on nothing the graph computes: all of them go into ONE strided-copy
+ *                              launch in front of the first node instead of a small launch each.
  * Nodes whose value nothing reads any more are dropped.  Shared sub-expressions are never fused or placed (a value
  * with two readers is materialised once).  Retained words and all bits are those of the tape, of the one-by-one
  * calls and of the reference.  The graph must be launched on the stream the inputs were written on, or after
@@ -515,15 +518,16 @@ int csgn_circuit_node_key(const csgn_rng *h_rng, uint32_t h_node_key[8]);
 #define CSGN_CIRCUIT_REUSE 1u
 #define CSGN_CIRCUIT_PLACE 2u
 #define CSGN_CIRCUIT_FUSE_DECRYPT 4u
-#define CSGN_CIRCUIT_ALL 7u
 #define CSGN_CIRCUIT_PUSHDOWN 8u
+#define CSGN_CIRCUIT_HOIST 16u
+#define CSGN_CIRCUIT_ALL 23u
 int csgn_circuit_optimize(csgn_circuit *circuit, uint32_t flags);
 int csgn_circuit_output(csgn_circuit *circuit, uint32_t value);                /* keep this value materialised and addressable */
 int csgn_circuit_build(csgn_circuit *circuit);
 uint64_t csgn_circuit_block_bytes(const csgn_circuit *circuit);               /* size of the circuit's HBM block; 0 before build */
 /* After build: {block bytes, algorithmic bytes of one run (reads + writes of every emitted kernel, SURVEY 8d's
  * per-operation figures), nodes described, kernels emitted, add operands placed (copies that disappeared),
- * decrypts fused, nodes dropped, value regions in the block}. */
+ * decrypts fused, nodes dropped, input copies hoisted into the prologue launch}. */
 int csgn_circuit_stats(const csgn_circuit *circuit, uint64_t h_stats[8]);
 /* What csgn_circuit_build would do, without touching a device (host only, before build): a JSON object
  * {"bytes", "values": [{region, addressable, offset, pitch, parent, terms, total}], "ops": [{kind, a, b, out, elided,

@@ -16,7 +16,8 @@ import pytest
 from csgn_amd import capi
 from csgn_amd.capi import check
 
-REUSE, PLACE, FUSE, ALL, PUSHDOWN = 1, 2, 4, 7, 8
+REUSE, PLACE, FUSE, PUSHDOWN, HOIST = 1, 2, 4, 8, 16
+CORE, ALL = 7, 23
 FOREVER = 2 ** 31 - 1
 FAKE_PTR = 0x1000                                   # a device pointer the host passes never read
 
@@ -127,10 +128,22 @@ def execute(d, plan, inputs, mask):
         if node[0] == "in":
             assert plan["values"][v]["addressable"]
             write(v, inputs[v])
-    op_of = {}
-    for i, op in enumerate(plan["ops"]):
-        if op["kind"] in (0, 1):
-            op_of[op["out"]] = i
+    def copy_operand(op, side):
+        """operand `side` of add `op` into its slice of the sum (what the add's own copy, or the prologue launch, does)"""
+        ta = d.terms[op["a"]]
+        out = plan["values"][op["out"]]
+        base, pitch = out["offset"] // 8, out["pitch"]
+        v = op["b"] if side else op["a"]
+        idx = base + (ta * dl if side else 0) + np.arange(B)[:, None] * pitch + np.arange(d.terms[v] * dl)[None, :]
+        block[idx] = read(v).reshape(B, -1)
+
+    # the prologue: every hoisted copy (its source is an input) before the first node
+    for op in plan["ops"]:
+        if op["kind"] == 0 and not op["elided"]:
+            for side, key in ((0, "hoist_a"), (1, "hoist_b")):
+                if op[key]:
+                    assert d.nodes[op["b"] if side else op["a"]][0] == "in" and not op["placed_b" if side else "placed_a"]
+                    copy_operand(op, side)
     bits = {}
     for i, op in enumerate(plan["ops"]):
         if op["elided"]:
@@ -142,17 +155,14 @@ def execute(d, plan, inputs, mask):
             ta = d.terms[op["a"]]
             out = plan["values"][op["out"]]
             base, pitch = out["offset"] // 8, out["pitch"]
-            if not op["placed_a"]:
-                idx = base + np.arange(B)[:, None] * pitch + np.arange(ta * dl)[None, :]
-                block[idx] = read(op["a"]).reshape(B, -1)
-            else:
+            if op["placed_a"]:
                 pa = plan["values"][op["a"]]
                 assert pa["parent"] == op["out"] and pa["offset"] == out["offset"] and pa["pitch"] == pitch
-            if not op["placed_b"]:
-                tb = d.terms[op["b"]]
-                idx = base + ta * dl + np.arange(B)[:, None] * pitch + np.arange(tb * dl)[None, :]
-                block[idx] = read(op["b"]).reshape(B, -1)
-            else:
+            elif not op["hoist_a"]:
+                copy_operand(op, 0)
+            if not op["placed_b"] and not op["hoist_b"]:
+                copy_operand(op, 1)
+            elif op["placed_b"]:
                 pb = plan["values"][op["b"]]
                 assert pb["parent"] == op["out"] and pb["offset"] == out["offset"] + ta * dl * 8 and pb["pitch"] == pitch
         elif op["kind"] == 2:
@@ -201,7 +211,7 @@ def random_circuit(lib, seed, n, batch, mask_ptr=FAKE_PTR, max_terms=400):
     return d
 
 
-@pytest.mark.parametrize("flags", [ALL, REUSE, PLACE, FUSE, PLACE | FUSE, ALL | PUSHDOWN, REUSE | PUSHDOWN])
+@pytest.mark.parametrize("flags", [ALL, CORE, REUSE, PLACE, FUSE, HOIST, REUSE | HOIST, PLACE | FUSE, ALL | PUSHDOWN, REUSE | PUSHDOWN])
 def test_compiled_plans_of_random_circuits_compute_what_the_tape_computes(lib, flags):
     """60 random DAGs per flag set (chains, shared sub-expressions, squares a*a and doubles a+a, values nobody reads,
     several decrypts, random retained outputs): the executed plan's retained words and all bits equal the direct
@@ -242,6 +252,8 @@ def test_compiled_plans_of_random_circuits_compute_what_the_tape_computes(lib, f
                     assert readers[v] == 0, (seed, v)
             if not flags & PLACE:
                 assert all(pv["parent"] < 0 for pv in plan["values"])
+            if not flags & HOIST:
+                assert not any(op["hoist_a"] or op["hoist_b"] for op in plan["ops"])
             if not flags & (FUSE | PUSHDOWN):
                 assert not plan["exprs"]
         finally:
@@ -253,7 +265,7 @@ def test_tape_mode_keeps_every_value_in_a_region_of_its_own(lib):
     try:
         plan = d.plan(0)
         assert all(pv["region"] and pv["addressable"] and pv["parent"] < 0 for pv in plan["values"])
-        assert not any(op["elided"] or op["placed_a"] or op["placed_b"] for op in plan["ops"])
+        assert not any(op["elided"] or op["placed_a"] or op["placed_b"] or op["hoist_a"] or op["hoist_b"] for op in plan["ops"])
         check_regions(plan)
         assert all(r["to"] == FOREVER or r["from"] == r["to"] for r in plan["regions"])
     finally:
@@ -285,7 +297,12 @@ def test_config5_plan_elides_the_last_product_and_every_copy_of_a_product(lib):
         muls = [op for op in comp["ops"] if op["kind"] == 1]
         assert len(muls) == 8 and [m["elided"] for m in muls] == [False] * 7 + [True]
         x_adds = [op for op in comp["ops"] if op["kind"] == 0 and d.nodes[op["a"]][0] == "mul"]
-        assert len(x_adds) == 7 and all(op["placed_a"] and not op["placed_b"] for op in x_adds)
+        assert len(x_adds) == 7 and all(op["placed_a"] and not op["placed_b"] and op["hoist_b"] for op in x_adds)
+        # ... and every copy of an input (the other half of those adds, x0 + e, the eight sums e + e') is in the prologue:
+        # no add launches a kernel of its own any more
+        adds = [op for op in comp["ops"] if op["kind"] == 0 and not op["elided"]]
+        assert all((op["placed_a"] or op["hoist_a"]) and (op["placed_b"] or op["hoist_b"]) for op in adds)
+        assert sum(op["hoist_a"] + op["hoist_b"] for op in adds) == 25          # every one of the 25 inputs, once
         dec = [op for op in comp["ops"] if op["kind"] == 2][0]
         root = comp["exprs"][dec["expr"]]
         assert root["kind"] == 1 and comp["exprs"][root["l"]]["kind"] < 0 and comp["exprs"][root["r"]]["kind"] < 0

@@ -1858,7 +1858,7 @@ def test_circuit_graph_matches_one_by_one_calls_and_oracle(hip, oracle, n, d, ba
     lib.csgn_circuit_destroy(c)
 
 
-@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 300, 0), (4096, 32, 7, 0), (129, 3, 33, 0), (1247, 16, 300, 7),
+@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 300, 0), (4096, 32, 7, 0), (129, 3, 33, 0), (1247, 16, 300, 23),
                                              (129, 3, 33, 15)])
 def test_circuit_with_compaction_bounds_growth(hip, oracle, n, d, batch, flags):
     """csgn_circuit_compact: x <- compact((x + a_k) * (x + a_k)) four times over, then + and Dec, as ONE
@@ -2078,7 +2078,7 @@ def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
     _ragged_circuit(hip, oracle, n, d, batch, 0, True)
 
 
-@pytest.mark.parametrize("flags,keep", [(7, True), (7, False), (15, False), (3, True)])
+@pytest.mark.parametrize("flags,keep", [(23, True), (23, False), (31, False), (3, True)])
 def test_circuit_graph_ragged_values_compiled(hip, oracle, flags, keep):
     """The same circuit COMPILED: with x and s kept their words and offsets are the tape's; with nothing kept only the
     bits exist -- Dec(x) = Dec(s) & Dec(a + u) from the materialised s (it has a second reader: its own decrypt) and the
@@ -2236,13 +2236,13 @@ def test_circuit_graph_config5_with_permutation(hip, oracle, batch):
     lib.csgn_circuit_destroy(c)
 
 
-@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 5, 7), (4096, 32, 3, 7), (130, 3, 70, 7), (1247, 16, 9, 15),
-                                             (1247, 16, 5, 2), (4096, 32, 4, 5)])
+@pytest.mark.parametrize("n,d,batch,flags", [(1247, 16, 5, 23), (4096, 32, 3, 23), (130, 3, 70, 7), (1247, 16, 9, 31),
+                                             (1247, 16, 5, 2), (4096, 32, 4, 5), (130, 3, 11, 17)])
 def test_circuit_compiled_matches_tape_on_random_dags(hip, oracle, n, d, batch, flags):
     """The compiler property on the real kernels: 60 random DAG circuits -- chains, shared
     sub-expressions, a*a and a+a, values nobody reads, several decrypts, random retained outputs -- built twice, as a
-    TAPE and COMPILED (liveness + placement + decrypt fusion; one parameter set with PUSHDOWN, two with single
-    passes).  Every bit vector of the compiled graph equals the tape's and the circuit evaluated in the clear on
+    TAPE and COMPILED (liveness + placement + decrypt fusion + the prologue copy launch; one parameter set with
+    PUSHDOWN, three with some of the passes only).  Every bit vector of the compiled graph equals the tape's and the circuit evaluated in the clear on
     the plaintext bits; every retained value is word-identical to the tape's; values the compiler did not retain
     answer NULL; element 0 of every retained value equals the oracle's mul/add chain; the compiled block is
     never larger than the tape's."""
@@ -2255,7 +2255,7 @@ def test_circuit_compiled_matches_tape_on_random_dags(hip, oracle, n, d, batch, 
     key = make_key(n, d, 31)
     dmask = hip.upload(hip.key_mask(n, key))
     dkey = hip.upload(key)
-    placed = fused = 0
+    placed = fused = hoisted = 0
     for seed in range(60):
         tape = random_circuit(lib, 3000 + seed, n, batch, dmask.data_ptr(), max_terms=300)
         comp = random_circuit(lib, 3000 + seed, n, batch, dmask.data_ptr(), max_terms=300)
@@ -2268,6 +2268,7 @@ def test_circuit_compiled_matches_tape_on_random_dags(hip, oracle, n, d, batch, 
             check(lib.csgn_circuit_stats(comp.c, stats))
             placed += stats[4]
             fused += stats[5]
+            hoisted += stats[7]
             ins = [v for v, nd in enumerate(tape.nodes) if nd[0] == "in"]
             nterms = sum(tape.terms[v] for v in ins)
             plain = np.random.default_rng(seed).integers(0, 2, size=(nterms, batch)).astype(np.uint8)
@@ -2337,6 +2338,8 @@ def test_circuit_compiled_matches_tape_on_random_dags(hip, oracle, n, d, batch, 
         assert placed > 20
     if flags & 12:
         assert fused > 20
+    if flags & 16:
+        assert hoisted > 20
 
 
 @pytest.mark.parametrize("n,d,batch", [(4096, 32, 64), (1247, 16, 300), (1247, 16, 1)])
@@ -2358,14 +2361,15 @@ def test_circuit_compiled_config5(hip, oracle, n, d, batch):
     kept, _ = config5(lib, n, batch, mask_ptr=dmask.data_ptr())
     ins = [v for v, nd in enumerate(tape.nodes) if nd[0] == "in"]
     try:
-        check(lib.csgn_circuit_optimize(comp.c, 7))
-        check(lib.csgn_circuit_optimize(kept.c, 7))
+        check(lib.csgn_circuit_optimize(comp.c, 23))
+        check(lib.csgn_circuit_optimize(kept.c, 23))
         kept.output(x)
         for c in (tape, comp, kept):
             check(lib.csgn_circuit_build(c.c))
         st = (C.c_uint64 * 8)()
         check(lib.csgn_circuit_stats(comp.c, st))
         assert st[4] == 7 and st[5] == 1 and st[6] == 1                   # placed, fused, dropped (the last product)
+        assert st[7] == 25 and st[3] == 11     # all 25 input copies in the prologue: 7 products + 1 copy launch + 2 decrypts + 1 combine
         st_t = (C.c_uint64 * 8)()
         check(lib.csgn_circuit_stats(tape.c, st_t))
         assert st[1] * 2 < st_t[1] and st[0] * 2 < st_t[0]                # algorithmic bytes and block: less than half

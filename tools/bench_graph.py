@@ -76,8 +76,8 @@ for n, d, levels in [(4096, 32, 16), (1247, 16, 16)]:
         xe, be = eager()
         te = timed(eager)
         line = {"n": n, "d": d, "depth": levels, "batch": B, "one_by_one_us": round(te, 1)}
-        for name, flags, keep in (("tape", 0, False), ("compiled", 7, False), ("compiled_keep_x", 7, True),
-                                  ("pushdown", 15, False)):
+        for name, flags, keep in (("tape", 0, False), ("compiled", 23, False), ("compiled_keep_x", 23, True),
+                                  ("pushdown", 31, False)):
             c, ids, x, bid, st = describe(n, B, levels, dmask, flags, keep)
             for i in range(nin):
                 check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, ids[i]), inp(i).data_ptr(), B * dl * 8, hip.stream))
@@ -94,7 +94,7 @@ for n, d, levels in [(4096, 32, 16), (1247, 16, 16)]:
             t = timed(lambda: check(lib.csgn_circuit_run(c, hip.stream)))
             line[name] = {"us": round(t, 1), "alg_bytes": st[1], "TBps": round(st[1] / t / 1e6, 3),
                           "frac": round(st[1] / (t * 1e-6) / PEAK, 4), "block_bytes": st[0], "kernels": st[3],
-                          "placed": st[4], "fused": st[5], "dropped": st[6], "identical": bool(same)}
+                          "placed": st[4], "fused": st[5], "dropped": st[6], "hoisted": st[7], "identical": bool(same)}
             lib.csgn_circuit_destroy(c)
         results.append(line)
         f = lambda k: f"{line[k]['us']:8.1f} us {line[k]['alg_bytes'] / 1e6:9.2f} MB {100 * line[k]['frac']:5.1f}%"
