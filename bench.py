@@ -541,6 +541,45 @@ def secondary_suite(hip, budget_s: float = 25.0):
             case(f"mul_ragged_mean{mean}_async", wl + ": csgn_mul_ragged_async (device-side plan + multiply, no host round trip)",
                  lambda: (alg, secs, ok))
 
+    def ragged_singles(kind, bounded):
+        """1 M single-term ciphertexts handed over as CSR: the ragged add (1 + 1 terms) / decrypt entry points, with and
+        without the caller's bounds (csgn_*_ragged_bounded: bounds met with equality run the uniform kernels)"""
+        def body():
+            B = 1 << 20
+            off = hip.upload(np.arange(B + 1, dtype=np.uint64))
+            if kind == "add":
+                sets, nxt = rotate(lambda k: (hip.synth_fill(71 + 2 * k, n, 0, B * dl), hip.synth_fill(72 + 2 * k, n, 0, B * dl)), 2 * B * dl * 8)
+                out, off_out = hip.empty_words(2 * B * dl), hip.empty_words(B + 1)
+                mx = 1 if bounded else 0
+                def run():
+                    l, r = nxt()
+                    check(lib.csgn_add_ragged_bounded(n, B, mx, mx, l.data_ptr(), off.data_ptr(), r.data_ptr(), off.data_ptr(),
+                                                      out.data_ptr(), off_out.data_ptr(), 2 * B, hip.stream))
+                secs = timed(run)
+                l, r = sets[0]
+                check(lib.csgn_add_ragged_bounded(n, B, mx, mx, l.data_ptr(), off.data_ptr(), r.data_ptr(), off.data_ptr(),
+                                                  out.data_ptr(), off_out.data_ptr(), 2 * B, hip.stream))
+                oo = hip.download(off_out)
+                ok = np.array_equal(oo, 2 * np.arange(B + 1, dtype=np.uint64))
+                ok = ok and all(np.array_equal(el(out, i, 2 * dl), orc.add(el(l, i, dl), el(r, i, dl))[0]) for i in (0, 4242, B - 1))
+                return 2 * 8 * dl * 2 * B, secs, ok
+            sets, nxt = rotate(lambda k: hip.synth_fill(81 + k, n, 0, B * dl), B * dl * 8)
+            bits = torch.empty(B, dtype=torch.uint8, device=hip.device)
+            scratch = torch.empty(int(lib.csgn_decrypt_scratch_bytes(B, B)), dtype=torch.uint8, device=hip.device)
+            run = lambda: check(lib.csgn_decrypt_ragged_bounded(n, B, B, 1 if bounded else 0, nxt().data_ptr(), off.data_ptr(),
+                                                                dmask2.data_ptr(), bits.data_ptr(), scratch.data_ptr(), hip.stream))
+            secs = timed(run)
+            check(lib.csgn_decrypt_ragged_bounded(n, B, B, 1 if bounded else 0, sets[0].data_ptr(), off.data_ptr(), dmask2.data_ptr(),
+                                                  bits.data_ptr(), scratch.data_ptr(), hip.stream))
+            got = hip.download(bits)
+            ok = all(int(got[i]) == orc.decrypt_canonical(n, key2, el(sets[0], i, dl)) for i in (0, 1, 77777, B - 1)) and 0 < got.sum() < B
+            return B * 8 * dl, secs, ok
+        return body
+    for kind, what in (("add", "Ciphertext+Ciphertext, 2^20 sums of 1 + 1 terms given as CSR"), ("decrypt", "SecretKey::decrypt of 2^20 single-term ciphertexts given as CSR")):
+        case(f"{kind}_ragged_singles", f"{what}, N={n}: csgn_{kind}_ragged (shapes unknown to the dispatch: the CSR kernels)", ragged_singles(kind, False))
+        case(f"{kind}_ragged_singles_bounded", f"{what}, N={n}: csgn_{kind}_ragged_bounded with the caller's bound (met with equality: the uniform kernels)",
+             ragged_singles(kind, True))
+
     def compact(frac):
         def body():
             B, T = 4096, 1024

@@ -70,12 +70,14 @@ def test_bench_contract_line_on_the_gpu():
     for name in ("config5_graph_compiled_n4096", "config5_graph_compiled_n1247", "config5_graph_tape_n4096",
                  "config5_graph_tape_n1247", "mul_1x1", "add_1024", "decrypt_1024", "permute_1m", "encrypt_keyed_1m",
                  "mul_ragged_mean8_kernel", "mul_ragged_mean8_async", "mul_ragged_mean16_kernel", "mul_ragged_mean16_async",
-                 "compact_0pct", "compact_50pct"):
+                 "compact_0pct", "compact_50pct", "add_ragged_singles", "add_ragged_singles_bounded", "decrypt_ragged_singles",
+                 "decrypt_ragged_singles_bounded"):
         assert name in sec, name
         row = sec[name]
         assert "error" not in row and "skipped" not in row, row
         assert row["verified"] is True and row["ms"] > 0 and row["bytes"] > 0, row
         assert abs(row["frac"] - row["bytes"] / (row["ms"] / 1e3) / 8.0e12) < 1e-9 and row["frac"] < 1.0, row
+    assert sec["add_ragged_singles_bounded"]["ms"] < sec["add_ragged_singles"]["ms"]
     # the compiled config-5 graph moves about a third of the tape's bytes and takes less than two thirds of its time
     assert sec["config5_graph_compiled_n4096"]["bytes"] * 2 < sec["config5_graph_tape_n4096"]["bytes"]
     assert sec["config5_graph_compiled_n4096"]["ms"] * 1.5 < sec["config5_graph_tape_n4096"]["ms"]

@@ -2483,6 +2483,46 @@ def test_mul_ragged_async_offsets_that_do_not_start_at_zero(hip, oracle, capacit
             assert np.array_equal(out[int(oo[b]) * dl:int(oo[b + 1]) * dl], want), b
 
 
+@pytest.mark.parametrize("n,d", [(1247, 2), (4096, 3), (130, 2)])
+def test_decrypt_batches_of_every_kind_on_scratch_that_holds_garbage(hip, oracle, n, d):
+    """Ragged batches with empty, short and long (> 4096 terms: queued for the chunk kernel) ciphertexts and uniform
+    batches of 1 to 700 terms, on a scratch block pre-filled with random bytes and used three times over: the same bits
+    every time, the oracle's on sampled ciphertexts.  (Written for round 5's attempt to fold the parity pass into the
+    hit-bit launch -- tail workgroups waiting on counters in the scratch block; DESIGN section 8 has why it was not kept.)"""
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    dl = oracle.default_len(n)
+    key = make_key(n, d, 13)
+    dmask = hip.upload(hip.key_mask(n, key))
+    rng = np.random.default_rng(n)
+    cases = [("ragged", rng.integers(0, 12, size=5000)),
+             ("ragged", np.concatenate([rng.integers(0, 4, size=700), [5000, 0, 4097, 4096, 1], rng.integers(0, 40, size=300)])),
+             ("uniform", np.full(3000, 1)), ("uniform", np.full(777, 5)), ("uniform", np.full(9, 700)), ("ragged", np.zeros(40, dtype=np.int64))]
+    for kind, counts in cases:
+        counts = np.asarray(counts, dtype=np.int64)
+        batch, total = counts.size, int(counts.sum())
+        off_h = csr(counts.tolist())
+        W = hip.synth_fill(90 + batch, n, 0, max(total, 1) * dl)
+        off = hip.upload(off_h)
+        nbytes = int(lib.csgn_decrypt_scratch_bytes(batch, total))
+        scratch = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device=hip.device)
+        res = []
+        for _ in range(3):
+            bits = torch.full((batch,), 7, dtype=torch.uint8, device=hip.device)
+            if kind == "uniform":
+                check(lib.csgn_decrypt_uniform(n, batch, int(counts[0]), W.data_ptr(), dmask.data_ptr(), bits.data_ptr(), scratch.data_ptr(), hip.stream))
+            else:
+                check(lib.csgn_decrypt_ragged(n, batch, total, W.data_ptr(), off.data_ptr(), dmask.data_ptr(), bits.data_ptr(), scratch.data_ptr(), hip.stream))
+            res.append(hip.download(bits))
+        assert all(np.array_equal(r, res[0]) for r in res), (kind, batch)
+        assert res[0].max() <= 1
+        h = hip.download(W)
+        for b in list(range(0, batch, max(1, batch // 25))) + [batch - 1]:
+            v = h[int(off_h[b]) * dl:int(off_h[b + 1]) * dl]
+            assert res[0][b] == (oracle.decrypt_canonical(n, key, v) if v.size else 0), (kind, b)
+
+
 def test_add_ragged_with_bounds_on_the_term_counts(hip, oracle):
     """csgn_add_ragged_bounded: bounds met with equality send a CSR batch to the uniform kernel (50 000 sums of 1 + 1
     terms, 700 of 3 + 2) -- words and offsets equal csgn_add_ragged's and the oracle's; loose bounds change nothing; bounds
