@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "certFHE.h"
+#include <thread>
 #include "csgn_hip.h"      // wirebench only: csgn_stream_sync
 
 using namespace certFHE;
@@ -928,6 +929,49 @@ static int cmd_deferred(int rounds)
     return 0;
 }
 
+static int cmd_deferred_threads(int rounds)
+{
+    // The deferred queue across host threads: a ciphertext whose producing operation is still queued in thread A's queue is
+    // handed to thread B, which uses it as an operand (B evaluates A's queue under A's lock, on A's device) while A keeps
+    // queueing; both threads' results against the same operations done one launch at a time.
+    Library::initializeLibrary();
+    Context ctx(1247, 16);
+    SecretKey sk(ctx);
+    for (int r = 0; r < rounds; ++r) {
+        Plaintext p1(1), p0(r & 1);
+        Ciphertext a = sk.encrypt(p1), b = sk.encrypt(p0), c = sk.encrypt(p1);
+        Library::deferSmallOperations(false);
+        Ciphertext want_ab = a * b, want_x = (a * b) + c, want_y = ((a * b) + c) * (a * b), want_z = (a + c) * b;
+        Library::deferSmallOperations(true);
+        Ciphertext ab = a * b;                                    // queued here, in the main thread's queue
+        Ciphertext x, y;
+        std::thread other([&] {
+            x = ab + c;                                           // operand pending in ANOTHER thread's queue
+            y = x * ab;
+            volatile uint64_t w = y.getValues()[0];               // evaluates this thread's queue
+            (void)w;
+        });
+        Ciphertext z = (a + c) * b;                               // meanwhile the main thread keeps queueing
+        other.join();
+        auto same = [](const Ciphertext &u, const Ciphertext &v) {
+            if (u.getLen() != v.getLen())
+                return false;
+            const uint64_t *p = u.getValues(), *q = v.getValues();
+            for (uint64_t i = 0; i < u.getLen(); ++i)
+                if (p[i] != q[i])
+                    return false;
+            return true;
+        };
+        EXPECT(same(ab, want_ab));
+        EXPECT(same(x, want_x));
+        EXPECT(same(y, want_y));
+        EXPECT(same(z, want_z));
+        EXPECT(sk.decrypt(y).getValue() == (unsigned)((((1 & (r & 1)) ^ 1) & (1 & (r & 1)))));
+    }
+    printf("deferred threads ok rounds=%d\n", rounds);
+    return 0;
+}
+
 static int cmd_latency(int iters)
 {
     // steady-state cost of single operations through the value-semantic class API
@@ -1009,6 +1053,8 @@ int main(int argc, char **argv)
             return cmd_latency(argc > 2 ? atoi(argv[2]) : 2000);
         if (cmd == "deferred")
             return cmd_deferred(argc > 2 ? atoi(argv[2]) : 20);
+        if (cmd == "deferred_threads")
+            return cmd_deferred_threads(argc > 2 ? atoi(argv[2]) : 50);
         return 64;
     } catch (const std::exception &e) {
         fprintf(stderr, "certFHE error: %s\n", e.what());

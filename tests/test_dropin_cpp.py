@@ -32,7 +32,7 @@ def driver():
         subprocess.check_call(
             ["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include", "certfhe"),
              "-I" + os.path.join(ROOT, "include"), "-o", DRIVER, DRIVER_SRC,
-             "-L" + LIBDIR, "-lcertFHE", "-lcsgn_hip", "-Wl,-rpath," + LIBDIR])
+             "-L" + LIBDIR, "-lcertFHE", "-lcsgn_hip", "-lpthread", "-Wl,-rpath," + LIBDIR])
     return DRIVER
 
 
@@ -67,6 +67,9 @@ def test_deferred_queue_equals_one_launch_per_operation(driver):
     give the words and plaintexts of the same program with one launch per operation."""
     p = run(driver, "deferred", 20)
     assert "deferred ok rounds=20" in p.stdout
+    # ... and a ciphertext whose operation is still queued in one host thread used as an operand in another
+    p = run(driver, "deferred_threads", 50)
+    assert "deferred threads ok rounds=50" in p.stdout
 
 
 @pytest.mark.gpu
