@@ -2073,6 +2073,64 @@ def test_circuit_graph_fused_fresh_chain_node(hip, oracle, n, d, batch):
     lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("flags", [0, 23, 31])
+def test_circuit_compiled_with_encrypt_nodes(hip, oracle, flags):
+    """Encrypt nodes under the compiler: e1 = Enc(a), e2 = Enc(b) generated inside the graph, Dec(e1 + e2), Dec(e1 * e2)
+    and a fused Enc*Enc node that is kept for its bits only (its value has no reader: it must still have somewhere to be
+    written).  Tape and compiled give a ^ b, a & b, a & b on three runs with new plaintexts; in the compiled graph the sum
+    and the product are never computed (both decrypts fused) and the fused node's value is not addressable."""
+    import ctypes as C
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    n, d, batch = 1247, 16, 500
+    key = make_key(n, d, 43)
+    dmask, dkey = hip.upload(hip.key_mask(n, key)), hip.upload(key)
+    r1, r2, r3, r4 = (hip.rng_from_seed(500 + i, 8) for i in range(4))
+    pa = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    pb = torch.zeros(batch, dtype=torch.uint8, device=hip.device)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    e1 = new(lib.csgn_circuit_encrypt, d, pa.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(r1), 0)
+    e2 = new(lib.csgn_circuit_encrypt, d, pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(r2), batch)
+    vf, bf = C.c_uint32(), C.c_uint32()
+    check(lib.csgn_circuit_encrypt_mul(c, d, pa.data_ptr(), pb.data_ptr(), dkey.data_ptr(), dmask.data_ptr(), C.byref(r3),
+                                       C.byref(r4), 2 * batch, C.byref(vf), C.byref(bf)))
+    vs = new(lib.csgn_circuit_add, e1, e2)
+    vp = new(lib.csgn_circuit_mul, e1, e2)
+    b_s = new(lib.csgn_circuit_decrypt, vs, dmask.data_ptr())
+    b_p = new(lib.csgn_circuit_decrypt, vp, dmask.data_ptr())
+    if flags:
+        check(lib.csgn_circuit_optimize(c, flags))
+    check(lib.csgn_circuit_build(c))
+    try:
+        if flags:
+            st = (C.c_uint64 * 8)()
+            check(lib.csgn_circuit_stats(c, st))
+            assert st[5] == 2 and st[6] == 2                         # two decrypts fused, sum and product dropped
+            assert lib.csgn_circuit_value(c, vf.value) is None and lib.csgn_circuit_value(c, vs) is None
+        for run in range(3):
+            ha = np.random.default_rng(run).integers(0, 2, batch).astype(np.uint8)
+            hb = np.random.default_rng(50 + run).integers(0, 2, batch).astype(np.uint8)
+            pa.copy_(torch.from_numpy(ha))
+            pb.copy_(torch.from_numpy(hb))
+            check(lib.csgn_circuit_run(c, hip.stream))
+            got = {}
+            for name, bid in (("sum", b_s), ("product", b_p), ("fused", bf.value)):
+                gb = torch.empty(batch, dtype=torch.uint8, device=hip.device)
+                check(lib.csgn_memcpy_d2d(gb.data_ptr(), lib.csgn_circuit_bits(c, bid), batch, hip.stream))
+                got[name] = hip.download(gb)
+            assert np.array_equal(got["sum"], ha ^ hb), run
+            assert np.array_equal(got["product"], ha & hb), run
+            assert np.array_equal(got["fused"], ha & hb), run
+    finally:
+        lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 40), (65, 4, 1000)])
 def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
     _ragged_circuit(hip, oracle, n, d, batch, 0, True)
