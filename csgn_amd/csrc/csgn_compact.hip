@@ -27,9 +27,15 @@
 //      already running);
 //   6. the registers are stored to their final place (16-byte stores, U lanes per term).
 // Ciphertexts of more than capT terms ("large") cannot be deduplicated inside one workgroup: their
-// terms are hashed chunk by chunk into an HBM table first (k_cl_*: the same protocol with global
-// atomics), and the main kernel then moves their chunks exactly like a group, reading the keep
-// decision from that table instead of making it.  Their terms are read twice.
+// terms are hashed first (k_cl_hash: the first read) and every {hash, index} pair is dealt by the top
+// bits of the hash to one of T/1024 PARTITIONS of its ciphertext (one atomic on the partition's cursor,
+// one 12-byte scatter -- no read-modify-write of a table in HBM); a partition fits LDS and is
+// deduplicated there like a group (k_cl_scatter, k_cl_dedup), leaving one keep byte per term; k_cl_verify compares
+// the terms that joined a class with their representatives.  The main kernel then moves the chunks of
+// a large ciphertext exactly like a group, reading the keep bytes instead of making the decision:
+// their terms are read twice.  A partition that overflows (one term repeated thousands of times) or a
+// hash collision between unequal terms sends the call to the exact path: an open-addressing table in
+// HBM with full compares inside the probe loop (k_cl_clear, k_cl_insert).
 #include "csgn_device.h"
 
 namespace csgn {
@@ -45,7 +51,29 @@ constexpr u32 kCapUnits = kCT * kCR, kCapUnitsWide = kCT * kCRWide;
 constexpr u32 kMaxGroupTerms = 1024, kMaxGroupTermsWide = 1792;     // LDS: 24 B per term + the hash strips, under 64 KiB
 
 // control words (u64 each) at the head of the scratch block; zeroed, with the status granules, per call
-enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlWords = 32 };
+// (kCtrlCollision: a partition overflowed or unequal terms shared a hash -- the exact path decides the large ciphertexts)
+enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlParts = 4, kCtrlJoined = 5, kCtrlStripes = 6, kCtrlWords = 32 };
+
+// Partitions of a large ciphertext of T terms: P = 2^lp >= T / 1024 of them, picked by the top lp bits of a term's hash,
+// each with room for cap = 2T / P <= 2048 {hash, index} pairs (twice the mean; P <= 2 cannot overflow at all).
+constexpr u32 kPartTerms = 1024, kPartCap = 2048;
+constexpr u32 kStripeTerms = 8192, kStripeMaxLp = 11;       // k_cl_scatter
+struct PartGeom {
+    u32 lp, cap;
+};
+__host__ __device__ inline PartGeom part_geom(u64 T)
+{
+    PartGeom g;
+    g.lp = 0;
+    while (((u64)kPartTerms << g.lp) < T)
+        ++g.lp;
+    const u64 cap = (2 * T) >> g.lp;
+    g.cap = (u32)(cap < kPartCap ? cap : kPartCap);
+    return g;
+}
+// Cursor of partition q of a ciphertext, in the head of the ciphertext's share of `slot_of`: a 128-byte line each
+// where the share has the room (atomics on one line queue behind one another)
+__host__ __device__ inline u32 cursor_stride(u64 c_terms, u32 lp) { return ((u64)32 << lp) <= c_terms ? 32u : 1u; }
 
 struct Geom {
     u32 U;          // units per term
@@ -72,8 +100,9 @@ u64 group_bound(u64 total_terms, const Geom &g) { return 4 + 10 * (total_terms /
 struct GroupDesc;
 struct Layout {
     GroupDesc *groups;
-    u64 *ctrl, *status, *chunks, *partial, *hash, *tab;
+    u64 *ctrl, *status, *chunks, *partial, *hash, *tab, *plist, *slist, *joined;
     u32 *gpos, *par, *slot_of;
+    unsigned char *keepb;
     size_t bytes, head_bytes;
 };
 
@@ -100,6 +129,10 @@ Layout make_layout(void *scratch, u64 batch, u64 total_terms, const Geom &g)
     l.tab = reinterpret_cast<u64 *>(take(total_terms * 16));
     l.par = reinterpret_cast<u32 *>(take(total_terms * 8));
     l.slot_of = reinterpret_cast<u32 *>(take(total_terms * 4));
+    l.plist = reinterpret_cast<u64 *>(take((ng + total_terms / (kPartTerms / 2) + 1) * 8));
+    l.slist = reinterpret_cast<u64 *>(take((ng + total_terms / kStripeTerms + 1) * 8));
+    l.joined = reinterpret_cast<u64 *>(take(total_terms * 8));
+    l.keepb = reinterpret_cast<unsigned char *>(take(total_terms));
     l.bytes = (p - p0) + 256;
     return l;
 }
@@ -232,7 +265,7 @@ __global__ void __launch_bounds__(256) k_cg_count(u32 batch, const u64 *__restri
     }
     if (c < batch)
         gpos[c] = base + incl - n;                    // block-local; k_cg_fill adds the block's base
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && blockIdx.x < (batch + 255u) / 256u)   // (blocks past the batch only clear)
         partial[blockIdx.x] = tot;
 }
 
@@ -274,17 +307,23 @@ struct GroupDesc {
 };
 
 // The thread of a group's FIRST ciphertext writes {tb, c0, chunk, large}, the thread of its LAST one
-// {te, c1} (the same thread for a group of one); the chunks of large ciphertexts are listed a second
-// time (any order) for the k_cl_* kernels.
+// {te, c1} (the same thread for a group of one).  The chunks of a LARGE ciphertext are written by the whole
+// block together (a ciphertext of 2^20 terms has a thousand of them), listed a second time (any order) for
+// k_cl_hash, and its partitions are listed for k_cl_dedup with their cursors zeroed.
 __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restrict__ off, Geom g,
                                                  const u32 *__restrict__ gpos, const u64 *__restrict__ partial,
                                                  GroupDesc *__restrict__ groups, u64 *__restrict__ chunks,
+                                                 u64 *__restrict__ plist, u64 *__restrict__ slist, u32 *__restrict__ cursor,
                                                  u64 *__restrict__ ctrl, u32 scanned)
 {
     // the block's base: `partial` already scanned by k_cg_scan (scanned != 0), or -- up to 1024 blocks --
     // summed here, which saves the scan kernel's launch; block 0 then also leaves the total for the main kernel
     __shared__ u64 s_base, s_part[4];
+    __shared__ u32 s_nlarge, s_lc[256];
+    __shared__ u64 s_lbefore[256], s_at[3];
     u64 block_base = 0;
+    if (threadIdx.x == 0)
+        s_nlarge = 0u;
     if (scanned) {
         block_base = partial[blockIdx.x];
     } else {
@@ -310,28 +349,53 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
         __syncthreads();
         block_base = s_base;
     }
+    __syncthreads();                                              // (s_nlarge is zero for everybody)
     const u32 c = blockIdx.x * 256u + threadIdx.x;
-    if (c >= batch)
-        return;
-    bool large, next_large;
-    const u32 n = group_count(off, c, g, large);
-    const u64 before = block_base + gpos[c];                      // groups started before c
-    const u64 o0 = off[c], o1 = off[c + 1];
+    bool large = false, next_large;
+    const u32 n = c < batch ? group_count(off, c, g, large) : 0u;
+    const u64 before = c < batch ? block_base + gpos[c] : 0ull;   // groups started before c
     if (large) {
-        const u64 at = atomicAdd(ull(ctrl + kCtrlChunks), (unsigned long long)n);
-        for (u32 i = 0; i < n; ++i) {
+        const u32 slot = atomicAdd(&s_nlarge, 1u);
+        s_lc[slot] = c;
+        s_lbefore[slot] = before;
+    }
+    __syncthreads();
+    const u32 nlarge = s_nlarge;
+    for (u32 li = 0; li < nlarge; ++li) {
+        const u32 lc = s_lc[li];
+        const u64 o0 = off[lc], o1 = off[lc + 1], first = s_lbefore[li];
+        const u32 nch = (u32)((o1 - o0 + g.capT - 1) / g.capT);
+        const PartGeom pg = part_geom(o1 - o0);
+        const u32 nst = (u32)((o1 - o0 + kStripeTerms - 1) / kStripeTerms);
+        if (threadIdx.x < 3u) {                                   // (three lanes: the round trips overlap)
+            const u32 word = threadIdx.x == 0 ? kCtrlChunks : threadIdx.x == 1 ? kCtrlParts : kCtrlStripes;
+            const u32 want = threadIdx.x == 0 ? nch : threadIdx.x == 1 ? (1u << pg.lp) : nst;
+            s_at[threadIdx.x] = atomicAdd(ull(ctrl + word), (unsigned long long)want);
+        }
+        __syncthreads();
+        const u64 at = s_at[0], pat = s_at[1], sat = s_at[2];
+        for (u32 i = threadIdx.x; i < nch; i += 256u) {
             GroupDesc d;
             d.tb = o0 + (u64)i * g.capT;
             d.te = min(d.tb + g.capT, o1);
-            d.c0 = c;
-            d.c1 = c + 1u;
+            d.c0 = lc;
+            d.c1 = lc + 1u;
             d.chunk = i;
             d.large = 1u;
-            groups[before + i] = d;
-            chunks[at + i] = (u64)c | ((u64)i << 32);
+            groups[first + i] = d;
+            chunks[at + i] = (u64)lc | ((u64)i << 32);
         }
-        return;
+        for (u32 j = threadIdx.x; j < nst; j += 256u)
+            slist[sat + j] = (u64)lc | ((u64)j << 32);
+        for (u32 q = threadIdx.x; q < (1u << pg.lp); q += 256u) {
+            plist[pat + q] = (u64)lc | ((u64)q << 32);
+            cursor[o0 + (u64)q * cursor_stride(o1 - o0, pg.lp)] = 0u;
+        }
+        __syncthreads();
     }
+    if (c >= batch || large)
+        return;
+    const u64 o0 = off[c], o1 = off[c + 1];
     const u64 gid = n ? before : before - 1u;                     // the run c belongs to
     if (n) {
         groups[gid].tb = o0;
@@ -354,7 +418,8 @@ struct CompactArgs {
     u64 *ctrl;
     u64 *status;
     const GroupDesc *groups;
-    const u64 *tab;          // HBM table of the large ciphertexts (k_cl_*), two slots per term
+    const unsigned char *keepb;   // large ciphertexts: one keep byte per term (k_cl_dedup) ...
+    const u64 *tab;          // ... or, on the exact path (kCtrlCollision), the open-addressing table, two slots per term
     const u32 *par;
     const u32 *slot_of;
     u64 tag_mask;            // all ones; a test narrows it to force tag collisions
@@ -410,6 +475,7 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
     Unit *__restrict__ out = static_cast<Unit *>(a.out);
     u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const u32 ngroups = (u32)a.ctrl[kCtrlGroups];
+    const bool exact_large = a.ctrl[kCtrlCollision] != 0ull;      // who decided the large ciphertexts
     UnitWalk walk;                                                // from one register row to the next: 64 units on
     walk.U = U;
     walk.step_t = kWave / U;
@@ -669,8 +735,12 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
                     keep[p] = 1u;                                 // no decision made: the chunk is copied as it is
                     if (a.large_ready) {
                         const u64 g = tb + t;
-                        const u32 s = a.slot_of[g];
-                        keep[p] = ((u32)a.tab[s] - 1u == (u32)g && (a.par[s] & 1u)) ? 1u : 0u;
+                        if (exact_large) {
+                            const u32 s = a.slot_of[g];
+                            keep[p] = ((u32)a.tab[s] - 1u == (u32)g && (a.par[s] & 1u)) ? 1u : 0u;
+                        } else {
+                            keep[p] = a.keepb[g];
+                        }
                     }
                 }
             }
@@ -736,7 +806,8 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
         }
         if (!large) {
             for (u32 x = tid; x < ncts; x += kCT) {
-                const u32 rel = staged ? s_coff[x] : (u32)(a.off[c0 + x] - tb);
+                // (a group of ONE ciphertext starts at its first term: no dependent load in front of the stores)
+                const u32 rel = staged ? s_coff[x] : multi ? (u32)(a.off[c0 + x] - tb) : 0u;
                 a.off_out[c0 + x] = prefix + (s_rk[rel] >> 1);
             }
         } else if (chunk == 0u && tid == 0) {
@@ -773,20 +844,24 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
     }
 }
 
-// ------------------------------------------------- large ciphertexts: the table in HBM
+// ------------------------------------------------- large ciphertexts: partitions by hash
 struct LargeArgs {
     const void *terms;
     const u64 *off;
     u64 *ctrl;
     const u64 *chunks;
+    const u64 *plist, *slist;
     u64 *hash;
-    u64 *tab;
-    u32 *par;
-    u32 *slot_of;
+    u64 *tab;                // {tag}[2 per term]: the partitions' tags; exact path: the open-addressing table
+    u32 *par;                // {index in the ciphertext}[2 per term] beside the tags; exact path: class parities
+    u32 *slot_of;            // the partitions' cursors at the head of each ciphertext's share; exact path: a term's slot
+    u64 *joined;             // {term, its representative} of every term that joined a class
+    unsigned char *keepb;    // one byte per term: 1 = it survives
     u64 tag_mask;
     Geom g;
-    FastDiv dU;
     u32 dL;
+    u32 lg;                  // lanes per pair of the verify kernel: 2^lg >= min(U, 64)
+    FastDiv dGU, dTpi;       // k_cl_hash: by min(U, 64) lanes per term, by 64 / that terms per wave instruction
 };
 
 struct Chunk {
@@ -807,43 +882,303 @@ __device__ inline Chunk chunk_of(const LargeArgs &a, u64 ci)
     return k;
 }
 
-// hash of every term of every chunk (the first read of a large ciphertext) + its table slots cleared
+// The first read of a large ciphertext.  min(U, 64) consecutive lanes take a term (lane l of them its units l,
+// l + 64, ...), 64 / U terms per wave instruction -- whole consecutive terms, 60 of 64 lanes busy at N=1247 -- and
+// eight such instructions in flight.  The unit hashes meet in the wave's own LDS strip (DS operations of one
+// wave run in order: no barrier), where one lane per term adds them up, writes the term's hash and sets its
+// keep byte (both coalesced).  The next chunk's descriptor is fetched while this one streams.
 template <typename Unit>
-__global__ void __launch_bounds__(kCT) k_cl_hash(LargeArgs a)
+__global__ void __launch_bounds__(256) k_cl_hash(LargeArgs a)
 {
-    extern __shared__ u64 s_dyn[];
-    u64 *s_hash = s_dyn;
+    constexpr int kFly = 8;
+    __shared__ u64 s_strip[4][kFly][kWave];
     const u64 nchunks = a.ctrl[kCtrlChunks];
     const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
-    const u32 tid = threadIdx.x, U = a.g.U;
+    const u32 lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, U = a.g.U;
+    const u32 GU = min(U, (u32)kWave), tpi = kWave / GU, tpw = tpi * kFly;
+    const u32 grp = csgn_fastdiv(lane, a.dGU), gl = lane - grp * GU;
+    const bool live = grp < tpi;
+    if (blockIdx.x >= nchunks)
+        return;
+    Chunk k = chunk_of(a, blockIdx.x);
     for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
-        const Chunk k = chunk_of(a, ci);
-        const u32 nunits = k.nt * U;
-        for (u32 x = tid; x < k.nt; x += kCT)
-            s_hash[x] = 0ull;
-        for (u32 x = tid; x < 2u * k.nt; x += kCT) {
-            a.tab[2 * k.tb + x] = 0ull;
-            a.par[2 * k.tb + x] = 0u;
+        const u64 cn = ci + gridDim.x;
+        const Chunk next = chunk_of(a, cn < nchunks ? cn : ci);
+        for (u32 t0 = wave * tpw; t0 < k.nt; t0 += 4u * tpw) {
+            u64 acc[kFly];
+#pragma unroll
+            for (int i = 0; i < kFly; ++i)
+                acc[i] = 0ull;
+            for (u32 kk = gl; kk < U; kk += GU) {
+                Unit v[kFly];
+#pragma unroll
+                for (int i = 0; i < kFly; ++i) {
+                    const u32 t = t0 + (u32)i * tpi + grp;
+                    v[i] = (live && t < k.nt) ? terms[(k.tb + t) * U + kk] : unit_zero<Unit>();
+                }
+#pragma unroll
+                for (int i = 0; i < kFly; ++i)
+                    acc[i] += unit_hash(v[i], kk);                // (dead lanes: never read back)
+            }
+#pragma unroll
+            for (int i = 0; i < kFly; ++i)
+                s_strip[wave][i][lane] = acc[i];
+            __builtin_amdgcn_wave_barrier();
+            for (u32 x = lane; x < tpw && t0 + x < k.nt; x += kWave) {
+                // term t0 + x = instruction x / tpi, group x % tpi
+                const u32 i = csgn_fastdiv(x, a.dTpi), gq = x - i * tpi;
+                const u64 *row = &s_strip[wave][i][gq * GU];
+                u64 s0 = 0ull, s1 = 0ull;
+                u32 u = 0u;
+                for (; u + 1u < GU; u += 2u) {
+                    s0 += row[u];
+                    s1 += row[u + 1u];
+                }
+                if (u < GU)
+                    s0 += row[u];
+                const u64 gt = k.tb + t0 + x;
+                a.hash[gt] = csgn_splitmix64(s0 + s1);
+                a.keepb[gt] = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        k = next;
+    }
+}
+
+// The {hash, index} pair of every term goes to the partition the top bits of the hash pick.  Scattered one by one
+// the pairs cost more than the terms' first read (8 M partial-line writes for 4 M terms: 80 us of a 117 us kernel;
+// and a cursor taken per term serves its thousand atomics one after the other).  So a workgroup takes a STRIPE of
+// 8192 consecutive terms of one ciphertext and SORTS its pairs by partition in LDS first (count, scan, rank: LDS
+// atomics), reserves its share of every partition with ONE atomic on the partition's cursor, and writes every
+// partition's run of pairs side by side: whole 32- and 64-byte pieces instead of single words.  (Beyond 2048
+// partitions -- ciphertexts of more than two million terms -- every term takes the cursor itself.)
+constexpr u32 kScatterThreads = 1024;
+inline size_t scatter_lds_bytes() { return (size_t)kStripeTerms * 12 + (size_t)(3u << kStripeMaxLp) * 4 + 64 * 4; }
+__global__ void __launch_bounds__(kScatterThreads) k_cl_scatter(LargeArgs a)
+{
+    extern __shared__ u64 s_dyn[];
+    u64 *s_h = s_dyn;                                             // [stripe] hashes, sorted by partition
+    u32 *s_i = reinterpret_cast<u32 *>(s_h + kStripeTerms);       // [stripe] ... and their terms
+    u32 *s_cnt = s_i + kStripeTerms;                              // [P] terms per partition, then the local cursors
+    u32 *s_lbase = s_cnt + (1u << kStripeMaxLp);                  // [P] where a partition's run starts in s_h
+    u32 *s_gbase = s_lbase + (1u << kStripeMaxLp);                // [P] ... and in the partition itself
+    u32 *s_w = s_gbase + (1u << kStripeMaxLp);                    // [waves] scan
+    constexpr int kPer = kStripeTerms / kScatterThreads;          // terms per thread: their hashes stay in registers
+    const u64 nstripes = a.ctrl[kCtrlStripes];
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    bool overflow = false;
+    for (u64 si = blockIdx.x; si < nstripes; si += gridDim.x) {
+        const u64 desc = a.slist[si];
+        const u32 c = (u32)desc;
+        const u64 c_begin = a.off[c], T = a.off[c + 1] - c_begin;
+        const u64 t_lo = (desc >> 32) * kStripeTerms;
+        const u32 ns = (u32)(min(T, t_lo + kStripeTerms) - t_lo);
+        const PartGeom pg = part_geom(T);
+        const u32 cs = cursor_stride(T, pg.lp), P = 1u << pg.lp;
+        u32 *cursor = a.slot_of + c_begin;
+        u64 *tags = a.tab + 2 * c_begin;
+        u32 *idx = a.par + 2 * c_begin;
+        const bool full_tag = ~a.tag_mask == 0ull;
+        if (pg.lp > kStripeMaxLp) {
+            for (u32 x = tid; x < ns; x += kScatterThreads) {
+                const u64 h = a.hash[c_begin + t_lo + x];
+                const u32 q = (u32)(h >> (64u - pg.lp));
+                const u32 pos = atomicAdd(cursor + (u64)q * cs, 1u);
+                if (pos < pg.cap) {
+                    tags[(u64)q * pg.cap + pos] = full_tag ? h : ((h >> 16) & a.tag_mask);
+                    idx[(u64)q * pg.cap + pos] = (u32)(t_lo + x);
+                } else {
+                    overflow = true;
+                }
+            }
+            continue;
+        }
+        for (u32 x = tid; x < P; x += kScatterThreads)
+            s_cnt[x] = 0u;
+        __syncthreads();
+        u64 h[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const u32 x = tid + (u32)i * kScatterThreads;
+            h[i] = x < ns ? a.hash[c_begin + t_lo + x] : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+            if (tid + (u32)i * kScatterThreads < ns)
+                atomicAdd(s_cnt + (pg.lp ? (u32)(h[i] >> (64u - pg.lp)) : 0u), 1u);
+        __syncthreads();
+        // exclusive scan of the counts (a thread takes P / 1024 consecutive partitions), and the reservations
+        {
+            const u32 per = (P + kScatterThreads - 1u) / kScatterThreads, b0 = tid * per;
+            u32 mine = 0u;
+            for (u32 j = 0; j < per; ++j)
+                mine += b0 + j < P ? s_cnt[b0 + j] : 0u;
+            const u32 incl = wave_incl_scan(mine);
+            if (lane == kWave - 1)
+                s_w[wave] = incl;
+            __syncthreads();
+            u32 run = incl - mine;
+            for (u32 w = 0; w < wave; ++w)
+                run += s_w[w];
+            for (u32 j = 0; j < per; ++j)
+                if (b0 + j < P) {
+                    const u32 n = s_cnt[b0 + j];
+                    s_lbase[b0 + j] = run;
+                    s_cnt[b0 + j] = run;
+                    s_gbase[b0 + j] = n ? atomicAdd(cursor + (u64)(b0 + j) * cs, n) : 0u;
+                    run += n;
+                }
         }
         __syncthreads();
-        for (u32 j = tid; j < nunits; j += kCT) {
-            const u32 t = csgn_fastdiv(j, a.dU), kk = j - t * U;
-            atomicAdd(ull(s_hash + t), unit_hash(terms[k.tb * U + j], kk));
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const u32 x = tid + (u32)i * kScatterThreads;
+            if (x < ns) {
+                const u32 at = atomicAdd(s_cnt + (pg.lp ? (u32)(h[i] >> (64u - pg.lp)) : 0u), 1u);
+                s_h[at] = h[i];
+                s_i[at] = (u32)(t_lo + x);
+            }
         }
         __syncthreads();
-        for (u32 x = tid; x < k.nt; x += kCT)
-            a.hash[k.tb + x] = csgn_splitmix64(s_hash[x]);
+        for (u32 x = tid; x < ns; x += kScatterThreads) {
+            const u64 hh = s_h[x];
+            const u32 q = pg.lp ? (u32)(hh >> (64u - pg.lp)) : 0u;
+            const u32 pos = s_gbase[q] + (x - s_lbase[q]);
+            if (pos < pg.cap) {
+                tags[(u64)q * pg.cap + pos] = full_tag ? hh : ((hh >> 16) & a.tag_mask);
+                idx[(u64)q * pg.cap + pos] = s_i[x];
+            } else {
+                overflow = true;
+            }
+        }
+        __syncthreads();
+    }
+    if (overflow)
+        a.ctrl[kCtrlCollision] = 1ull;
+}
+
+// One workgroup per partition: its pairs go to LDS, are chained into buckets by tag (ONE exchange on the
+// bucket's head, as in the main kernel) and every pair walks its bucket: the smallest index with the same
+// tag is the class's representative, the class's size mod 2 decides.  Only terms that do NOT survive
+// write their keep byte (k_cl_hash set it); a term that joined a class is listed for k_cl_verify.
+__global__ void __launch_bounds__(256) k_cl_dedup(LargeArgs a)
+{
+    __shared__ u64 s_tag[kPartCap];
+    __shared__ u32 s_idx[kPartCap], s_next[kPartCap], s_head[kPartCap];
+    if (a.ctrl[kCtrlCollision] != 0ull)
+        return;
+    const u64 nparts = a.ctrl[kCtrlParts];
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
+    for (u64 pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+        const u64 desc = a.plist[pi];
+        const u32 c = (u32)desc, q = (u32)(desc >> 32);
+        const u64 c_begin = a.off[c], T = a.off[c + 1] - c_begin;
+        const PartGeom pg = part_geom(T);
+        const u32 n = min(a.slot_of[c_begin + (u64)q * cursor_stride(T, pg.lp)], pg.cap);
+        const u64 base = 2 * c_begin + (u64)q * pg.cap;
+        u32 nb = 1u;
+        while (nb < n)
+            nb <<= 1;
+        for (u32 x = tid; x < nb; x += 256u)
+            s_head[x] = 0u;
+        for (u32 x = tid; x < n; x += 256u) {
+            s_tag[x] = a.tab[base + x];
+            s_idx[x] = a.par[base + x];
+        }
+        __syncthreads();
+        for (u32 x = tid; x < n; x += 256u)
+            s_next[x] = atomicExch(s_head + ((u32)s_tag[x] & (nb - 1u)), x + 1u);
+        __syncthreads();
+        for (u32 x0 = 0; x0 < n; x0 += 256u) {
+            const u32 x = x0 + tid;
+            bool joins = false;
+            u32 mine = 0u, rep = 0u;
+            if (x < n) {
+                const u64 tag = s_tag[x];
+                mine = rep = s_idx[x];
+                u32 cnt = 0u;
+                for (u32 e = s_head[(u32)tag & (nb - 1u)]; e != 0u; e = s_next[e - 1u])
+                    if (s_tag[e - 1u] == tag) {
+                        ++cnt;
+                        rep = min(rep, s_idx[e - 1u]);
+                    }
+                joins = rep != mine;
+                if (joins || !(cnt & 1u))
+                    a.keepb[c_begin + mine] = 0;
+            }
+            const u64 m = __ballot(joins);
+            if (m != 0ull) {                                      // wave-uniform
+                u64 at = 0ull;
+                if (lane == 0u)
+                    at = atomicAdd(ull(a.ctrl + kCtrlJoined), (unsigned long long)__popcll(m));
+                at = (u64)__shfl((unsigned long long)at, 0, kWave);
+                if (joins)
+                    a.joined[at + __popcll(m & ((1ull << lane) - 1ull))] = (c_begin + mine) | ((c_begin + rep) << 32);
+            }
+        }
         __syncthreads();
     }
 }
 
-// one lane per term: insert into the ciphertext's region [2*begin, 2*(begin+terms)) of the HBM table;
-// entries are {32-bit tag, GLOBAL term index + 1}
-template <bool EXACT>
+// every unit of a term that joined a class against the same unit of the class's smallest member; a difference
+// is a hash collision between unequal terms and sends the call's large ciphertexts to the exact path
+template <typename Unit>
+__global__ void __launch_bounds__(256) k_cl_verify(LargeArgs a)
+{
+    constexpr int kFly = 4;
+    if (a.ctrl[kCtrlCollision] != 0ull)
+        return;
+    const u64 njoined = a.ctrl[kCtrlJoined];
+    const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
+    const u32 lane = threadIdx.x & (kWave - 1), U = a.g.U;
+    const u32 G = 1u << a.lg, gl = lane & (G - 1u), grp = lane >> a.lg, ppi = kWave >> a.lg;
+    const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = (u64)gridDim.x * 4u;
+    bool bad = false;
+    for (u64 j0 = wave * (ppi * kFly); j0 < njoined; j0 += nwaves * (ppi * kFly)) {
+        u64 e[kFly];
+#pragma unroll
+        for (int i = 0; i < kFly; ++i) {
+            const u64 j = j0 + (u64)i * ppi + grp;
+            e[i] = j < njoined ? a.joined[j] : 0ull;              // (term 0 against term 0: equal)
+        }
+        for (u32 kk = gl; kk < U; kk += G) {
+            Unit x[kFly], y[kFly];
+#pragma unroll
+            for (int i = 0; i < kFly; ++i) {
+                x[i] = terms[(e[i] & 0xFFFFFFFFull) * U + kk];
+                y[i] = terms[(e[i] >> 32) * U + kk];
+            }
+#pragma unroll
+            for (int i = 0; i < kFly; ++i)
+                bad |= !unit_same(x[i], y[i]);
+        }
+    }
+    if (bad)
+        a.ctrl[kCtrlCollision] = 1ull;
+}
+
+// ---- the exact path (kCtrlCollision set): an open-addressing table in HBM per large ciphertext, two slots per
+// term, entries {32-bit tag, GLOBAL term index + 1}; a tag match is confirmed by comparing the terms' words
+__global__ void __launch_bounds__(256) k_cl_clear(LargeArgs a)
+{
+    const u64 nchunks = a.ctrl[kCtrlChunks];
+    if (a.ctrl[kCtrlCollision] == 0ull)
+        return;
+    for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
+        const Chunk k = chunk_of(a, ci);
+        for (u32 x = threadIdx.x; x < 2u * k.nt; x += 256u) {
+            a.tab[2 * k.tb + x] = 0ull;
+            a.par[2 * k.tb + x] = 0u;
+        }
+    }
+}
+
+// one lane per term: insert into the ciphertext's region [2*begin, 2*(begin+terms)) of the table
 __global__ void __launch_bounds__(256) k_cl_insert(LargeArgs a)
 {
     const u64 nchunks = a.ctrl[kCtrlChunks];
-    if (EXACT && a.ctrl[kCtrlCollision] == 0ull)
+    if (a.ctrl[kCtrlCollision] == 0ull)
         return;
     const u64 *words = static_cast<const u64 *>(a.terms);
     for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
@@ -861,56 +1196,15 @@ __global__ void __launch_bounds__(256) k_cl_insert(LargeArgs a)
                     if (cur == 0ull)
                         break;
                 }
-                if ((cur >> 32) == tag) {
-                    bool same = true;
-                    if (EXACT)
-                        same = words_equal(words + g * a.dL, words + (u64)((u32)cur - 1u) * a.dL, a.dL);
-                    if (same) {
-                        atomicMin(ull(a.tab + base + slot), entry);
-                        break;
-                    }
+                if ((cur >> 32) == tag &&
+                    words_equal(words + g * a.dL, words + (u64)((u32)cur - 1u) * a.dL, a.dL)) {
+                    atomicMin(ull(a.tab + base + slot), entry);
+                    break;
                 }
                 slot = slot + 1 == ns ? 0 : slot + 1;
             }
             atomicXor(a.par + base + slot, 1u);
             a.slot_of[g] = (u32)(base + slot);
-        }
-    }
-}
-
-// every unit of a term that joined a class against the same unit of the class's smallest member
-template <typename Unit>
-__global__ void __launch_bounds__(256) k_cl_verify(LargeArgs a)
-{
-    const u64 nchunks = a.ctrl[kCtrlChunks];
-    const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
-    const u32 U = a.g.U;
-    bool bad = false;
-    for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
-        const Chunk k = chunk_of(a, ci);
-        const u32 nunits = k.nt * U;
-        for (u32 j = threadIdx.x; j < nunits; j += 256u) {
-            const u32 t = csgn_fastdiv(j, a.dU), kk = j - t * U;
-            const u64 g = k.tb + t;
-            const u64 rep = (u64)((u32)a.tab[a.slot_of[g]] - 1u);
-            if (rep != g && !unit_same(terms[g * U + kk], terms[rep * U + kk]))
-                bad = true;
-        }
-    }
-    if (bad)
-        a.ctrl[kCtrlCollision] = 1ull;
-}
-
-__global__ void __launch_bounds__(256) k_cl_clear(LargeArgs a)
-{
-    const u64 nchunks = a.ctrl[kCtrlChunks];
-    if (a.ctrl[kCtrlCollision] == 0ull)
-        return;
-    for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
-        const Chunk k = chunk_of(a, ci);
-        for (u32 x = threadIdx.x; x < 2u * k.nt; x += 256u) {
-            a.tab[2 * k.tb + x] = 0ull;
-            a.par[2 * k.tb + x] = 0u;
         }
     }
 }
@@ -928,11 +1222,12 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     // the call's head (control words + status granules) is cleared by the first kernel itself: no memset
     // node (see zero_words), no launch of its own
     const u32 cblocks = ceil_div_u64(batch, 256);
-    k_cg_count<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.ctrl, l.head_bytes / 8);
+    k_cg_count<<<max(cblocks, (u32)min((u64)256, l.head_bytes / 8 / 2048)), 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.ctrl, l.head_bytes / 8);
     const bool scan = cblocks > 1024u;
     if (scan)
         k_cg_scan<<<1, 1024, 0, s>>>(cblocks, l.partial, l.ctrl);
-    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.groups, l.chunks, l.ctrl, scan ? 1u : 0u);
+    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.groups, l.chunks, l.plist, l.slist, l.slot_of, l.ctrl,
+                                       scan ? 1u : 0u);
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
 
@@ -947,20 +1242,34 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
         la.off = off;
         la.ctrl = l.ctrl;
         la.chunks = l.chunks;
+        la.plist = l.plist;
+        la.slist = l.slist;
         la.hash = l.hash;
         la.tab = l.tab;
         la.par = l.par;
         la.slot_of = l.slot_of;
+        la.joined = l.joined;
+        la.keepb = l.keepb;
         la.tag_mask = tag_mask;
         la.g = g;
-        la.dU = csgn_fastdiv_make(U);
         la.dL = (u32)dL;
+        la.dGU = csgn_fastdiv_make(min(U, (u32)kWave));
+        la.dTpi = csgn_fastdiv_make((u32)kWave / min(U, (u32)kWave));
+        la.lg = 0u;
+        while ((1u << la.lg) < min(U, (u32)kWave))
+            ++la.lg;
         const u32 grid = (u32)min(ng, (u64)2048);
-        k_cl_hash<Unit><<<min(grid, 512u), kCT, g.capT * 8, s>>>(la);
-        k_cl_insert<false><<<grid, 256, 0, s>>>(la);
-        k_cl_verify<Unit><<<grid, 256, 0, s>>>(la);
-        k_cl_clear<<<grid, 256, 0, s>>>(la);
-        k_cl_insert<true><<<grid, 256, 0, s>>>(la);
+        k_cl_hash<Unit><<<grid, 256, 0, s>>>(la);
+        // (per call: the attribute belongs to the current device's copy of the kernel)
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cl_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)scatter_lds_bytes())) != hipSuccess)
+            return e;
+        k_cl_scatter<<<(u32)min(ng + total_terms / kStripeTerms, (u64)512), kScatterThreads, scatter_lds_bytes(), s>>>(la);
+        k_cl_dedup<<<(u32)min(ng + total_terms / (kPartTerms / 2), (u64)1024), 256, 0, s>>>(la);
+        k_cl_verify<Unit><<<min(grid, 1024u), 256, 0, s>>>(la);
+        // (no-ops unless a partition overflowed or unequal terms shared a hash)
+        k_cl_clear<<<min(grid, 256u), 256, 0, s>>>(la);
+        k_cl_insert<<<min(grid, 256u), 256, 0, s>>>(la);
     }
     CompactArgs a;
     a.terms = terms;
@@ -970,6 +1279,7 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     a.ctrl = l.ctrl;
     a.status = l.status;
     a.groups = l.groups;
+    a.keepb = l.keepb;
     a.tab = l.tab;
     a.par = l.par;
     a.slot_of = l.slot_of;

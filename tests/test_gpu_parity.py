@@ -1436,7 +1436,7 @@ def _check_compaction(hip, oracle, n, cts, max_terms=0, expect_compacted=True):
 def test_compaction_many_groups_and_sizes(hip, oracle, n):
     """Several hundred ciphertexts of every size class in one call: runs of small ones that share a
     workgroup, ciphertexts that fill one alone, empty ones in every position, and (at the wider contexts)
-    ciphertexts beyond a workgroup's group that go through the HBM table -- all behind one look-back
+    ciphertexts beyond a workgroup's group that are deduplicated by hash partitions -- all behind one look-back
     chain of output offsets.  Term lists identical to the checker's."""
     rng = np.random.default_rng(n + 11)
     cts = []
@@ -1459,7 +1459,7 @@ def test_compaction_many_groups_and_sizes(hip, oracle, n):
 
 
 def test_compaction_large_ciphertexts(hip, oracle):
-    """Ciphertexts of many workgroup groups (3 000 to 40 000 terms at N=1247: the HBM-table path), between
+    """Ciphertexts of many workgroup groups (3 000 to 40 000 terms at N=1247: the hash-partition path), between
     small ones, with 0 %, 50 % and 97 % duplicates."""
     n = 1247
     rng = np.random.default_rng(5)
@@ -1475,11 +1475,30 @@ def test_compaction_large_ciphertexts(hip, oracle):
     assert int(off_out[6]) - int(off_out[5]) <= 100
 
 
+@pytest.mark.parametrize("n", [1247, 4096, 129, 64])
+def test_compaction_large_ciphertexts_partition_overflow_and_shapes(hip, oracle, n):
+    """The partitions of a large ciphertext (pairs dealt by the top bits of the term hash, 2048 to a partition at
+    most): one term repeated thousands of times overflows its partition and the call takes the exact path; sizes
+    on both sides of every partition count (one, two, many partitions); several large ciphertexts in one batch
+    with small ones between them.  Term lists identical to the checker's."""
+    rng = np.random.default_rng(n)
+    dl = oracle.default_len(n)
+    heavy = _dup_ciphertext(oracle, rng, n, 60, 3000, 9000).reshape(-1, dl)
+    heavy[rng.permutation(9000)[:5001]] = heavy[0]                # one term 5001 times: its partition overflows
+    cts = [_dup_ciphertext(oracle, rng, n, 61, 4, 6), np.ascontiguousarray(heavy.reshape(-1)),
+           _dup_ciphertext(oracle, rng, n, 62, 5000, 5000)]
+    _check_compaction(hip, oracle, n, cts)
+    sizes = [1025, 2048, 2049, 4097, 0, 7, 12289, 1500]
+    cts = [_dup_ciphertext(oracle, rng, n, 63 + i, max(1, int(t * f)), t) for i, (t, f) in
+           enumerate(zip(sizes, [1.0, 0.5, 4.0, 0.25, 1.0, 1.0, 0.6, 0.01]))]
+    _check_compaction(hip, oracle, n, cts)
+
+
 @pytest.mark.parametrize("n,sizes", [(1247, [1100, 1792, 3, 1500, 0, 1025, 700]), (4096, [766, 321, 768, 5, 500])])
 def test_compaction_wide_groups(hip, oracle, n, sizes):
     """Ciphertexts between one workgroup's usual group (1024 terms at N=1247, 320 at N=4096) and the wide build's
     (1792 / 768 -- BASELINE config 5 ends at 766 terms): with the caller's bound they are read once by the
-    48-units-per-lane build of the main kernel; without it they take the HBM-table path.  Same term lists as the
+    48-units-per-lane build of the main kernel; without it they take the hash-partition path.  Same term lists as the
     checker's either way, 0 % to 97 % duplicates."""
     rng = np.random.default_rng(n + 3)
     cts = [_dup_ciphertext(oracle, rng, n, 40 + i, max(1, int(t * f)), t) for i, (t, f) in
@@ -1515,7 +1534,7 @@ def test_compaction_one_million_single_terms_and_empties(hip, oracle):
 @pytest.mark.parametrize("bits", [1, 3])
 def test_compaction_survives_tag_collisions(hip, oracle, knobs, bits):
     """With the hash tags narrowed to a few bits, unequal terms collide all the time: the verify pass
-    catches it and the group (or the HBM table) is redone with full compares -- the words stay exact."""
+    catches it and the group (or, for large ciphertexts, the call: the exact open-addressing table in HBM) is redone with full compares -- the words stay exact."""
     knobs.set("compact_tag_bits", bits)
     rng = np.random.default_rng(bits)
     for n in (1247, 129):

@@ -8,7 +8,7 @@ steady state (>= 30 ms of warm-up, runs of back-to-back calls between one pair o
 than the 256 MB memory-side cache or rotates through sets that are, so no call finds its terms cached.
 Shapes: 4096 ciphertexts of 1024 terms (BASELINE config 3's operands) with 0 / 50 / 95 % duplicate terms; the square
 of a 32-term sum (1024 product terms of which 32 survive: a_i a_j = a_j a_i cancel, a_i a_i = a_i stay); the literal
-(a+b)^2 (4 terms -> 2) and single-term ciphertexts by the million; 2^20-term ciphertexts (the HBM-table path);
+(a+b)^2 (4 terms -> 2) and single-term ciphertexts by the million; 2^20-term ciphertexts (the hash-partition path);
 N=4096.
 """
 import argparse
@@ -138,9 +138,9 @@ ragged = np.minimum(np.maximum(rng.lognormal(np.log(48.0), 1.0, size=1 << 16), 1
 case(f"compact ragged log-normal (mean {ragged.mean():.0f} terms) x 65536, 0% duplicates N={n}", n, ragged,
      lambda: [hip.synth_fill(24, n, 0, int(ragged.sum()) * dl)], max_terms=1024)
 for frac in (0.0, 0.5):
-    case(f"compact 4 x 2^20 terms, {int(frac*100)}% duplicates (HBM table) N={n}", n, (4, 1 << 20),
+    case(f"compact 4 x 2^20 terms, {int(frac*100)}% duplicates (hash partitions) N={n}", n, (4, 1 << 20),
          lambda frac=frac: [with_duplicates(n, dl, 4, 1 << 20, frac, 12)])
-case(f"compact 256 x 16384 terms, 50% duplicates (HBM table) N={n}", n, (256, 16384),
+case(f"compact 256 x 16384 terms, 50% duplicates (hash partitions) N={n}", n, (256, 16384),
      lambda: [with_duplicates(n, dl, 256, 16384, 0.5, 13)])
 n, dl = 4096, 64
 for frac in (0.0, 0.5):
@@ -148,7 +148,7 @@ for frac in (0.0, 0.5):
          lambda frac=frac: [with_duplicates(n, dl, 8192, 256, frac, 14)], max_terms=256)
 case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates, wide groups N={n}", n, (2048, 766),
      lambda: [with_duplicates(n, dl, 2048, 766, 0.0, 15)], max_terms=766)
-case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates, bound unknown (HBM table) N={n}", n, (2048, 766),
+case(f"compact 2048 x 766 terms (config 5's end size), 0% duplicates, bound unknown (hash partitions) N={n}", n, (2048, 766),
      lambda: [with_duplicates(n, dl, 2048, 766, 0.0, 15)])
 n, dl = 1247, 20
 case(f"compact 2048 x 1792 terms, 0% duplicates, wide groups N={n}", n, (2048, 1792),

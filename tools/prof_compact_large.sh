@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats of the compaction of 4 ciphertexts x 2^20 terms (the HBM-table path).  usage: bash tools/prof_compact_large.sh OUTDIR
+# rocprofv3 --kernel-trace --stats of the compaction of 4 ciphertexts x 2^20 terms (the hash-partition path).  usage: bash tools/prof_compact_large.sh OUTDIR
 export TMPDIR=/tmp
 OUT=$1; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
