@@ -30,8 +30,8 @@
 // terms are hashed first (k_cl_hash: the first read) and every {hash, index} pair is dealt by the top
 // bits of the hash to one of T/1024 PARTITIONS of its ciphertext (one atomic on the partition's cursor,
 // one 12-byte scatter -- no read-modify-write of a table in HBM); a partition fits LDS and is
-// deduplicated there like a group (k_cl_scatter, k_cl_dedup), leaving one keep byte per term; k_cl_verify compares
-// the terms that joined a class with their representatives.  The main kernel then moves the chunks of
+// deduplicated there like a group (k_cl_scatter, k_cl_dedup), leaving one keep byte per term, the terms that
+// joined a class compared with their representatives.  The main kernel then moves the chunks of
 // a large ciphertext exactly like a group, reading the keep bytes instead of making the decision:
 // their terms are read twice.  A partition that overflows (one term repeated thousands of times) or a
 // hash collision between unequal terms sends the call to the exact path: an open-addressing table in
@@ -52,7 +52,7 @@ constexpr u32 kMaxGroupTerms = 1024, kMaxGroupTermsWide = 1792;     // LDS: 24 B
 
 // control words (u64 each) at the head of the scratch block; zeroed, with the status granules, per call
 // (kCtrlCollision: a partition overflowed or unequal terms shared a hash -- the exact path decides the large ciphertexts)
-enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlParts = 4, kCtrlJoined = 5, kCtrlStripes = 6, kCtrlWords = 32 };
+enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlParts = 4, kCtrlStripes = 5, kCtrlWords = 32 };
 
 // Partitions of a large ciphertext of T terms: P = 2^lp >= T / 1024 of them, picked by the top lp bits of a term's hash,
 // each with room for cap = 2T / P <= 2048 {hash, index} pairs (twice the mean; P <= 2 cannot overflow at all).
@@ -100,7 +100,7 @@ u64 group_bound(u64 total_terms, const Geom &g) { return 4 + 10 * (total_terms /
 struct GroupDesc;
 struct Layout {
     GroupDesc *groups;
-    u64 *ctrl, *status, *chunks, *partial, *hash, *tab, *plist, *slist, *joined;
+    u64 *ctrl, *status, *chunks, *partial, *hash, *tab, *plist, *slist;
     u32 *gpos, *par, *slot_of;
     unsigned char *keepb;
     size_t bytes, head_bytes;
@@ -131,7 +131,6 @@ Layout make_layout(void *scratch, u64 batch, u64 total_terms, const Geom &g)
     l.slot_of = reinterpret_cast<u32 *>(take(total_terms * 4));
     l.plist = reinterpret_cast<u64 *>(take((ng + total_terms / (kPartTerms / 2) + 1) * 8));
     l.slist = reinterpret_cast<u64 *>(take((ng + total_terms / kStripeTerms + 1) * 8));
-    l.joined = reinterpret_cast<u64 *>(take(total_terms * 8));
     l.keepb = reinterpret_cast<unsigned char *>(take(total_terms));
     l.bytes = (p - p0) + 256;
     return l;
@@ -320,7 +319,7 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
     // summed here, which saves the scan kernel's launch; block 0 then also leaves the total for the main kernel
     __shared__ u64 s_base, s_part[4];
     __shared__ u32 s_nlarge, s_lc[256];
-    __shared__ u64 s_lbefore[256], s_at[3];
+    __shared__ u64 s_lbefore[256], s_at[256][3];
     u64 block_base = 0;
     if (threadIdx.x == 0)
         s_nlarge = 0u;
@@ -361,19 +360,21 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
     }
     __syncthreads();
     const u32 nlarge = s_nlarge;
+    if (threadIdx.x < nlarge) {                                   // every large ciphertext's three reservations at once
+        const u32 lc = s_lc[threadIdx.x];
+        const u64 t = off[lc + 1] - off[lc];
+        s_at[threadIdx.x][0] = atomicAdd(ull(ctrl + kCtrlChunks), (unsigned long long)((t + g.capT - 1) / g.capT));
+        s_at[threadIdx.x][1] = atomicAdd(ull(ctrl + kCtrlParts), (unsigned long long)(1u << part_geom(t).lp));
+        s_at[threadIdx.x][2] = atomicAdd(ull(ctrl + kCtrlStripes), (unsigned long long)((t + kStripeTerms - 1) / kStripeTerms));
+    }
+    __syncthreads();
     for (u32 li = 0; li < nlarge; ++li) {
         const u32 lc = s_lc[li];
         const u64 o0 = off[lc], o1 = off[lc + 1], first = s_lbefore[li];
         const u32 nch = (u32)((o1 - o0 + g.capT - 1) / g.capT);
         const PartGeom pg = part_geom(o1 - o0);
         const u32 nst = (u32)((o1 - o0 + kStripeTerms - 1) / kStripeTerms);
-        if (threadIdx.x < 3u) {                                   // (three lanes: the round trips overlap)
-            const u32 word = threadIdx.x == 0 ? kCtrlChunks : threadIdx.x == 1 ? kCtrlParts : kCtrlStripes;
-            const u32 want = threadIdx.x == 0 ? nch : threadIdx.x == 1 ? (1u << pg.lp) : nst;
-            s_at[threadIdx.x] = atomicAdd(ull(ctrl + word), (unsigned long long)want);
-        }
-        __syncthreads();
-        const u64 at = s_at[0], pat = s_at[1], sat = s_at[2];
+        const u64 at = s_at[li][0], pat = s_at[li][1], sat = s_at[li][2];
         for (u32 i = threadIdx.x; i < nch; i += 256u) {
             GroupDesc d;
             d.tb = o0 + (u64)i * g.capT;
@@ -391,7 +392,6 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
             plist[pat + q] = (u64)lc | ((u64)q << 32);
             cursor[o0 + (u64)q * cursor_stride(o1 - o0, pg.lp)] = 0u;
         }
-        __syncthreads();
     }
     if (c >= batch || large)
         return;
@@ -449,6 +449,55 @@ constexpr int term_passes(int R) { return (int)(((R == kCR ? kMaxGroupTerms : kM
 inline size_t main_lds_bytes(u32 capT, int R)
 {
     return (size_t)capT * (8 + 4 + 4 + 4 + 4) + 64 + (size_t)(kCT / kWave) * sub_rows(R) * kWave * 8;
+}
+
+// Ranks of a group's survivors (per pass the waves' ballots, then one look at all the wave counts: s_rk[t] = rank << 1
+// | keep) and the group's place in the output: wave 0's look-back, left in *s_prefix for the caller's next barrier to
+// publish.  Returns the number of survivors.
+// (Round 5: the look-back by the whole workgroup -- thread t reads the status of group gid - 1 - t, the kCT nearest
+// predecessors in one round trip instead of up to eight windows of 64 -- changed nothing, 0.322 against 0.30-0.31
+// ms: the 8.7 us a group spends here are not the walk, they are the wait for the SLOWEST of the up to 511 groups
+// in flight before it to publish its count.)
+template <int kPasses>
+__device__ inline u32 rank_and_place(const u32 (&keep)[kPasses], u32 nt, u32 tid, u32 lane, u32 wave, u32 *s_wsum, u32 *s_rk,
+                                     u64 *status, u32 gid, u64 *s_prefix, bool lds_only)
+{
+    u32 before[kPasses];
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const u64 m = __ballot(keep[p] != 0u);
+        before[p] = (u32)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_wsum[(u32)p * (kCT / kWave) + wave] = (u32)__popcll(m);
+    }
+    if (lds_only)
+        lds_barrier();                                            // (global requests stay in flight)
+    else
+        __syncthreads();
+    u32 count = 0u, mybase[kPasses];
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        mybase[p] = count;
+        for (u32 w = 0; w < kCT / kWave; ++w) {
+            const u32 v = s_wsum[(u32)p * (kCT / kWave) + w];
+            mybase[p] += w < wave ? v : 0u;
+            count += v;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const u32 t = (u32)p * kCT + tid;
+        if (t < nt)
+            s_rk[t] = ((mybase[p] + before[p]) << 1) | keep[p];
+    }
+    if (tid == 0)
+        s_rk[nt] = count << 1;
+    if (wave == 0) {
+        const u64 excl = lookback(status, gid, count);
+        if (lane == 0)
+            *s_prefix = excl;
+    }
+    return count;
 }
 
 // Unit j of a group sits in wave w = j / (64 rows), register row i = (j / 64) % rows, lane j % 64, with
@@ -534,28 +583,58 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
         const u32 j0 = wave * span + lane;
         CSGN_STAMP(1);
 
+        // A chunk of a large ciphertext knows its survivors before it has read a single unit: its keep bytes are
+        // loaded FIRST, and count, look-back and offsets run under the unit loads (LDS-only barriers: nothing waits
+        // for the units until the stores) -- and the groups behind it learn its count at once.
+        // (Not in the wide build: one workgroup per CU has nobody to overlap with, and the extra live range spills.)
+        constexpr bool kEarly = R <= kCR;
+        u32 keep[kPasses], count = 0u;
+        auto large_keep = [&]() {
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                const u32 t = (u32)p * kCT + tid;
+                keep[p] = 0u;
+                if (t < nt) {
+                    keep[p] = 1u;                                 // no decision made: the chunk is copied as it is
+                    if (a.large_ready) {
+                        const u64 g = tb + t;
+                        if (exact_large) {
+                            const u32 s = a.slot_of[g];
+                            keep[p] = ((u32)a.tab[s] - 1u == (u32)g && (a.par[s] & 1u)) ? 1u : 0u;
+                        } else {
+                            keep[p] = a.keepb[g];
+                        }
+                    }
+                }
+            }
+        };
+        if (kEarly && large) {
+            large_keep();
+            count = rank_and_place<kPasses>(keep, nt, tid, lane, wave, s_wsum, s_rk, a.status, gid, &s_prefix, true);
+        }
         // 1. the group's units -> registers
         Unit reg[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const u32 j = j0 + (u32)i * kWave;
-            reg[i] = ((u32)i < rows && j < nunits) ? terms[ub + j] : unit_zero<Unit>();
+            reg[i] = ((u32)i < rows && j < nunits) ? terms[ub + j] : unit_zero<Unit>();   // (non-temporal loads: no gain, measured)
         }
-        for (u32 x = tid; x < nt; x += kCT) {
-            s_node[x] = 0ull;
-            s_head[x] = 0u;
+        if (!large) {
+            for (u32 x = tid; x < nt; x += kCT) {
+                s_node[x] = 0ull;
+                s_head[x] = 0u;
+            }
+            if (staged)
+                for (u32 x = tid; x <= ncts; x += kCT)
+                    s_coff[x] = (u32)(a.off[c0 + x] - tb);
+            __syncthreads();
         }
-        if (staged)
-            for (u32 x = tid; x <= ncts; x += kCT)
-                s_coff[x] = (u32)(a.off[c0 + x] - tb);
-        __syncthreads();
 #ifdef CSGN_COMPACT_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // so that stamp 2 - stamp 1 is the load time
         __syncthreads();
 #endif
         CSGN_STAMP(2);
 
-        u32 keep[kPasses];
         if (!large) {
             // 2. term hashes: kSub rows of unit hashes at a time through the wave's own LDS strip, then
             //    one lane per term of the strip adds its units up (DS operations of one wave run in order:
@@ -726,69 +805,17 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
                 }
             }
             CSGN_STAMP(5);
-        } else {
-#pragma unroll
-            for (int p = 0; p < kPasses; ++p) {
-                const u32 t = (u32)p * kCT + tid;
-                keep[p] = 0u;
-                if (t < nt) {
-                    keep[p] = 1u;                                 // no decision made: the chunk is copied as it is
-                    if (a.large_ready) {
-                        const u64 g = tb + t;
-                        if (exact_large) {
-                            const u32 s = a.slot_of[g];
-                            keep[p] = ((u32)a.tab[s] - 1u == (u32)g && (a.par[s] & 1u)) ? 1u : 0u;
-                        } else {
-                            keep[p] = a.keepb[g];
-                        }
-                    }
-                }
-            }
         }
         CSGN_STAMP(6);
-        // ranks of the survivors: per pass the waves' ballots, then one look at all the wave counts
-        u32 before[kPasses];
-#pragma unroll
-        for (int p = 0; p < kPasses; ++p) {
-            const u64 m = __ballot(keep[p] != 0u);
-            before[p] = (u32)__popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0)
-                s_wsum[(u32)p * (kCT / kWave) + wave] = (u32)__popcll(m);
-        }
-        __syncthreads();
-        u32 count = 0u;
-        {
-            u32 mybase[kPasses];
-#pragma unroll
-            for (int p = 0; p < kPasses; ++p) {
-                mybase[p] = count;
-                for (u32 w = 0; w < kCT / kWave; ++w) {
-                    const u32 v = s_wsum[(u32)p * (kCT / kWave) + w];
-                    mybase[p] += w < wave ? v : 0u;
-                    count += v;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < kPasses; ++p) {
-                const u32 t = (u32)p * kCT + tid;
-                if (t < nt)
-                    s_rk[t] = ((mybase[p] + before[p]) << 1) | keep[p];
-            }
-            if (tid == 0)
-                s_rk[nt] = count << 1;
-        }
+        if (!kEarly && large)
+            large_keep();
+        if (!(kEarly && large))
+            count = rank_and_place<kPasses>(keep, nt, tid, lane, wave, s_wsum, s_rk, a.status, gid, &s_prefix, false);
         CSGN_STAMP(7);
-        // where the group's survivors go
-        // (Round 5: the look-back by the whole workgroup -- thread t reads the status of group gid - 1 - t, the kCT nearest
-        // predecessors in one round trip instead of up to eight windows of 64 -- changed nothing, 0.322 against 0.30-0.31
-        // ms: the 8.7 us a group spends here are not the walk, they are the wait for the SLOWEST of the up to 511 groups
-        // in flight before it to publish its count.)
-        if (wave == 0) {
-            const u64 excl = lookback(a.status, gid, count);
-            if (lane == 0)
-                s_prefix = excl;
-        }
-        __syncthreads();
+        if (kEarly && large)
+            lds_barrier();
+        else
+            __syncthreads();
         const u64 prefix = s_prefix;
         CSGN_STAMP(8);
         // The next ticket, taken by the last wave while the others write; its descriptor is loaded before
@@ -855,13 +882,11 @@ struct LargeArgs {
     u64 *tab;                // {tag}[2 per term]: the partitions' tags; exact path: the open-addressing table
     u32 *par;                // {index in the ciphertext}[2 per term] beside the tags; exact path: class parities
     u32 *slot_of;            // the partitions' cursors at the head of each ciphertext's share; exact path: a term's slot
-    u64 *joined;             // {term, its representative} of every term that joined a class
     unsigned char *keepb;    // one byte per term: 1 = it survives
     u64 tag_mask;
     Geom g;
     u32 dL;
-    u32 lg;                  // lanes per pair of the verify kernel: 2^lg >= min(U, 64)
-    FastDiv dGU, dTpi;       // k_cl_hash: by min(U, 64) lanes per term, by 64 / that terms per wave instruction
+    FastDiv dGU, dTpi;       // by min(U, 64) lanes per term, by 64 / that terms per wave instruction
 };
 
 struct Chunk {
@@ -1061,15 +1086,24 @@ __global__ void __launch_bounds__(kScatterThreads) k_cl_scatter(LargeArgs a)
 // One workgroup per partition: its pairs go to LDS, are chained into buckets by tag (ONE exchange on the
 // bucket's head, as in the main kernel) and every pair walks its bucket: the smallest index with the same
 // tag is the class's representative, the class's size mod 2 decides.  Only terms that do NOT survive
-// write their keep byte (k_cl_hash set it); a term that joined a class is listed for k_cl_verify.
+// write their keep byte (k_cl_hash set it).  Every unit of a term that joined a class is then compared with
+// the same unit of its representative (min(U, 64) lanes a pair, four pairs in flight per lane group): a
+// difference is a hash collision between unequal terms and sends the call's large ciphertexts to the exact path.
+template <typename Unit>
 __global__ void __launch_bounds__(256) k_cl_dedup(LargeArgs a)
 {
+    constexpr int kFly = 4;
     __shared__ u64 s_tag[kPartCap];
     __shared__ u32 s_idx[kPartCap], s_next[kPartCap], s_head[kPartCap];
+    __shared__ u32 s_njoin;
     if (a.ctrl[kCtrlCollision] != 0ull)
         return;
     const u64 nparts = a.ctrl[kCtrlParts];
-    const u32 tid = threadIdx.x, lane = tid & (kWave - 1);
+    const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
+    const u32 tid = threadIdx.x, lane = tid & (kWave - 1), U = a.g.U;
+    const u32 GU = min(U, (u32)kWave), ppi = kWave / GU;          // lanes per pair, pairs per wave instruction
+    const u32 grp = csgn_fastdiv(lane, a.dGU), gl = lane - grp * GU;
+    bool bad = false;
     for (u64 pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
         const u64 desc = a.plist[pi];
         const u32 c = (u32)desc, q = (u32)(desc >> 32);
@@ -1080,79 +1114,98 @@ __global__ void __launch_bounds__(256) k_cl_dedup(LargeArgs a)
         u32 nb = 1u;
         while (nb < n)
             nb <<= 1;
+        if (tid == 0)
+            s_njoin = 0u;
         for (u32 x = tid; x < nb; x += 256u)
             s_head[x] = 0u;
-        for (u32 x = tid; x < n; x += 256u) {
-            s_tag[x] = a.tab[base + x];
-            s_idx[x] = a.par[base + x];
+        {
+            u64 tg[kPartCap / 256];
+            u32 ix[kPartCap / 256];
+#pragma unroll
+            for (u32 r = 0; r < kPartCap / 256; ++r) {            // (all of a lane's loads in flight together)
+                const u32 x = tid + r * 256u;
+                tg[r] = x < n ? a.tab[base + x] : 0ull;
+                ix[r] = x < n ? a.par[base + x] : 0u;
+            }
+#pragma unroll
+            for (u32 r = 0; r < kPartCap / 256; ++r) {
+                const u32 x = tid + r * 256u;
+                if (x < n) {
+                    s_tag[x] = tg[r];
+                    s_idx[x] = ix[r];
+                }
+            }
         }
         __syncthreads();
         for (u32 x = tid; x < n; x += 256u)
             s_next[x] = atomicExch(s_head + ((u32)s_tag[x] & (nb - 1u)), x + 1u);
         __syncthreads();
-        for (u32 x0 = 0; x0 < n; x0 += 256u) {
-            const u32 x = x0 + tid;
-            bool joins = false;
-            u32 mine = 0u, rep = 0u;
+        u32 jm[kPartCap / 256], jr[kPartCap / 256];               // a lane's terms that joined, and whom
+        u32 njoin = 0u;
+#pragma unroll
+        for (u32 r = 0; r < kPartCap / 256; ++r) {
+            const u32 x = tid + r * 256u;
+            jm[r] = jr[r] = 0u;
             if (x < n) {
                 const u64 tag = s_tag[x];
-                mine = rep = s_idx[x];
-                u32 cnt = 0u;
+                const u32 mine = s_idx[x];
+                u32 rep = mine, cnt = 0u;
                 for (u32 e = s_head[(u32)tag & (nb - 1u)]; e != 0u; e = s_next[e - 1u])
                     if (s_tag[e - 1u] == tag) {
                         ++cnt;
                         rep = min(rep, s_idx[e - 1u]);
                     }
-                joins = rep != mine;
-                if (joins || !(cnt & 1u))
+                if (rep != mine || !(cnt & 1u))
                     a.keepb[c_begin + mine] = 0;
+                if (rep != mine) {
+                    jm[r] = mine;
+                    jr[r] = rep;
+                    njoin |= 1u << r;
+                }
             }
-            const u64 m = __ballot(joins);
-            if (m != 0ull) {                                      // wave-uniform
-                u64 at = 0ull;
-                if (lane == 0u)
-                    at = atomicAdd(ull(a.ctrl + kCtrlJoined), (unsigned long long)__popcll(m));
-                at = (u64)__shfl((unsigned long long)at, 0, kWave);
-                if (joins)
-                    a.joined[at + __popcll(m & ((1ull << lane) - 1ull))] = (c_begin + mine) | ((c_begin + rep) << 32);
+        }
+        __syncthreads();                                          // the chains are read: heads and links become the list
+        if (__ballot(njoin != 0u) != 0ull) {                      // wave-uniform
+#pragma unroll
+            for (u32 r = 0; r < kPartCap / 256; ++r) {
+                const bool j = (njoin >> r) & 1u;
+                const u64 m = __ballot(j);
+                if (m != 0ull) {
+                    u32 at = 0u;
+                    if (lane == 0u)
+                        at = atomicAdd(&s_njoin, (u32)__popcll(m));
+                    at = __shfl(at, 0, kWave) + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                    if (j) {
+                        s_head[at] = jm[r];
+                        s_next[at] = jr[r];
+                    }
+                }
             }
         }
         __syncthreads();
-    }
-}
-
-// every unit of a term that joined a class against the same unit of the class's smallest member; a difference
-// is a hash collision between unequal terms and sends the call's large ciphertexts to the exact path
-template <typename Unit>
-__global__ void __launch_bounds__(256) k_cl_verify(LargeArgs a)
-{
-    constexpr int kFly = 4;
-    if (a.ctrl[kCtrlCollision] != 0ull)
-        return;
-    const u64 njoined = a.ctrl[kCtrlJoined];
-    const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
-    const u32 lane = threadIdx.x & (kWave - 1), U = a.g.U;
-    const u32 G = 1u << a.lg, gl = lane & (G - 1u), grp = lane >> a.lg, ppi = kWave >> a.lg;
-    const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = (u64)gridDim.x * 4u;
-    bool bad = false;
-    for (u64 j0 = wave * (ppi * kFly); j0 < njoined; j0 += nwaves * (ppi * kFly)) {
-        u64 e[kFly];
+        const u32 nj = s_njoin;
+        if (grp < ppi)
+            for (u32 j0 = (tid >> 6) * ppi * kFly; j0 < nj; j0 += 4u * ppi * kFly) {
+                u64 tm[kFly], tr[kFly];
 #pragma unroll
-        for (int i = 0; i < kFly; ++i) {
-            const u64 j = j0 + (u64)i * ppi + grp;
-            e[i] = j < njoined ? a.joined[j] : 0ull;              // (term 0 against term 0: equal)
-        }
-        for (u32 kk = gl; kk < U; kk += G) {
-            Unit x[kFly], y[kFly];
+                for (int i = 0; i < kFly; ++i) {
+                    const u32 j = j0 + (u32)i * ppi + grp;
+                    tm[i] = c_begin + (j < nj ? s_head[j] : 0u);  // (past the list: the ciphertext's first term twice)
+                    tr[i] = c_begin + (j < nj ? s_next[j] : 0u);
+                }
+                for (u32 kk = gl; kk < U; kk += GU) {
+                    Unit x[kFly], y[kFly];
 #pragma unroll
-            for (int i = 0; i < kFly; ++i) {
-                x[i] = terms[(e[i] & 0xFFFFFFFFull) * U + kk];
-                y[i] = terms[(e[i] >> 32) * U + kk];
+                    for (int i = 0; i < kFly; ++i) {
+                        x[i] = terms[tm[i] * U + kk];
+                        y[i] = terms[tr[i] * U + kk];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kFly; ++i)
+                        bad |= !unit_same(x[i], y[i]);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < kFly; ++i)
-                bad |= !unit_same(x[i], y[i]);
-        }
+        __syncthreads();
     }
     if (bad)
         a.ctrl[kCtrlCollision] = 1ull;
@@ -1248,16 +1301,12 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
         la.tab = l.tab;
         la.par = l.par;
         la.slot_of = l.slot_of;
-        la.joined = l.joined;
         la.keepb = l.keepb;
         la.tag_mask = tag_mask;
         la.g = g;
         la.dL = (u32)dL;
         la.dGU = csgn_fastdiv_make(min(U, (u32)kWave));
         la.dTpi = csgn_fastdiv_make((u32)kWave / min(U, (u32)kWave));
-        la.lg = 0u;
-        while ((1u << la.lg) < min(U, (u32)kWave))
-            ++la.lg;
         const u32 grid = (u32)min(ng, (u64)2048);
         k_cl_hash<Unit><<<grid, 256, 0, s>>>(la);
         // (per call: the attribute belongs to the current device's copy of the kernel)
@@ -1265,8 +1314,7 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
                                      (int)scatter_lds_bytes())) != hipSuccess)
             return e;
         k_cl_scatter<<<(u32)min(ng + total_terms / kStripeTerms, (u64)512), kScatterThreads, scatter_lds_bytes(), s>>>(la);
-        k_cl_dedup<<<(u32)min(ng + total_terms / (kPartTerms / 2), (u64)1024), 256, 0, s>>>(la);
-        k_cl_verify<Unit><<<min(grid, 1024u), 256, 0, s>>>(la);
+        k_cl_dedup<Unit><<<(u32)min(ng + total_terms / (kPartTerms / 2), (u64)1024), 256, 0, s>>>(la);
         // (no-ops unless a partition overflowed or unequal terms shared a hash)
         k_cl_clear<<<min(grid, 256u), 256, 0, s>>>(la);
         k_cl_insert<<<min(grid, 256u), 256, 0, s>>>(la);

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""A/B of the compaction kernel's knobs on the 4096 x 1024-term cases (dev tool)."""
-import os, sys, subprocess
-for env in ({}, {"CSGN_COMPACT_STAGGER_US": "8"}, {"CSGN_COMPACT_STAGGER_US": "16"}, {"CSGN_COMPACT_STAGGER_US": "24"},
-            {"CSGN_COMPACT_GRID": "768"}, {"CSGN_COMPACT_GRID": "1024"}):
-    print("==", env or "defaults", flush=True)
-    out = subprocess.run([sys.executable, "tools/bench_compact.py", "--only", "4096 x 1024 terms"], env=dict(os.environ, **env),
-                         capture_output=True, text=True).stdout
-    print("\n".join(l[:150] for l in out.splitlines() if l.startswith("compact")), flush=True)
+"""tools/bench_compact.py against two builds of libcsgn_hip.so, alternating on one box (dev tool).
+usage: ab_compact.py <libA> <libB> [bench_compact arguments]"""
+import os, subprocess, sys
+for rnd in range(2):
+    for lib in sys.argv[1:3]:
+        env = dict(os.environ, CSGN_HIP_LIB=os.path.abspath(lib))
+        r = subprocess.run([sys.executable, "tools/bench_compact.py"] + sys.argv[3:], env=env, capture_output=True, text=True)
+        for l in r.stdout.splitlines():
+            if l.startswith("compact"):
+                print(f"{os.path.basename(lib):<18} {l[:150]}", flush=True)
+        if r.returncode:
+            print(r.stderr[-400:])
