@@ -2,7 +2,10 @@
 """Where a compaction group's time goes (dev tool): builds libcsgn_hip with -DCSGN_COMPACT_STAMPS into
 /tmp, runs the 4096 x 1024-term case once warm and prints the mean time between the main kernel's phase stamps.
 
-    python tools/prof_compact_phases.py [dup_fraction [batch terms]]
+    python tools/prof_compact_phases.py [dup_fraction [batch terms [max_terms]]]
+
+max_terms 0 = bound unknown: ciphertexts beyond one workgroup's group take the hash-partition path and the stamps are
+those of their chunks.
 """
 import os
 import subprocess
@@ -28,6 +31,7 @@ hip = HipPath(0)
 n, dl, batch, terms = 1247, 20, 4096, 1024
 if len(sys.argv) > 3:
     batch, terms = int(sys.argv[2]), int(sys.argv[3])
+bound = int(sys.argv[4]) if len(sys.argv) > 4 else terms
 w = hip.synth_fill(11, n, 0, batch * terms * dl).view(batch, terms, dl)
 distinct = max(1, int(round(terms * (1.0 - frac))))
 if distinct < terms:
@@ -42,7 +46,7 @@ extra = 16 * 8 * (ngroups * 2 + 64)
 scratch = torch.zeros(nbytes + extra, dtype=torch.uint8, device=hip.device)
 out, off_out = hip.empty_words(total * dl), hip.empty_words(batch + 1)
 for _ in range(5):
-    hip.compact_ragged(n, w, off, total_terms=total, max_terms=terms, out=out, off_out=off_out, scratch=scratch, sync=False)
+    hip.compact_ragged(n, w, off, total_terms=total, max_terms=bound, out=out, off_out=off_out, scratch=scratch, sync=False)
 torch.cuda.synchronize()
 st = scratch[nbytes: nbytes + ngroups * 16 * 8].view(torch.int64).cpu().numpy().reshape(ngroups, 16)
 st = st[st[:, 0] != 0]                                            # the groups that ran
