@@ -607,6 +607,34 @@ def secondary_suite(hip, budget_s: float = 25.0):
         case(f"compact_{int(frac * 100)}pct", f"mod-2 compaction (extension), 4096 ciphertexts x 1024 terms, {int(frac * 100)} % duplicate terms, N={n}",
              compact(frac))
 
+    def compact_large():
+        # ciphertexts beyond one workgroup's group: pairs dealt to hash partitions, terms read twice
+        B, T = 4, 1 << 20
+        w = hip.synth_fill(63, n, 0, B * T * dl)
+        off = torch.arange(0, (B + 1) * T, T, dtype=torch.int64, device=hip.device)
+        out, off_out = hip.empty_words(B * T * dl), hip.empty_words(B + 1)
+        scratch = torch.empty(int(lib.csgn_compact_scratch_bytes(n, B, B * T)), dtype=torch.uint8, device=hip.device)
+        run = lambda: hip.compact_ragged(n, w, off, total_terms=B * T, max_terms=0, out=out, off_out=off_out,
+                                         scratch=scratch, sync=False)
+        secs = timed(run)
+        kept = int(hip.download(off_out)[-1])
+        ok = kept == B * T and bool(torch.equal(out, w))                 # distinct terms: nothing cancels, nothing moves
+        # ... and the same path against the oracle where it finishes in a second: 3 x 6000 terms drawn from 3000
+        Ts = 6000
+        small = hip.synth_fill(64, n, 0, 3 * Ts * dl).view(3, Ts, dl)
+        g = torch.Generator(device=hip.device)
+        g.manual_seed(64)
+        src = torch.randint(0, Ts // 2, (3, Ts // 2), device=hip.device, generator=g)
+        small[:, Ts // 2:, :] = torch.gather(small[:, :Ts // 2, :], 1, src.unsqueeze(-1).expand(-1, -1, dl))
+        small = small.reshape(-1)
+        so, soo = hip.compact_ragged(n, small, torch.arange(0, 4 * Ts, Ts, dtype=torch.int64, device=hip.device), total_terms=3 * Ts)
+        soo = hip.download(soo)
+        ok = ok and all(np.array_equal(hip.download(so[int(soo[i]) * dl:int(soo[i + 1]) * dl]), orc.compact(n, el(small, i, Ts * dl)))
+                        for i in range(3))
+        return 8 * dl * (B * T + kept), secs, ok
+    case("compact_large", f"mod-2 compaction (extension), 4 ciphertexts x 2^20 distinct terms (hash partitions: terms read twice), N={n}",
+         compact_large)
+
     for nb, dk in ((4096, 32), (N_BITS, D_KEY)):
         case(f"config5_graph_tape_n{nb}", c5(nb, dk) + "; TAPE (every value materialised, one kernel per node)", config5(nb, dk, 0))
     return rows

@@ -70,7 +70,7 @@ def test_bench_contract_line_on_the_gpu():
     for name in ("config5_graph_compiled_n4096", "config5_graph_compiled_n1247", "config5_graph_tape_n4096",
                  "config5_graph_tape_n1247", "mul_1x1", "add_1024", "decrypt_1024", "permute_1m", "encrypt_keyed_1m",
                  "mul_ragged_mean8_kernel", "mul_ragged_mean8_async", "mul_ragged_mean16_kernel", "mul_ragged_mean16_async",
-                 "compact_0pct", "compact_50pct", "add_ragged_singles", "add_ragged_singles_bounded", "decrypt_ragged_singles",
+                 "compact_0pct", "compact_50pct", "compact_large", "add_ragged_singles", "add_ragged_singles_bounded", "decrypt_ragged_singles",
                  "decrypt_ragged_singles_bounded"):
         assert name in sec, name
         row = sec[name]
