@@ -354,9 +354,37 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
     const u32 n = c < batch ? group_count(off, c, g, large) : 0u;
     const u64 before = c < batch ? block_base + gpos[c] : 0ull;   // groups started before c
     if (large) {
-        const u32 slot = atomicAdd(&s_nlarge, 1u);
-        s_lc[slot] = c;
-        s_lbefore[slot] = before;
+        const u64 o0 = off[c], o1 = off[c + 1];
+        if (n <= 16u) {
+            // a few chunks (hence one or two partitions, one stripe): the ciphertext's own thread writes them -- a batch of
+            // thousands of such ciphertexts is 256 threads a block at work, not a wave walking a list
+            const PartGeom pg = part_geom(o1 - o0);
+            const u32 nst = (u32)((o1 - o0 + kStripeTerms - 1) / kStripeTerms);
+            const u64 at = atomicAdd(ull(ctrl + kCtrlChunks), (unsigned long long)n);
+            const u64 pat = atomicAdd(ull(ctrl + kCtrlParts), (unsigned long long)(1u << pg.lp));
+            const u64 sat = atomicAdd(ull(ctrl + kCtrlStripes), (unsigned long long)nst);
+            for (u32 i = 0; i < n; ++i) {
+                GroupDesc d;
+                d.tb = o0 + (u64)i * g.capT;
+                d.te = min(d.tb + g.capT, o1);
+                d.c0 = c;
+                d.c1 = c + 1u;
+                d.chunk = i;
+                d.large = 1u;
+                groups[before + i] = d;
+                chunks[at + i] = (u64)c | ((u64)i << 32);
+            }
+            for (u32 j = 0; j < nst; ++j)
+                slist[sat + j] = (u64)c | ((u64)j << 32);
+            for (u32 q = 0; q < (1u << pg.lp); ++q) {
+                plist[pat + q] = (u64)c | ((u64)q << 32);
+                cursor[o0 + (u64)q * cursor_stride(o1 - o0, pg.lp)] = 0u;
+            }
+        } else {
+            const u32 slot = atomicAdd(&s_nlarge, 1u);
+            s_lc[slot] = c;
+            s_lbefore[slot] = before;
+        }
     }
     __syncthreads();
     const u32 nlarge = s_nlarge;
@@ -368,14 +396,15 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
         s_at[threadIdx.x][2] = atomicAdd(ull(ctrl + kCtrlStripes), (unsigned long long)((t + kStripeTerms - 1) / kStripeTerms));
     }
     __syncthreads();
-    for (u32 li = 0; li < nlarge; ++li) {
+    for (u32 li = threadIdx.x >> 6; li < nlarge; li += 4u) {       // a wave per large ciphertext: their latencies overlap
+        const u32 ln = threadIdx.x & (kWave - 1);
         const u32 lc = s_lc[li];
         const u64 o0 = off[lc], o1 = off[lc + 1], first = s_lbefore[li];
         const u32 nch = (u32)((o1 - o0 + g.capT - 1) / g.capT);
         const PartGeom pg = part_geom(o1 - o0);
         const u32 nst = (u32)((o1 - o0 + kStripeTerms - 1) / kStripeTerms);
         const u64 at = s_at[li][0], pat = s_at[li][1], sat = s_at[li][2];
-        for (u32 i = threadIdx.x; i < nch; i += 256u) {
+        for (u32 i = ln; i < nch; i += kWave) {
             GroupDesc d;
             d.tb = o0 + (u64)i * g.capT;
             d.te = min(d.tb + g.capT, o1);
@@ -386,9 +415,9 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
             groups[first + i] = d;
             chunks[at + i] = (u64)lc | ((u64)i << 32);
         }
-        for (u32 j = threadIdx.x; j < nst; j += 256u)
+        for (u32 j = ln; j < nst; j += kWave)
             slist[sat + j] = (u64)lc | ((u64)j << 32);
-        for (u32 q = threadIdx.x; q < (1u << pg.lp); q += 256u) {
+        for (u32 q = ln; q < (1u << pg.lp); q += kWave) {
             plist[pat + q] = (u64)lc | ((u64)q << 32);
             cursor[o0 + (u64)q * cursor_stride(o1 - o0, pg.lp)] = 0u;
         }
@@ -911,24 +940,42 @@ __device__ inline Chunk chunk_of(const LargeArgs &a, u64 ci)
 // l + 64, ...), 64 / U terms per wave instruction -- whole consecutive terms, 60 of 64 lanes busy at N=1247 -- and
 // eight such instructions in flight.  The unit hashes meet in the wave's own LDS strip (DS operations of one
 // wave run in order: no barrier), where one lane per term adds them up, writes the term's hash and sets its
-// keep byte (both coalesced).  The next chunk's descriptor is fetched while this one streams.
+// keep byte (both coalesced).  The next piece's descriptor is fetched while this one streams.
 template <typename Unit>
 __global__ void __launch_bounds__(256) k_cl_hash(LargeArgs a)
 {
     constexpr int kFly = 8;
     __shared__ u64 s_strip[4][kFly][kWave];
-    const u64 nchunks = a.ctrl[kCtrlChunks];
     const Unit *__restrict__ terms = static_cast<const Unit *>(a.terms);
     const u32 lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, U = a.g.U;
     const u32 GU = min(U, (u32)kWave), tpi = kWave / GU, tpw = tpi * kFly;
     const u32 grp = csgn_fastdiv(lane, a.dGU), gl = lane - grp * GU;
     const bool live = grp < tpi;
-    if (blockIdx.x >= nchunks)
+    // a workgroup's piece of work: a quarter of a stripe (2048 terms: eleven turns of 4 x 48 terms at N=1247, the last
+    // one two thirds full; by chunks of 1024 terms every sixth turn ran a third full)
+    constexpr u32 kPiece = kStripeTerms / 4;
+    // (piece pi = quarter pi / stripes of stripe pi % stripes: the first quarters -- all there is of a ciphertext of under
+    // 2048 terms -- are dealt over the whole grid)
+    const u64 nstripes = a.ctrl[kCtrlStripes], npieces = nstripes * 4u;
+    auto piece_of = [&](u64 pi) {
+        const u64 quarter = pi / nstripes;
+        const u64 desc = a.slist[pi - quarter * nstripes];
+        Chunk k;
+        k.c = (u32)desc;
+        k.c_begin = a.off[k.c];
+        k.c_terms = a.off[k.c + 1] - k.c_begin;
+        const u64 t_lo = min(k.c_terms, (desc >> 32) * kStripeTerms + quarter * kPiece);
+        const u64 t_hi = min(k.c_terms, min(((desc >> 32) + 1u) * kStripeTerms, t_lo + kPiece));
+        k.tb = k.c_begin + t_lo;
+        k.nt = (u32)(t_hi - t_lo);
+        return k;
+    };
+    if (blockIdx.x >= npieces)
         return;
-    Chunk k = chunk_of(a, blockIdx.x);
-    for (u64 ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
+    Chunk k = piece_of(blockIdx.x);
+    for (u64 ci = blockIdx.x; ci < npieces; ci += gridDim.x) {
         const u64 cn = ci + gridDim.x;
-        const Chunk next = chunk_of(a, cn < nchunks ? cn : ci);
+        const Chunk next = piece_of(cn < npieces ? cn : ci);
         for (u32 t0 = wave * tpw; t0 < k.nt; t0 += 4u * tpw) {
             u64 acc[kFly];
 #pragma unroll
