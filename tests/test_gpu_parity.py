@@ -1475,12 +1475,13 @@ def test_compaction_large_ciphertexts(hip, oracle):
     assert int(off_out[6]) - int(off_out[5]) <= 100
 
 
-@pytest.mark.parametrize("n", [1247, 4096, 129, 64])
+@pytest.mark.parametrize("n", [1247, 4096, 129, 64, 16500])
 def test_compaction_large_ciphertexts_partition_overflow_and_shapes(hip, oracle, n):
     """The partitions of a large ciphertext (pairs dealt by the top bits of the term hash, 2048 to a partition at
     most): one term repeated thousands of times overflows its partition and the call takes the exact path; sizes
     on both sides of every partition count (one, two, many partitions); several large ciphertexts in one batch
-    with small ones between them.  Term lists identical to the checker's."""
+    with small ones between them; N = 16 500 has terms of 129 sixteen-byte units -- more than a wave's lanes, which then
+    loop over a term's units.  Term lists identical to the checker's."""
     rng = np.random.default_rng(n)
     dl = oracle.default_len(n)
     heavy = _dup_ciphertext(oracle, rng, n, 60, 3000, 9000).reshape(-1, dl)
