@@ -52,7 +52,7 @@ constexpr u32 kMaxGroupTerms = 1024, kMaxGroupTermsWide = 1792;     // LDS: 24 B
 
 // control words (u64 each) at the head of the scratch block; zeroed, with the status granules, per call
 // (kCtrlCollision: a partition overflowed or unequal terms shared a hash -- the exact path decides the large ciphertexts)
-enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlParts = 4, kCtrlStripes = 5, kCtrlWords = 32 };
+enum { kCtrlTicket = 0, kCtrlGroups = 1, kCtrlChunks = 2, kCtrlCollision = 3, kCtrlParts = 4, kCtrlStripes = 5, kCtrlGeomB = 6, kCtrlWords = 32 };
 
 // Partitions of a large ciphertext of T terms: P = 2^lp >= T / 1024 of them, picked by the top lp bits of a term's hash,
 // each with room for cap = 2T / P <= 2048 {hash, index} pairs (twice the mean; P <= 2 cannot overflow at all).
@@ -80,9 +80,15 @@ struct Geom {
     u32 capT;       // terms per group at most
     u32 wshift;     // log2 of the window: ciphertexts whose first terms share a window may share a group
     u32 bigT;       // a ciphertext of more terms than this is a group by itself: capT - window
+    u32 wany;       // the window is NOT a power of two: capT - (the caller's bound on a ciphertext), divided by dW
+    FastDiv dW;
 };
 
-Geom make_geom(u32 U, bool wide = false)
+// max_terms: the caller's bound on one ciphertext's terms (0 = unknown).  A run of ciphertexts that begin in one window of
+// W terms and are at most bigT terms each spans fewer than W + bigT <= capT terms.  Without a bound W = bigT = capT / 2:
+// runs of tiny ciphertexts make HALF-full groups (2^22 single terms: 8192 groups of 512, each paying a whole group's
+// look-back and latencies).  With a small bound m the window is capT - m: 2^20 ciphertexts of four terms are 4112 groups.
+Geom make_geom(u32 U, bool wide = false, u64 max_terms = 0)
 {
     Geom g;
     g.U = U;
@@ -91,8 +97,17 @@ Geom make_geom(u32 U, bool wide = false)
     while ((2u << g.wshift) <= g.capT / 2)
         ++g.wshift;
     g.bigT = g.capT - (1u << g.wshift);
+    g.wany = 0;
+    g.dW = csgn_fastdiv_make(1u);
+    if (max_terms != 0 && max_terms < g.bigT) {
+        g.bigT = (u32)max_terms;
+        g.wany = 1;
+        g.dW = csgn_fastdiv_make(g.capT - g.bigT);
+    }
     return g;
 }
+// the window a ciphertext's first term lies in (term indices stay under 2^31: csgn::compact)
+__device__ inline u32 window_of(u64 o, const Geom &g) { return g.wany ? csgn_fastdiv((u32)o, g.dW) : (u32)(o >> g.wshift); }
 
 // groups a call can produce at most: one per window, two per big ciphertext, the chunks of large ones
 u64 group_bound(u64 total_terms, const Geom &g) { return 4 + 10 * (total_terms / g.capT + 1); }
@@ -101,7 +116,8 @@ struct GroupDesc;
 struct Layout {
     GroupDesc *groups;
     u64 *ctrl, *status, *chunks, *partial, *hash, *tab, *plist, *slist;
-    u32 *gpos, *par, *slot_of;
+    u32 *gpos, *gposB, *par, *slot_of;
+    u64 *partialB;
     unsigned char *keepb;
     size_t bytes, head_bytes;
 };
@@ -124,7 +140,9 @@ Layout make_layout(void *scratch, u64 batch, u64 total_terms, const Geom &g)
     l.groups = reinterpret_cast<GroupDesc *>(take(ng * 32));
     l.chunks = reinterpret_cast<u64 *>(take(ng * 8));
     l.gpos = reinterpret_cast<u32 *>(take(batch * 4));
+    l.gposB = reinterpret_cast<u32 *>(take(batch * 4));
     l.partial = reinterpret_cast<u64 *>(take((batch / 256 + 2) * 8));
+    l.partialB = reinterpret_cast<u64 *>(take((batch / 256 + 2) * 8));
     l.hash = reinterpret_cast<u64 *>(take(total_terms * 8));
     l.tab = reinterpret_cast<u64 *>(take(total_terms * 16));
     l.par = reinterpret_cast<u32 *>(take(total_terms * 8));
@@ -223,7 +241,7 @@ __device__ inline u32 group_count(const u64 *__restrict__ off, u32 c, Geom g, bo
     bool start = c == 0;
     if (!start) {
         const u64 om = off[c - 1];
-        start = t > g.bigT || o0 - om > g.bigT || (o0 >> g.wshift) != (om >> g.wshift);
+        start = t > g.bigT || o0 - om > g.bigT || window_of(o0, g) != window_of(om, g);
     }
     if (!start)
         return 0u;
@@ -243,40 +261,82 @@ __device__ inline u32 wave_incl_scan(u32 v)
 
 // (also clears the call's control words and status granules: `head`, nothing of which is touched before
 // the next kernel of the call)
-__global__ void __launch_bounds__(256) k_cg_count(u32 batch, const u64 *__restrict__ off, Geom g,
-                                                  u32 *__restrict__ gpos, u64 *__restrict__ partial,
+// DUAL: the caller gave a bound on one ciphertext's terms and geometry A was cut to it (make_geom).  A caller whose
+// ciphertexts break the bound must still get a legal result from a scratch block sized without it: every ciphertext over
+// the bound is a group of its own, and thousands of them would overrun the group arrays.  So the groups are counted under
+// the unbounded geometry B as well, every block leaves word of any ciphertext between the two limits (bit 63 of its B
+// count), and k_cg_scan / k_cg_fill take geometry B for the whole call if any block did.
+constexpr u64 kViolation = 1ull << 63;
+__global__ void __launch_bounds__(256) k_cg_count(u32 batch, const u64 *__restrict__ off, Geom gA, Geom gB, u32 dual,
+                                                  u32 *__restrict__ gposA, u32 *__restrict__ gposB,
+                                                  u64 *__restrict__ partialA, u64 *__restrict__ partialB,
                                                   u64 *__restrict__ head, u64 head_words)
 {
-    __shared__ u32 wsum[4];
+    __shared__ u32 wsum[2][4];
+    __shared__ u32 s_viol;
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < head_words; i += (u64)gridDim.x * 256u)
         head[i] = 0ull;
+    if (threadIdx.x == 0)
+        s_viol = 0u;
     const u32 c = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     bool large;
-    const u32 n = c < batch ? group_count(off, c, g, large) : 0u;
-    const u32 incl = wave_incl_scan(n);
-    if (lane == kWave - 1)
-        wsum[wave] = incl;
-    __syncthreads();
-    u32 base = 0, tot = 0;
-    for (u32 w = 0; w < 4; ++w) {
-        base += w < wave ? wsum[w] : 0u;
-        tot += wsum[w];
+    const u32 nA = c < batch ? group_count(off, c, gA, large) : 0u;
+    const u32 nB = (dual && c < batch) ? group_count(off, c, gB, large) : 0u;
+    const u32 inclA = wave_incl_scan(nA), inclB = dual ? wave_incl_scan(nB) : 0u;
+    if (lane == kWave - 1) {
+        wsum[0][wave] = inclA;
+        wsum[1][wave] = inclB;
     }
-    if (c < batch)
-        gpos[c] = base + incl - n;                    // block-local; k_cg_fill adds the block's base
-    if (threadIdx.x == 0 && blockIdx.x < (batch + 255u) / 256u)   // (blocks past the batch only clear)
-        partial[blockIdx.x] = tot;
+    __syncthreads();
+    if (dual && c < batch) {
+        const u64 t = off[c + 1] - off[c];
+        if (t > gA.bigT && t <= gB.bigT)
+            s_viol = 1u;
+    }
+    u32 baseA = 0, totA = 0, baseB = 0, totB = 0;
+    for (u32 w = 0; w < 4; ++w) {
+        baseA += w < wave ? wsum[0][w] : 0u;
+        totA += wsum[0][w];
+        baseB += w < wave ? wsum[1][w] : 0u;
+        totB += wsum[1][w];
+    }
+    if (c < batch) {
+        gposA[c] = baseA + inclA - nA;                // block-local; k_cg_fill adds the block's base
+        if (dual)
+            gposB[c] = baseB + inclB - nB;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < (batch + 255u) / 256u) { // (blocks past the batch only clear)
+        partialA[blockIdx.x] = totA;
+        if (dual)
+            partialB[blockIdx.x] = (u64)totB | (s_viol ? kViolation : 0ull);
+    }
 }
 
-__global__ void __launch_bounds__(1024) k_cg_scan(u64 nblocks, u64 *__restrict__ partial, u64 *__restrict__ ctrl)
+// (beyond 262 144 ciphertexts) exclusive scan of the blocks' counts, left in partialA whichever geometry it is for
+__global__ void __launch_bounds__(1024) k_cg_scan(u64 nblocks, u64 *__restrict__ partialA, const u64 *__restrict__ partialB,
+                                                  u32 dual, u64 *__restrict__ ctrl)
 {
     __shared__ u64 part[1024];
+    __shared__ u32 s_flag;
     const u32 tid = threadIdx.x;
     const u64 chunk = (nblocks + 1023) / 1024;
     const u64 c0 = min(nblocks, (u64)tid * chunk), c1 = min(nblocks, c0 + chunk);
+    if (tid == 0)
+        s_flag = 0u;
+    __syncthreads();
+    if (dual) {
+        bool v = false;
+        for (u64 c = c0; c < c1; ++c)
+            v = v || (partialB[c] & kViolation) != 0ull;
+        if (v)
+            s_flag = 1u;
+    }
+    __syncthreads();
+    const bool useB = s_flag != 0u;
     u64 sum = 0;
     for (u64 c = c0; c < c1; ++c)
-        sum += partial[c];
+        sum += useB ? (partialB[c] & ~kViolation) : partialA[c];
     part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
@@ -287,12 +347,13 @@ __global__ void __launch_bounds__(1024) k_cg_scan(u64 nblocks, u64 *__restrict__
             run += v;
         }
         ctrl[kCtrlGroups] = run;
+        ctrl[kCtrlGeomB] = useB ? 1ull : 0ull;
     }
     __syncthreads();
     u64 run = part[tid];
     for (u64 c = c0; c < c1; ++c) {
-        const u64 v = partial[c];
-        partial[c] = run;
+        const u64 v = useB ? (partialB[c] & ~kViolation) : partialA[c];
+        partialA[c] = run;
         run += v;
     }
 }
@@ -309,8 +370,9 @@ struct GroupDesc {
 // {te, c1} (the same thread for a group of one).  The chunks of a LARGE ciphertext are written by the whole
 // block together (a ciphertext of 2^20 terms has a thousand of them), listed a second time (any order) for
 // k_cl_hash, and its partitions are listed for k_cl_dedup with their cursors zeroed.
-__global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restrict__ off, Geom g,
-                                                 const u32 *__restrict__ gpos, const u64 *__restrict__ partial,
+__global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restrict__ off, Geom gA, Geom gB, u32 dual,
+                                                 const u32 *__restrict__ gposA, const u32 *__restrict__ gposB,
+                                                 const u64 *__restrict__ partial, const u64 *__restrict__ partialB,
                                                  GroupDesc *__restrict__ groups, u64 *__restrict__ chunks,
                                                  u64 *__restrict__ plist, u64 *__restrict__ slist, u32 *__restrict__ cursor,
                                                  u64 *__restrict__ ctrl, u32 scanned)
@@ -321,19 +383,25 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
     __shared__ u32 s_nlarge, s_lc[256];
     __shared__ u64 s_lbefore[256], s_at[256][3];
     u64 block_base = 0;
+    bool useB = false;                                            // (see k_cg_count: the caller's bound did not hold)
     if (threadIdx.x == 0)
         s_nlarge = 0u;
     if (scanned) {
         block_base = partial[blockIdx.x];
+        useB = dual && ctrl[kCtrlGeomB] != 0ull;
     } else {
-        u64 mine = 0, all = 0;
+        u64 mineA = 0, allA = 0, mineB = 0, allB = 0;
         for (u32 b = threadIdx.x; b < gridDim.x; b += 256u) {
-            const u64 v = partial[b];
-            all += v;
-            mine += b < blockIdx.x ? v : 0ull;
+            const u64 vA = partial[b], vB = dual ? partialB[b] : 0ull;
+            allA += vA;
+            mineA += b < blockIdx.x ? vA : 0ull;
+            allB += vB & ~kViolation;
+            mineB += b < blockIdx.x ? (vB & ~kViolation) : 0ull;
+            useB = useB || (vB & kViolation) != 0ull;
         }
+        useB = __syncthreads_or(useB ? 1 : 0) != 0;
         const bool want_total = blockIdx.x == 0;
-        u64 red = want_total ? all : mine;
+        u64 red = useB ? (want_total ? allB : mineB) : (want_total ? allA : mineA);
         for (int o = 32; o > 0; o >>= 1)
             red += (u64)__shfl_down(red, o, 64);
         if ((threadIdx.x & (kWave - 1)) == 0)
@@ -348,6 +416,8 @@ __global__ void __launch_bounds__(256) k_cg_fill(u32 batch, const u64 *__restric
         __syncthreads();
         block_base = s_base;
     }
+    const Geom g = useB ? gB : gA;
+    const u32 *__restrict__ gpos = useB ? gposB : gposA;
     __syncthreads();                                              // (s_nlarge is zero for everybody)
     const u32 c = blockIdx.x * 256u + threadIdx.x;
     bool large = false, next_large;
@@ -1316,18 +1386,22 @@ hipError_t compact_launch(u32 U, u64 dL, u64 batch, u64 total_terms, u64 max_ter
     // the wide build only on the caller's word that some ciphertext needs it and none is larger still
     const Geom narrow = make_geom(U), wide_g = make_geom(U, true);
     const bool wide_groups = max_terms > narrow.capT && max_terms <= wide_g.capT;
-    const Geom g = wide_groups ? wide_g : narrow;
+    const Geom g = wide_groups ? make_geom(U, true, max_terms) : make_geom(U, false, max_terms);
     const Layout l = make_layout(scratch, batch, total_terms, g);
     hipError_t e;
     // the call's head (control words + status granules) is cleared by the first kernel itself: no memset
     // node (see zero_words), no launch of its own
     const u32 cblocks = ceil_div_u64(batch, 256);
-    k_cg_count<<<max(cblocks, (u32)min((u64)256, l.head_bytes / 8 / 2048)), 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.ctrl, l.head_bytes / 8);
+    // (gB: the geometry without the caller's bound, taken by the whole call if a ciphertext breaks the bound: k_cg_count)
+    const Geom gB = make_geom(U, wide_groups);
+    const u32 dual = g.wany;
+    k_cg_count<<<max(cblocks, (u32)min((u64)256, l.head_bytes / 8 / 2048)), 256, 0, s>>>((u32)batch, off, g, gB, dual, l.gpos, l.gposB, l.partial,
+                                                                                        l.partialB, l.ctrl, l.head_bytes / 8);
     const bool scan = cblocks > 1024u;
     if (scan)
-        k_cg_scan<<<1, 1024, 0, s>>>(cblocks, l.partial, l.ctrl);
-    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, l.gpos, l.partial, l.groups, l.chunks, l.plist, l.slist, l.slot_of, l.ctrl,
-                                       scan ? 1u : 0u);
+        k_cg_scan<<<1, 1024, 0, s>>>(cblocks, l.partial, l.partialB, dual, l.ctrl);
+    k_cg_fill<<<cblocks, 256, 0, s>>>((u32)batch, off, g, gB, dual, l.gpos, l.gposB, l.partial, l.partialB, l.groups, l.chunks, l.plist, l.slist,
+                                       l.slot_of, l.ctrl, scan ? 1u : 0u);
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
 

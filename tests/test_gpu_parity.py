@@ -1495,6 +1495,33 @@ def test_compaction_large_ciphertexts_partition_overflow_and_shapes(hip, oracle,
     _check_compaction(hip, oracle, n, cts)
 
 
+@pytest.mark.parametrize("batch", [50_000, 300_000])
+def test_compaction_small_bound_fills_the_groups_and_survives_being_broken(hip, oracle, batch):
+    """With a small bound on a ciphertext's terms the runs of tiny ciphertexts are cut into FULL groups (window = group
+    size - bound) instead of half-full ones.  A caller who breaks such a bound everywhere (ciphertexts of up to 6 terms
+    promised to have at most 2) would make every ciphertext a group of its own and overrun the group arrays of a scratch
+    block sized without the bound: the plan notices and the whole call takes the unbounded geometry.  Both the honest
+    and the broken promise give the checker's term lists (300 000 ciphertexts: the plan's scan kernel)."""
+    n, dl = 1247, 20
+    rng = np.random.default_rng(batch)
+    for top, bound in ((3, 3), (6, 2), (3, 40)):
+        counts = rng.integers(0, top + 1, size=batch)
+        total = int(counts.sum())
+        words_ = oracle.synth(91, n, 0, total * dl).reshape(total, dl)
+        off = csr(counts)
+        starts = off[:-1].astype(np.int64)
+        twin = np.nonzero(counts >= 2)[0][::3]                        # every third such ciphertext: its second term = its first
+        words_[starts[twin] + 1] = words_[starts[twin]]
+        out, off_out = hip.compact_ragged(n, hip.upload(words_.reshape(-1)), hip.upload(off), total_terms=total, max_terms=bound)
+        out, off_out = hip.download(out).reshape(-1, dl), hip.download(off_out)
+        want_counts = counts.copy()
+        want_counts[twin] -= 2
+        assert np.array_equal(np.diff(off_out.astype(np.int64)), want_counts), (top, bound)
+        keep = np.ones(total, dtype=bool)
+        keep[starts[twin]] = keep[starts[twin] + 1] = False
+        assert np.array_equal(out, words_[keep]), (top, bound)
+
+
 @pytest.mark.parametrize("n,sizes", [(1247, [1100, 1792, 3, 1500, 0, 1025, 700]), (4096, [766, 321, 768, 5, 500])])
 def test_compaction_wide_groups(hip, oracle, n, sizes):
     """Ciphertexts between one workgroup's usual group (1024 terms at N=1247, 320 at N=4096) and the wide build's
