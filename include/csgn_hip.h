@@ -294,11 +294,14 @@ int csgn_decrypt_sum_uniform(uint64_t n_bits, uint64_t batch, uint64_t t1, uint6
  * knows it, 0 = unknown.  It is a launch hint only: a ciphertext up to one workgroup's group (1024
  * terms at N=1247, 320 at N=4096) is read once and deduplicated in LDS; with a bound of up to 1792 / 768
  * terms a wide build of the same kernel (48 units per lane, one workgroup per CU) does the same for the
- * whole batch; larger ciphertexts go through a hash table in HBM (terms read twice) whose kernels are
- * skipped when the bound rules them out.  A ciphertext that exceeds a
- * non-zero bound it was promised to respect is copied through uncompacted (still a legal result).
- * Bit-exact for every input: terms are matched by a 48-bit hash tag first and then compared in
- * full; a tag collision between unequal terms only costs time.
+ * whole batch; larger ciphertexts are deduplicated by hash partitions (terms read twice; an exact table
+ * in HBM behind a partition overflow or a hash collision) whose kernels are skipped when the bound rules
+ * them out; a bound under half a group lets runs of small ciphertexts fill their groups.  A ciphertext
+ * that exceeds a non-zero group-sized bound it was promised to respect is copied through uncompacted
+ * (still a legal result); a broken small bound sends the call back to the plan it would have had without one.
+ * Bit-exact for every input: terms are matched by a hash (48-bit tags inside a group, 64 bits between the
+ * chunks of a larger ciphertext) first and then compared in full; a collision between unequal terms only
+ * costs time.
  * Limits: fewer than 2^31 ciphertexts and terms per call (CSGN_ERR_UNSUPPORTED).
  * Never called on a parity path. */
 size_t csgn_compact_scratch_bytes(uint64_t n_bits, uint64_t batch, uint64_t total_terms);
