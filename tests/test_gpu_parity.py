@@ -2178,6 +2178,55 @@ def test_circuit_compiled_with_encrypt_nodes(hip, oracle, flags):
         lib.csgn_circuit_destroy(c)
 
 
+@pytest.mark.parametrize("flags", [0, 31])
+def test_circuit_compaction_of_values_beyond_one_workgroup_inside_a_graph(hip, oracle, flags):
+    """csgn_circuit_compact on a value whose static bound is beyond the wide build's group ((a + b)^2 with 46-term
+    inputs: 8464 product terms): the hash-partition kernels (1024-thread scatter with 120 KB of LDS set by
+    hipFuncSetAttribute, dedup, the no-op exact path) are captured into the circuit's graph.  92 terms survive of every
+    element (the cross terms cancel), words equal the oracle's on two input sets, tape and compiled."""
+    import torch
+    from csgn_amd.capi import check
+    lib = hip.lib
+    n, batch, T = 1247, 3, 46
+    dl = oracle.default_len(n)
+    c = C.c_void_p()
+    check(lib.csgn_circuit_create(n, batch, C.byref(c)))
+    def new(fn, *a):
+        v = C.c_uint32()
+        check(fn(c, *a, C.byref(v)))
+        return v.value
+    ia, ib = new(lib.csgn_circuit_input, T), new(lib.csgn_circuit_input, T)
+    s_ = new(lib.csgn_circuit_add, ia, ib)
+    x = new(lib.csgn_circuit_compact, new(lib.csgn_circuit_mul, s_, s_))
+    if flags:
+        check(lib.csgn_circuit_optimize(c, flags))
+        check(lib.csgn_circuit_output(c, x))
+    check(lib.csgn_circuit_build(c))
+    try:
+        for rnd in range(2):
+            ha = oracle.synth(300 + rnd, n, 0, batch * T * dl)
+            hb = oracle.synth(310 + rnd, n, 0, batch * T * dl)
+            for v, h in ((ia, ha), (ib, hb)):
+                d = hip.upload(h)
+                check(lib.csgn_memcpy_d2d(lib.csgn_circuit_value(c, v), d.data_ptr(), h.size * 8, hip.stream))
+            check(lib.csgn_circuit_run(c, hip.stream))
+            torch.cuda.synchronize()
+            bound = int(lib.csgn_circuit_value_total_terms(c, x))
+            off = hip.empty_words(batch + 1)
+            check(lib.csgn_memcpy_d2d(off.data_ptr(), lib.csgn_circuit_value_offsets(c, x), (batch + 1) * 8, hip.stream))
+            w = hip.empty_words(bound * dl)
+            check(lib.csgn_memcpy_d2d(w.data_ptr(), lib.csgn_circuit_value(c, x), bound * dl * 8, hip.stream))
+            off, w = hip.download(off), hip.download(w)
+            for b in range(batch):
+                sh, _ = oracle.add(ha[b * T * dl:(b + 1) * T * dl], hb[b * T * dl:(b + 1) * T * dl])
+                ph, _ = oracle.mul(n, sh, sh)
+                want = oracle.compact(n, ph)
+                assert want.size // dl == 2 * T
+                assert np.array_equal(w[int(off[b]) * dl:int(off[b + 1]) * dl], want), (rnd, b)
+    finally:
+        lib.csgn_circuit_destroy(c)
+
+
 @pytest.mark.parametrize("n,d,batch", [(1247, 16, 300), (4096, 32, 40), (65, 4, 1000)])
 def test_circuit_graph_ragged_values(hip, oracle, n, d, batch):
     _ragged_circuit(hip, oracle, n, d, batch, 0, True)
