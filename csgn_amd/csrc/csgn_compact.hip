@@ -9,27 +9,29 @@
 //
 // Shape of the work: 8*dL*T_in bytes read, 8*dL*T_out written; everything else must stay small beside
 // that.  The batch is cut into GROUPS of consecutive ciphertexts of at most capT terms (one ciphertext
-// of up to capT terms, or a run of smaller ones), and one 1024-thread workgroup takes one group:
-//   1. its units go from HBM into REGISTERS, lane l holding units l, l+1024, ... (coalesced 16-byte
-//      loads, R of them in flight per lane) -- they are read ONCE;
-//   2. every unit is hashed where it sits (64x64->128 multiply-fold with a position tweak) and the
-//      U partial hashes of a term are summed in LDS (ds_add_u64);
-//   3. one lane per term inserts {48-bit tag, term index} into the ciphertext's own region of an
-//      open-addressing table in LDS (2 slots per term): ds_cmpst claims an empty slot, ds_min keeps
-//      the SMALLEST index of a tag class, ds_xor counts the class's parity;
-//   4. every unit whose term joined somebody else's slot is compared with the same unit of that
-//      representative (one 16-byte load from L2, U lanes per term, coalesced).  A difference means a
-//      tag collision between unequal terms: the group is redone with full compares inside the probe
-//      loop (exact, slow, practically never taken: 2^-48 per pair);
+// of up to capT terms, or a run of smaller ones), and one 512-thread workgroup (two share a CU) takes one
+// group:
+//   1. its units go from HBM into REGISTERS, wave w owning a contiguous span of 64-unit rows (coalesced
+//      16-byte loads, R = 20 of them in flight per lane) -- they are read ONCE;
+//   2. every unit is hashed where it sits (UMAC's NH step with a position tweak: two v_mad_u64_u32) and
+//      the U unit hashes of a term are summed inside the wave through an LDS strip;
+//   3. one lane per term chains {48-bit tag, term index} into a bucket of its ciphertext (ONE ds_wrxchg
+//      on the bucket's head, as many buckets as terms) and walks its bucket: the smallest index with
+//      the same tag is the class's representative, the class's size mod 2 decides;
+//   4. every unit whose term joined a class is compared with the same unit of the representative (one
+//      16-byte load from L2, U lanes per term, coalesced).  A difference means a tag collision between
+//      unequal terms: the walk is redone with full word compares inside the bucket (exact, slow,
+//      practically never taken: 2^-48 per pair);
 //   5. survivors = representatives of odd classes; a ballot scan ranks them; the group's output
 //      offset comes from a decoupled look-back over one 8-byte {flag, count} granule per group
 //      (tickets are handed out in group order, so a group only ever waits for groups that are
 //      already running);
-//   6. the registers are stored to their final place (16-byte stores, U lanes per term).
+//   6. the registers are stored to their final place (16-byte non-temporal stores, U lanes per term).
 // Ciphertexts of more than capT terms ("large") cannot be deduplicated inside one workgroup: their
 // terms are hashed first (k_cl_hash: the first read) and every {hash, index} pair is dealt by the top
-// bits of the hash to one of T/1024 PARTITIONS of its ciphertext (one atomic on the partition's cursor,
-// one 12-byte scatter -- no read-modify-write of a table in HBM); a partition fits LDS and is
+// bits of the hash to one of T/1024 PARTITIONS of its ciphertext (sorted by partition in LDS a stripe of
+// 8192 terms at a time, one atomic on a partition's cursor per stripe -- no read-modify-write of a table in
+// HBM); a partition fits LDS and is
 // deduplicated there like a group (k_cl_scatter, k_cl_dedup), leaving one keep byte per term, the terms that
 // joined a class compared with their representatives.  The main kernel then moves the chunks of
 // a large ciphertext exactly like a group, reading the keep bytes instead of making the decision:
