@@ -1495,6 +1495,30 @@ def test_compaction_large_ciphertexts_partition_overflow_and_shapes(hip, oracle,
     _check_compaction(hip, oracle, n, cts)
 
 
+def test_compaction_of_a_ciphertext_of_more_than_two_million_terms(hip):
+    """One ciphertext of 2^21 + 5000 terms (4096 hash partitions: beyond what a stripe sorts in LDS, so every term takes
+    its partition's cursor itself) between two small ones: 1500 planted pairs of equal terms cancel, everything else
+    stays in order.  Checked on the device against the construction (the oracle would need minutes)."""
+    import torch
+    n, dl = 1247, 20
+    T = (1 << 21) + 5000
+    counts = [3, T, 2]
+    total = sum(counts)
+    w = hip.synth_fill(97, n, 0, total * dl).view(total, dl)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+    picks = (torch.randperm(T, generator=g)[:3000] + 3).to(hip.device)      # 1500 disjoint pairs inside the long ciphertext
+    a, b = picks[:1500], picks[1500:]
+    w[b] = w[a]
+    keep = torch.ones(total, dtype=torch.bool, device=hip.device)
+    keep[a] = False
+    keep[b] = False
+    out, off_out = hip.compact_ragged(n, w.reshape(-1), hip.upload(csr(counts)), total_terms=total)
+    off_out = hip.download(off_out)
+    assert list(np.diff(off_out.astype(np.int64))) == [3, T - 3000, 2]
+    assert torch.equal(out.view(-1, dl), w[keep])
+
+
 @pytest.mark.parametrize("batch", [50_000, 300_000])
 def test_compaction_small_bound_fills_the_groups_and_survives_being_broken(hip, oracle, batch):
     """With a small bound on a ciphertext's terms the runs of tiny ciphertexts are cut into FULL groups (window = group
