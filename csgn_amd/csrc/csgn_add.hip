@@ -65,6 +65,17 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
             }
             __syncthreads();
         }
+        // A window whose 256 pairs all have the shape of its first one (the common ragged batch: equal ciphertexts handed
+        // over as CSR -- a million 1 + 1 sums): a lane's pair is a DIVISION away, not the nine dependent LDS reads of the
+        // binary search.  (Past the end of the batch the offsets repeat: the last window searches.)
+        u32 uni_t = 0;                                          // terms of a pair's sum if the window is uniform, else 0
+        if (!whole && !two) {
+            const u32 i = threadIdx.x;
+            const u64 dl0 = w_l[1] - w_l[0], dr0 = w_r[1] - w_r[0];
+            const bool same = w_l[i + 1] - w_l[i] == dl0 && w_r[i + 1] - w_r[i] == dr0;
+            if (__syncthreads_and(same ? 1 : 0) && dl0 + dr0 < (1ull << 20))
+                uni_t = (u32)(dl0 + dr0);                       // (256 of them stay under 2^32; 0 = runs of empty pairs: search)
+        }
         u32 p[M];
         u64 src[M];                                             // unit index into L (from_l) or R
         bool from_l[M], live[M];
@@ -93,12 +104,17 @@ __global__ void __launch_bounds__(256) k_add_ragged_flat(const Unit *__restrict_
                 } else if (!whole && term >= s_o1) {
                     // largest j in [0, kAddWin] with w_l[j] + w_r[j] <= term
                     u32 lo = 0, hi = kAddWin + 1u;
+                    if (uni_t) {                                // (workgroup-uniform)
+                        const u64 ahead = term - (w_l[0] + w_r[0]);
+                        lo = ahead >= (u64)uni_t * kAddWin ? kAddWin : (u32)ahead / uni_t;
+                    } else {
 #pragma unroll
-                    for (int step = 0; step < 9; ++step) {
-                        const u32 mid = (lo + hi) >> 1;
-                        const bool le = w_l[mid] + w_r[mid] <= term;
-                        lo = le ? mid : lo;
-                        hi = le ? hi : mid;
+                        for (int step = 0; step < 9; ++step) {
+                            const u32 mid = (lo + hi) >> 1;
+                            const bool le = w_l[mid] + w_r[mid] <= term;
+                            lo = le ? mid : lo;
+                            hi = le ? hi : mid;
+                        }
                     }
                     if (lo == kAddWin && pw + kAddWin < batch) { // beyond the window (long runs of empty pairs)
                         p[m] = csr_gallop(offOut, pw + kAddWin, batch, term);
