@@ -61,7 +61,7 @@ hipError_t mul_ragged_plan(u64 batch, const u64 *offL, const u64 *offR, u64 *off
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
                       u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes = nullptr, u64 operand_terms = 0,
-                      const u64 *d_gate = nullptr);
+                      const u64 *d_gate = nullptr, const u64 *d_huge = nullptr);
 // plan + multiply enqueued back to back, nothing read back (csgn_mul_ragged_async); d_plan: mul_ragged_async_plan_words(batch)
 u64 mul_ragged_async_plan_words(u64 batch);
 hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R, const u64 *offR,

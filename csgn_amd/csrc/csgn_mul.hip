@@ -217,6 +217,86 @@ constexpr u32 kWin = 256;                                       // pairs per off
 constexpr u64 kHugeTerms = 65536;        // a product of this many terms is recorded by the plan (10 MB at N=1247)
 constexpr u64 kHugeRecords = 32;            // = the rows of MulPlanNotes::rec
 
+// csgn_mul_ragged_async's huge pairs.  The planned multiply gives a pair of kHugeTerms product terms and more the uniform
+// kernels on its own sub-buffers -- no lookup inside what is usually nearly all of a skewed batch's output -- but only the
+// HOST can launch those, and the async call never sees the plan.  So the records the plan kernel left on the device
+// ({pair, offL, offR, t1, t2, offOut}, up to kHugeRecords of them) are multiplied by the FIRST workgroups of the CSR
+// kernel's own launch (mul_huge_tiles; a launch of its own in front of the CSR kernel was 29 + 18 us on the skewed batch where
+// the CSR kernel alone took 40: the singles' latency-bound tail has to run BESIDE the huge pair): persistent workgroups over
+// 32 KiB tiles of the records' outputs, a lane's (left term, right term, place) from two multiply-high divisions, eight
+// operand pairs in flight per lane, non-temporal stores -- and the CSR kernel skips every turn that lies inside a recorded
+// pair (huge_record_valid: the same test on both sides).  A record is taken if its product stays under 2^32 units and
+// inside the real output (the gate).
+constexpr u32 kHugeTile = 2048;                                 // units per tile
+__device__ inline bool huge_record_valid(u64 t1, u64 t2, u64 o0, u32 U, u64 real_terms)
+{
+    const u64 c = t1 * t2;
+    return c >= kHugeTerms && t1 < (1ull << 31) && t2 < (1ull << 31) && c * U < (1ull << 32) && o0 + c <= real_terms;
+}
+// is pair `pw` (shape t1 x t2, output at o0) one of the recorded huge pairs that mul_huge_tiles writes?
+__device__ inline bool huge_pair_recorded(const u64 *__restrict__ huge, u32 pw, u64 t1, u64 t2, u64 o0, u32 U, u64 real_terms)
+{
+    if (!huge_record_valid(t1, t2, o0, U, real_terms))
+        return false;
+    const u32 n = (u32)min(huge[0], kHugeRecords);
+    bool found = false;
+    for (u32 i = 0; i < n; ++i)
+        found = found || huge[1 + i * 6] == (u64)pw;
+    return found;
+}
+template <typename Unit>
+__device__ inline void mul_huge_tiles(const Unit *__restrict__ L, const Unit *__restrict__ R, Unit *__restrict__ out,
+                                      const u64 *__restrict__ huge, const u64 *__restrict__ gate, u32 U, FastDiv dU,
+                                      u32 first_tile, u32 tile_stride)
+{
+    constexpr int kPer = kHugeTile / 256;
+    __shared__ u64 s_first[kHugeRecords + 1];
+    const u64 real_terms = gate[0];
+    const u32 n = real_terms ? (u32)min(huge[0], kHugeRecords) : 0u;
+    if (n == 0u)
+        return;
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (u32 i = 0; i < n; ++i) {
+            const u64 *rec = huge + 1 + i * 6;
+            s_first[i] = run;
+            if (huge_record_valid(rec[3], rec[4], rec[5], U, real_terms))
+                run += (rec[3] * rec[4] * U + kHugeTile - 1) / kHugeTile;
+        }
+        s_first[n] = run;
+    }
+    __syncthreads();
+    const u64 tiles = s_first[n];
+    for (u64 tile = first_tile; tile < tiles; tile += tile_stride) {
+        u32 i = 0;
+        while (i + 1u < n && s_first[i + 1u] <= tile)                // (workgroup-uniform; records without tiles are passed over)
+            ++i;
+        const u64 *rec = huge + 1 + i * 6;
+        const u64 l0 = rec[1], r0 = rec[2], t2 = rec[4], o0 = rec[5];
+        const u32 cU = (u32)(rec[3] * t2 * U);
+        const FastDiv d2 = csgn_fastdiv_make((u32)t2);
+        const u32 rel0 = (u32)(tile - s_first[i]) * kHugeTile + threadIdx.x;
+        Unit a[kPer], b[kPer];
+#pragma unroll
+        for (int m = 0; m < kPer; ++m) {
+            const u32 rel = min(rel0 + (u32)m * 256u, cU - 1u);     // (lanes past the end redo the last unit: loads unconditional)
+            const u32 term = csgn_fastdiv(rel, dU), k = rel - term * U;
+            const u32 ii = csgn_fastdiv(term, d2), jj = term - ii * (u32)t2;
+            a[m] = L[(l0 + ii) * U + k];
+            b[m] = R[(r0 + jj) * U + k];
+        }
+#pragma unroll
+        for (int m = 0; m < kPer; ++m)
+            asm volatile("" : "+v"(a[m]), "+v"(b[m]));               // (all loads issued before the first store)
+#pragma unroll
+        for (int m = 0; m < kPer; ++m) {
+            const u32 rel = rel0 + (u32)m * 256u;
+            if (rel < cU)
+                unit_store<Unit, true>(out + o0 * U + rel, a[m] & b[m]);
+        }
+    }
+}
+
 template <typename Unit, int C, int M>
 __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict__ L,
                                                          const u64 *__restrict__ offL,
@@ -226,7 +306,8 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
                                                          const u64 *__restrict__ offOut, u32 batch,
                                                          u64 unit_base, u64 total_units, u32 U, FastDiv dU,
                                                          u32 pf_pairs, const u64 *__restrict__ d_gate,
-                                                         u32 skip_t1, u32 skip_t2, u32 xcd_group = 0)
+                                                         u32 skip_t1, u32 skip_t2, u32 xcd_group = 0,
+                                                         const u64 *__restrict__ d_huge = nullptr, u32 huge_blocks = 0)
 {
     static_assert(C % M == 0, "chunks per workgroup must be a multiple of the chunks per turn");
     // csgn_mul_ragged_async: the grid was sized for the caller's bound; the real end of the output is
@@ -236,10 +317,28 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         total_units = min(total_units, d_gate[0] * U);
     __shared__ u64 w_out[kWin + 1], w_l[kWin + 1], w_r[kWin + 2];
     __shared__ u32 s_next;
-    const u32 bid = xcd_grouped_block(blockIdx.x, gridDim.x, xcd_group);
+    // (csgn_mul_ragged_async) the launch's first huge_blocks workgroups multiply the recorded huge pairs, the rest is the CSR
+    // kernel proper
+    if (huge_blocks != 0u && blockIdx.x < huge_blocks) {
+        mul_huge_tiles<Unit>(L, R, out, d_huge, d_gate, U, dU, blockIdx.x, huge_blocks);
+        return;
+    }
+    const u32 bid = xcd_grouped_block(blockIdx.x - huge_blocks, gridDim.x - huge_blocks, xcd_group);
     const u64 g_begin = unit_base + (u64)bid * (256u * C);
     if (g_begin >= total_units)
         return;
+    // (csgn_mul_ragged_async) a workgroup whose whole span lies inside a recorded huge pair has nothing to do -- and learns
+    // so from the records, before the search for its first pair
+    if (d_huge) {
+        const u32 nrec = (u32)min(d_huge[0], kHugeRecords);
+        const u64 span_end = min(g_begin + 256u * C, total_units);
+        for (u32 i = 0; i < nrec; ++i) {
+            const u64 *rec = d_huge + 1 + i * 6;
+            const u64 t1 = rec[3], t2 = rec[4], o0 = rec[5];
+            if (o0 * U <= g_begin && span_end <= (o0 + t1 * t2) * U && huge_record_valid(t1, t2, o0, U, d_gate[0]))
+                return;
+        }
+    }
     const u64 term0 = g_begin / U;                              // workgroup-uniform
     const u32 r0blk = (u32)(g_begin - term0 * U);
     u32 pw = wave_find(offOut, 0u, batch, term0);               // the same answer in every wave
@@ -275,6 +374,9 @@ __global__ void __launch_bounds__(256) k_mul_ragged_flat(const Unit *__restrict_
         const u64 last_term = term0 + csgn_fastdiv(r0blk + (u32)(turn_end - g_begin) - 1u, dU);
         const bool whole = last_term < s_o1;
         const bool two = !whole && last_term < s_o2;            // a turn that crosses ONE pair boundary: no window
+        // (csgn_mul_ragged_async) a turn inside a huge pair that mul_huge_tiles has written: nothing to do here
+        if (d_huge && whole && huge_pair_recorded(d_huge, pw, s_l1 - s_l0, s_r1 - s_r0, s_o0, U, d_gate[0]))
+            continue;
         // pairs of the size classes (t1 <= skip_t1, t2 <= skip_t2) were written by their own launches
         // (mul_ragged, "size classes"): a turn inside such pairs has nothing to do here
         if (skip_t1 && (whole || two)) {
@@ -1577,7 +1679,7 @@ hipError_t offsets_checksum(u64 batch, const u64 *offL, const u64 *offR, const u
 hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, const u64 *R,
                       const u64 *offR, u64 *out, const u64 *offOut, u64 max_t1, u64 max_t2,
                       u64 total_out_terms, hipStream_t s, const MulPlanNotes *notes, u64 operand_terms,
-                      const u64 *d_gate)
+                      const u64 *d_gate, const u64 *d_huge)
 {
     const u64 dL = (n_bits + 63) / 64;
     if (batch == 0 || max_t1 == 0 || max_t2 == 0 || total_out_terms == 0)
@@ -1745,6 +1847,15 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     // million: 1.7 against 4.0).  Auto (-1): where the range averages 16 product terms a pair and more (below).
     const int coop_mode = csgn::tune(TUNE_RAGGED_COOP);
     const bool coop_ok = coop_mode != 0 && pair_bound * U < (1ull << 28) && skip_t1 == 0;
+    // csgn_mul_ragged_async with the plan's records at hand: the huge pairs by the launch's first workgroups (mul_huge_tiles), the CSR kernel around them
+    // -- where the CSR kernel is what the (one) range gets; the wave-cooperative kernel has no skip and takes everything
+    const u64 *huge_csr = nullptr;
+    if (d_gate && d_huge && csgn::tune(TUNE_RAGGED_FLAT) == 0) {
+        const u64 all_terms = total_units / U;
+        const bool coop_all = coop_ok && (coop_mode == 1 || all_terms >= 32u * batch);
+        if (!coop_all)
+            huge_csr = d_huge;
+    }
     auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
         const u64 range_units = range_end - range_begin;
         // (the average is taken WITHOUT the largest product the shapes allow: one 1024 x 1024 pair among 65 535 singles
@@ -1765,6 +1876,8 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
         for (u64 u0 = range_begin; u0 < range_end && result == hipSuccess; u0 += per_launch) {
             const u64 nu = (range_end - u0 < per_launch) ? range_end - u0 : per_launch;
             const u32 blocks = ceil_div_u64(nu, 256u * (u32)chunks);
+            // (the huge pairs' workgroups ride in front of the range's FIRST launch: 1024 of them, four to a CU)
+            const u32 hb = (huge_csr && u0 == range_begin && range_begin == 0) ? 1024u : 0u;
             if (touch)
                 k_touch_ragged<<<2048, 256, 0, s>>>(reinterpret_cast<const u32 *>(L), offL,
                                                    reinterpret_cast<const u32 *>(R), offR, offOut, (u32)batch,
@@ -1818,14 +1931,14 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
 #define CSGN_RAGGED_FLAT(CH, MM)                                                                    \
     do {                                                                                            \
         if (wide)                                                                                   \
-            k_mul_ragged_flat<unit16, CH, MM><<<blocks, 256, 0, s>>>(                               \
+            k_mul_ragged_flat<unit16, CH, MM><<<blocks + hb, 256, 0, s>>>(                          \
                 reinterpret_cast<const unit16 *>(L), offL, reinterpret_cast<const unit16 *>(R), offR, \
                 reinterpret_cast<unit16 *>(out), offOut, (u32)batch, u0, u0 + nu, U, dU, pf_pairs,  \
-                d_gate, skip_t1, skip_t2, xcd_group);                                       \
+                d_gate, skip_t1, skip_t2, xcd_group, huge_csr, hb);                         \
         else                                                                                        \
-            k_mul_ragged_flat<unit8, CH, MM><<<blocks, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
+            k_mul_ragged_flat<unit8, CH, MM><<<blocks + hb, 256, 0, s>>>(L, offL, R, offR, out, offOut,  \
                                                                     (u32)batch, u0, u0 + nu, U, dU, \
-                                                                    pf_pairs, d_gate, skip_t1, skip_t2, xcd_group); \
+                                                                    pf_pairs, d_gate, skip_t1, skip_t2, xcd_group, huge_csr, hb); \
     } while (0)
 #define CSGN_RAGGED_LAUNCH(CH)                                                                      \
     do {                                                                                            \
@@ -1953,7 +2066,7 @@ hipError_t mul_ragged_async(u64 n_bits, u64 batch, const u64 *L, const u64 *offL
         }
     }
     // everything else: the CSR kernel over the caller's bound, stopping at the real end
-    return mul_ragged(n_bits, batch, L, offL, R, offR, out, offOut, 1, 1, capacity_terms, s, nullptr, 0, gate);
+    return mul_ragged(n_bits, batch, L, offL, R, offR, out, offOut, 1, 1, capacity_terms, s, nullptr, 0, gate, work + 4);
 }
 
 } // namespace csgn

@@ -3147,6 +3147,51 @@ def test_mul_ragged_async_matches_the_planned_multiply(hip, oracle, n):
             assert bool((guard == 0x5A5A5A5A).all())          # nothing was written
 
 
+@pytest.mark.parametrize("n", [129, 1247])
+def test_mul_ragged_async_huge_pairs_ride_in_the_csr_launch(hip, oracle, n):
+    """csgn_mul_ragged_async with pairs of 65 536 product terms and more: the plan kernel records up to 32 of them on the
+    device, the first workgroups of the CSR kernel's launch multiply the recorded ones tile by tile and the CSR workgroups
+    skip what lies inside them; pairs beyond the 32 records stay with the CSR kernel.  36 such pairs between singles,
+    empties and a run of small pairs, one of them last; exact, loose and insufficient capacity.  Same words and offsets
+    as plan + multiply."""
+    import torch
+    dl = oracle.default_len(n)
+    rng = np.random.default_rng(n + 7)
+    t1s, t2s = [], []
+    for k in range(36):
+        t1s += [260 + k % 3, 1, 0, 2]
+        t2s += [256 - k % 2, 1, 5, 3]
+        if k % 5 == 0:
+            t1s += list(rng.integers(0, 9, size=40))
+            t2s += list(rng.integers(0, 9, size=40))
+    t1s += [300]
+    t2s += [250]
+    t1s, t2s = np.array(t1s, dtype=np.int64), np.array(t2s, dtype=np.int64)
+    assert int((t1s * t2s >= 65536).sum()) == 37
+    offL, offR = csr(t1s.tolist()), csr(t2s.tolist())
+    L = hip.synth_fill(101, n, 0, int(offL[-1]) * dl)
+    R = hip.synth_fill(102, n, 0, int(offR[-1]) * dl)
+    dOL, dOR = hip.upload(offL), hip.upload(offR)
+    ref, ref_off = hip.mul_ragged(n, L, dOL, R, dOR)
+    total = int((t1s * t2s).sum())
+    for cap in (total, total + 12345):
+        out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, cap)
+        res = hip.mul_ragged_async_result(plan)
+        assert res[0] == total and res[4] == 0, (cap, res)
+        assert torch.equal(off, ref_off)
+        assert torch.equal(out[:total * dl], ref[:total * dl]), cap
+    guard = hip.empty_words(total * dl)
+    guard.fill_(0x5A5A5A5A)
+    out, off, plan = hip.mul_ragged_async(n, L, dOL, R, dOR, total - 1, out=guard)
+    assert hip.mul_ragged_async_result(plan)[4] == 1 and bool((guard == 0x5A5A5A5A).all())
+    # spot check against the oracle: the last pair (a recorded one or not, it is the 37th)
+    b = len(t1s) - 1
+    hl, hr = hip.download(L), hip.download(R)
+    want, _ = oracle.mul(n, hl[int(offL[b]) * dl:int(offL[b + 1]) * dl], hr[int(offR[b]) * dl:int(offR[b + 1]) * dl])
+    ro = hip.download(ref_off)
+    assert np.array_equal(hip.download(ref[int(ro[b]) * dl:int(ro[b + 1]) * dl]), want)
+
+
 def test_ragged_forms_fuzz(hip, oracle, knobs):
     """36 random CSR batches (empty operands, runs of empty pairs -- some longer than the 256-pair
     offset window of the flat kernels -- one large pair among small ones, all-singles and all-equal
