@@ -628,6 +628,8 @@ __device__ inline u32 rank_and_place(const u32 (&keep)[kPasses], u32 nt, u32 tid
     }
     if (tid == 0)
         s_rk[nt] = count << 1;
+    if (lds_only)
+        lds_barrier();                                            // (a chunk's loads read the ranks: before wave 0 goes looking back)
     if (wave == 0) {
         const u64 excl = lookback(status, gid, count);
         if (lane == 0)
@@ -748,12 +750,27 @@ __global__ void __launch_bounds__(kCT, (R <= kCR ? 2 : 1) * kCT / 256) k_compact
             large_keep();
             count = rank_and_place<kPasses>(keep, nt, tid, lane, wave, s_wsum, s_rk, a.status, gid, &s_prefix, true);
         }
-        // 1. the group's units -> registers
+        // 1. the group's units -> registers.  A chunk of a large ciphertext already knows which of its terms survive (the
+        // ranks are in LDS): the units of the others are not read a second time -- at 50 % duplicates two thirds of this
+        // kernel's bytes were reads of terms it then dropped.
         Unit reg[R];
+        if (kEarly && large) {
+            u32 jl = j0;
+            asm volatile("" : "+v"(jl));
+            UnitPos pos = walk_first(walk, jl);
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const u32 j = j0 + (u32)i * kWave;
-            reg[i] = ((u32)i < rows && j < nunits) ? terms[ub + j] : unit_zero<Unit>();   // (non-temporal loads: no gain, measured)
+            for (int i = 0; i < R; ++i) {
+                const u32 j = jl + (u32)i * kWave;
+                const bool want = (u32)i < rows && j < nunits && (s_rk[pos.t] & 1u) != 0u;
+                reg[i] = want ? terms[ub + j] : unit_zero<Unit>();
+                walk_next(walk, pos);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const u32 j = j0 + (u32)i * kWave;
+                reg[i] = ((u32)i < rows && j < nunits) ? terms[ub + j] : unit_zero<Unit>();   // (non-temporal loads: no gain, measured)
+            }
         }
         if (!large) {
             for (u32 x = tid; x < nt; x += kCT) {
