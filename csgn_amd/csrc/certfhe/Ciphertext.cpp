@@ -429,6 +429,90 @@ void Ciphertext::serialize(std::ostream &out) const
         throw std::runtime_error("certFHE::Ciphertext::serialize: write failed");
 }
 
+uint64_t Ciphertext::serializedSize() const
+{
+    requireContext(certFHEcontext);
+    resolve();
+    return 32u + len * 8u * (custom_bitlen ? 2u : 1u);
+}
+
+namespace {
+void storeU64(unsigned char *p, uint64_t v)
+{
+    for (int i = 0; i < 8; ++i)
+        p[i] = (unsigned char)(v >> (8 * i));
+}
+uint64_t loadU64(const unsigned char *p)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i)
+        v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+} // namespace
+
+uint64_t Ciphertext::serializeTo(void *buffer, uint64_t capacity) const
+{
+    const Context &ctx = requireContext(certFHEcontext);
+    const uint64_t need = serializedSize();
+    if (!buffer || capacity < need)
+        throw std::runtime_error("certFHE::Ciphertext::serializeTo: the buffer is too small");
+    unsigned char *b = static_cast<unsigned char *>(buffer);
+    memcpy(b, kWireMagic, 4);
+    const unsigned char ver_flags[4] = {1, 0, (unsigned char)(custom_bitlen ? 1 : 0), 0};
+    memcpy(b + 4, ver_flags, 4);
+    storeU64(b + 8, ctx.getN());
+    storeU64(b + 16, ctx.getD());
+    storeU64(b + 24, len);
+    unsigned char *w = b + 32;
+    if (host_v || !payload || !kHostIsLittleEndian) {
+        const uint64_t *v = getValues();
+        if (kHostIsLittleEndian)
+            memcpy(w, v, (size_t)len * 8);
+        else
+            for (uint64_t i = 0; i < len; ++i)
+                storeU64(w + 8 * i, v[i]);
+    } else if (len) {
+        // straight from HBM into the caller's memory (a page-locked buffer: the DMA engine writes it)
+        detail::downloadBytes(w, payload->ptr, (size_t)len * 8);    // (returns when the bytes are there, as for getValues())
+    }
+    if (custom_bitlen)
+        for (uint64_t i = 0; i < len; ++i)
+            storeU64(w + (len + i) * 8, host_bitlen[i]);
+    return need;
+}
+
+Ciphertext Ciphertext::deserializeFrom(const void *buffer, uint64_t bytes)
+{
+    const unsigned char *b = static_cast<const unsigned char *>(buffer);
+    if (!b || bytes < 32 || memcmp(b, kWireMagic, 4) != 0)
+        throw std::runtime_error("certFHE::Ciphertext::deserializeFrom: not a CSGN stream");
+    if (b[4] != 1 || b[5] != 0)
+        throw std::runtime_error("certFHE::Ciphertext::deserializeFrom: unsupported version");
+    const uint64_t n = loadU64(b + 8), d = loadU64(b + 16), words = loadU64(b + 24);
+    const bool with_bitlen = (b[6] & 1) != 0;
+    if (n == 0 || d == 0 || words > (1ull << 40) || bytes < 32 + words * 8 * (with_bitlen ? 2u : 1u))
+        throw std::runtime_error("certFHE::Ciphertext::deserializeFrom: implausible header or truncated buffer");
+    Context ctx(n, d);
+    const unsigned char *w = b + 32;
+    if (!with_bitlen && kHostIsLittleEndian && words % ctx.getDefaultN() == 0) {
+        Ciphertext c;
+        c.certFHEcontext = new Context(ctx);
+        // (uploadWords copies from the caller's memory and waits: the buffer may be reused at once)
+        c.publish(detail::uploadWords(reinterpret_cast<const uint64_t *>(w), words), words);
+        return c;
+    }
+    std::vector<uint64_t> v(words), bl;
+    for (uint64_t i = 0; i < words; ++i)
+        v[i] = loadU64(w + 8 * i);
+    if (with_bitlen) {
+        bl.resize(words);
+        for (uint64_t i = 0; i < words; ++i)
+            bl[i] = loadU64(w + (words + i) * 8);
+    }
+    return Ciphertext(v.data(), bl.empty() ? nullptr : bl.data(), words, ctx);
+}
+
 Ciphertext Ciphertext::deserialize(std::istream &in)
 {
     char magic[4];

@@ -439,6 +439,30 @@ static int cmd_wire(int argc, char **argv)
         threw = true;
     }
     EXPECT(threw);
+    // the buffer forms write and read the same bytes as the stream forms
+    {
+        std::stringstream ref;
+        prod.serialize(ref);
+        const std::string bytes = ref.str();
+        EXPECT(prod.serializedSize() == bytes.size());
+        std::vector<unsigned char> buf(bytes.size() + 8, 0xEE);
+        EXPECT(prod.serializeTo(buf.data(), buf.size()) == bytes.size());
+        EXPECT(memcmp(buf.data(), bytes.data(), bytes.size()) == 0 && buf[bytes.size()] == 0xEE);
+        Ciphertext p3 = Ciphertext::deserializeFrom(buf.data(), bytes.size());
+        EXPECT(p3.getLen() == prod.getLen() && sk.decrypt(p3).getValue() == 0);
+        for (uint64_t i = 0; i < prod.getLen(); ++i)
+            EXPECT(p3.getValues()[i] == prod.getValues()[i]);
+        std::stringstream oddref;
+        odd.serialize(oddref);
+        std::vector<unsigned char> ob(odd.serializedSize());
+        EXPECT(odd.serializeTo(ob.data(), ob.size()) == oddref.str().size() && memcmp(ob.data(), oddref.str().data(), ob.size()) == 0);
+        Ciphertext odd3 = Ciphertext::deserializeFrom(ob.data(), ob.size());
+        EXPECT(!odd3.hasCanonicalBitlen() && odd3.getBitlen()[1] == 9 && odd3.getValues()[1] == 2);
+        bool small_threw = false, short_threw = false;
+        try { prod.serializeTo(buf.data(), bytes.size() - 1); } catch (const std::runtime_error &) { small_threw = true; }
+        try { Ciphertext::deserializeFrom(buf.data(), bytes.size() - 1); } catch (const std::runtime_error &) { short_threw = true; }
+        EXPECT(small_threw && short_threw);
+    }
     printf("wire ok\n");
     return 0;
 }
@@ -518,6 +542,21 @@ static int cmd_wirebench()
     t = best_of(4, [&] { bulk.rewindForRead(); std::istream i(&bulk); back = Ciphertext::deserialize(i); });
     printf("wirebench deserialize 2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s\n", big_bytes / 1e6, t * 1e3, big_bytes / t / 1e9);
     EXPECT(back.getLen() == big.getLen());
+    // ... and without a stream: straight between HBM and a page-locked buffer of the caller's
+    {
+        void *pinned = nullptr, *alias = nullptr;
+        EXPECT(csgn_host_alloc(&pinned, &alias, (size_t)big_bytes + 64) == 0);
+        uint64_t wrote = 0;
+        t = best_of(4, [&] { wrote = big.serializeTo(pinned, (uint64_t)big_bytes + 64); });
+        printf("wirebench serializeTo     (pinned buffer) 2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s\n", big_bytes / 1e6, t * 1e3, big_bytes / t / 1e9);
+        EXPECT(wrote == 32 + (uint64_t)big_bytes);
+        Ciphertext back2;
+        t = best_of(4, [&] { back2 = Ciphertext::deserializeFrom(pinned, wrote); });
+        printf("wirebench deserializeFrom (pinned buffer) 2^20 terms %7.1f MB  %8.3f ms  %6.2f GB/s\n", big_bytes / 1e6, t * 1e3, big_bytes / t / 1e9);
+        EXPECT(back2.getLen() == big.getLen());
+        EXPECT(memcmp(static_cast<const char *>(pinned) + 32, bulk.store.data() + 32, 1 << 20) == 0);   // the stream form's bytes
+        csgn_host_free(pinned);
+    }
     // 160 KB ciphertexts, 200 in a row
     MemBuf sb(64 + words * 8);
     t = best_of(3, [&] { for (int k = 0; k < 200; ++k) { sb.rewindForWrite(); std::ostream o(&sb); c1k.serialize(o); } });

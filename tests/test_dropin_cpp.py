@@ -184,7 +184,10 @@ def test_wire_format_and_host_mirror_throughput(driver):
     out = run(driver, "wirebench").stdout
     assert "wirebench ok" in out
     rates = [float(ln.split("GB/s")[0].split()[-1]) for ln in out.splitlines() if "GB/s" in ln]
-    assert len(rates) == 5 and min(rates) > 0.2, out      # the per-word loops of round 3 ran at ~0.1 GB/s
+    assert len(rates) == 7 and min(rates) > 0.2, out      # the per-word loops of round 3 ran at ~0.1 GB/s
+    # the buffer forms (round 5): one copy between HBM and a page-locked buffer, no stream sink's memcpy in between
+    to_pinned = [float(ln.split("GB/s")[0].split()[-1]) for ln in out.splitlines() if "(pinned buffer)" in ln]
+    assert len(to_pinned) == 2 and min(to_pinned) > 20.0, out
 
 
 @pytest.mark.gpu
