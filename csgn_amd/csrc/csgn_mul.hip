@@ -1853,7 +1853,8 @@ hipError_t mul_ragged(u64 n_bits, u64 batch, const u64 *L, const u64 *offL, cons
     if (d_gate && d_huge && csgn::tune(TUNE_RAGGED_FLAT) == 0) {
         const u64 all_terms = total_units / U;
         const bool coop_all = coop_ok && (coop_mode == 1 || all_terms >= 32u * batch);
-        if (!coop_all)
+        // (and the 1024 workgroups in front must fit the launch: always, short of a 60 GB output)
+        if (!coop_all && ceil_div_u64(total_units, 256u * (u32)chunks) + 1024u <= kMaxBlocks256)
             huge_csr = d_huge;
     }
     auto flat_range = [&](u64 range_begin, u64 range_end, u64 range_pairs) -> hipError_t {
